@@ -1,0 +1,170 @@
+/*
+ * inquistr_hip.h — C ABI of the MI355X-native `inquiSTR call` hot path.
+ *
+ * What this boundary replaces in the reference (wdecoster/inquiSTR @ v0.13.0):
+ * the reference has no FFI; the per-locus seam is
+ *     genotype_repeat_phased(&mut IndexedReader, RepeatInterval, minlen, support)   src/call.rs:329-374
+ *     genotype_repeat_unphased(...)                                                  src/call.rs:279-327
+ * called once per locus from the serial loop (src/call.rs:150-157) or from a rayon
+ * worker (src/call.rs:115-136).  A per-locus call cannot feed a GPU, so the ABI is
+ * batch level: the host decodes BAM records (rust-htslib in the reference, the C++
+ * front end in this repo), packs them into the buffers below and asks for the two
+ * per-haplotype medians of every locus in one call.  Everything from "is this
+ * record yielded by fetch()" (src/call.rs:288,338) through call_from_cigar
+ * (src/call.rs:377-413) to median_str_length (src/call.rs:497-522) runs on the GPU.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Caller owns every buffer;
+ * the library keeps no pointer after a call returns.
+ */
+#ifndef INQUISTR_HIP_H
+#define INQUISTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INQ_ABI_VERSION 1
+
+/* ---- error codes (0 = ok, negative = failure; never throws / aborts) ---- */
+enum {
+    INQ_OK = 0,
+    INQ_ERR_ARG = -1,          /* NULL pointer, inconsistent sizes, non-monotone CSR               */
+    INQ_ERR_SUPPORT_ZERO = -2, /* support == 0: reference underflows `len/2 - 1` (src/call.rs:516) */
+    INQ_ERR_PHASE = -3,        /* a read that passes the phased filter has HP > 2:
+                                  reference `calls.get_mut(&phase).unwrap()` panics (src/call.rs:358) */
+    INQ_ERR_CIGAR_OP = -4,     /* CIGAR op code > 8: rust-htslib's cigar() panics (src/call.rs:382)  */
+    INQ_ERR_LOCUS = -5,        /* locus start < 10 (u32 underflow, src/call.rs:285,335) or end < start
+                                  (src/repeats.rs:102-104)                                           */
+    INQ_ERR_RANGE = -6,        /* pos + reference span of a read does not fit 31 bits (not a valid BAM) */
+    INQ_ERR_INDEX = -7,        /* pair_read[] or a read's CIGAR extent points outside the buffers    */
+    INQ_ERR_HIP = -8,          /* HIP runtime failure; see inq_last_error()                         */
+    INQ_ERR_NOMEM = -9,
+    INQ_ERR_NO_DEVICE = -10    /* no gfx950 device visible: the library has NO CPU fallback          */
+};
+
+/* ---- read descriptor: one 16-byte record per decoded BAM record ---------
+ * Replaces rust-htslib bam::Record accessors used on the path:
+ *   reference_start() src/call.rs:297,351,380   -> pos
+ *   mapq()            src/call.rs:299,352       -> mapq
+ *   cigar()           src/call.rs:382           -> cigar_off4 / n_cigar into inq_batch_t.cigar
+ *   aux(b"HP")        src/call.rs:482-491       -> bits&INQ_READ_HAS_HP, phase (value `as u8`)
+ *   is_accidental_2d  src/call.rs:415-459       -> bits&INQ_READ_IS_2D (host evaluates the SA string)
+ *   flag 0x4          (bam_endpos rule)         -> bits&INQ_READ_UNMAPPED
+ */
+typedef struct inq_read {
+    uint32_t cigar_off4; /* first CIGAR word of this read, in units of 4 words (16 bytes)     */
+    uint32_t n_cigar;    /* number of CIGAR ops                                               */
+    int32_t pos;         /* BAM core.pos, 0-based leftmost                                    */
+    uint8_t mapq;
+    uint8_t bits;        /* INQ_READ_* */
+    uint8_t phase;       /* HP value truncated to u8; meaningful iff INQ_READ_HAS_HP          */
+    uint8_t reserved;    /* must be 0                                                         */
+} inq_read_t;
+
+#define INQ_READ_UNMAPPED 0x01u /* BAM flag 0x4   */
+#define INQ_READ_REVERSE 0x02u  /* BAM flag 0x10  */
+#define INQ_READ_HAS_HP 0x04u   /* HP aux present */
+#define INQ_READ_IS_2D 0x08u    /* is_accidental_2d(record) == true */
+
+/* ---- one batch of loci ----------------------------------------------------
+ * cigar   : BAM-native packed ops, `len << 4 | op`, op in 0..8 = MIDNSHP=X, all reads
+ *           concatenated.  Every read starts on a 4-word boundary; the 0..3 words of
+ *           padding behind a read must be 0 (`0M`, a no-op for every rule on the path).
+ *           n_cigar_words counts the padding and is a multiple of 4.
+ * pairs   : CSR over loci.  pair_read[locus_pair_off[j] .. locus_pair_off[j+1]) are the
+ *           reads offered to locus j IN FILE ORDER (the order rc_records() yields them,
+ *           src/call.rs:294,345).  The list may be a superset of what fetch() would
+ *           yield: the device applies htslib's overlap rule itself
+ *           (pos < end_ext && bam_endpos > start_ext), so extra candidates change nothing.
+ * loci    : un-extended BED coordinates (src/repeats.rs:75-79); the ±10 extension
+ *           (src/call.rs:285-286,335-336) is applied on the device.
+ */
+typedef struct inq_batch {
+    uint64_t n_reads;
+    uint64_t n_cigar_words;
+    uint64_t n_pairs;
+    uint64_t n_loci;
+    const uint32_t *cigar;          /* [n_cigar_words], 16-byte aligned */
+    const inq_read_t *reads;        /* [n_reads]                        */
+    const uint32_t *pair_read;      /* [n_pairs] index into reads       */
+    const uint64_t *locus_pair_off; /* [n_loci + 1]                     */
+    const uint32_t *locus_start;    /* [n_loci]                         */
+    const uint32_t *locus_end;      /* [n_loci]                         */
+    uint32_t minlen;                /* -m, src/main.rs:43               */
+    uint32_t support;               /* -s, src/main.rs:47  (>= 1)       */
+    uint32_t unphased;              /* -u, src/main.rs:55  (0 / 1)      */
+    uint32_t reserved;              /* must be 0                        */
+} inq_batch_t;
+
+/* ---- results --------------------------------------------------------------
+ * phase1/phase2 : Genotype.phase1/.phase2 (src/call.rs:27-31): exact integers or
+ *                 halves, quiet NaN where the reference returns NAN (src/call.rs:499).
+ * pair_call     : optional (may be NULL) per-pair Call value (src/call.rs:67-71)
+ * pair_bits     : optional (may be NULL) per-pair INQ_PAIR_* bits
+ * n_tie_loci    : unphased only: loci whose median split (src/call.rs:312-314) cuts
+ *                 through equal values of mixed Span/Clip, where Rust's unstable sort
+ *                 makes the reference itself ambiguous; this library orders ties by
+ *                 file order (exact for <= 20 reads).
+ */
+typedef struct inq_result {
+    double *phase1;     /* [n_loci] */
+    double *phase2;     /* [n_loci] */
+    int64_t *pair_call; /* [n_pairs] or NULL */
+    uint8_t *pair_bits; /* [n_pairs] or NULL */
+    uint64_t n_tie_loci;
+} inq_result_t;
+
+#define INQ_PAIR_CLIP 0x01u    /* Call::Clip (a soft clip was counted)            */
+#define INQ_PAIR_FETCHED 0x02u /* yielded by fetch(): pos < end_ext && endpos > start_ext */
+#define INQ_PAIR_KEPT 0x04u    /* survived the read filter (src/call.rs:297-302 / 349-355) */
+
+typedef struct inq_ctx inq_ctx_t;
+
+/* Opens HIP device `device_id` (must be gfx950), creates the library's stream and
+ * scratch.  One ctx per device; a ctx serves one caller at a time. */
+int inq_ctx_create(int device_id, inq_ctx_t **out);
+void inq_ctx_destroy(inq_ctx_t *ctx);
+
+/* Host-buffer entry: batch and result point to HOST memory (pinned for best H2D).
+ * Validates the batch, uploads, runs the kernels, downloads, synchronises. */
+int inq_call_batch(inq_ctx_t *ctx, const inq_batch_t *batch, inq_result_t *result);
+
+/* Device-resident entry: every pointer in batch/result is a DEVICE pointer on the
+ * ctx's device; hip_stream is a hipStream_t (NULL = the ctx's own stream).  Enqueues
+ * only — no host synchronisation, no allocation.  result->n_tie_loci is not written;
+ * fetch it, and any domain error the kernels flagged, with inq_ctx_status() after
+ * the stream has been synchronised. */
+int inq_call_batch_device(inq_ctx_t *ctx, const inq_batch_t *batch, inq_result_t *result,
+                          void *hip_stream);
+
+/* Device-side status of the launches since the last inq_ctx_status() call: returns
+ * INQ_OK or the first domain error (INQ_ERR_PHASE / _CIGAR_OP / _LOCUS / _RANGE /
+ * _INDEX) and the tie count.  Synchronises the device. */
+int inq_ctx_status(inq_ctx_t *ctx, uint64_t *n_tie_loci);
+
+/* Kernel timing with HIP events on the launch stream (for bench.py's roofline block).
+ * which: 0 = whole inq_call_batch_device launch sequence, 1 = the CIGAR-walk kernel.
+ * Returns accumulated milliseconds and launch count since the last reset. */
+int inq_ctx_timing_enable(inq_ctx_t *ctx, int on);
+int inq_ctx_timing_read(inq_ctx_t *ctx, int which, double *total_ms, uint64_t *launches);
+int inq_ctx_timing_reset(inq_ctx_t *ctx);
+
+/* Tuning / test knobs.  key: "path" = 0 auto, 1 fused wave-per-locus, 2 two-kernel. */
+int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);
+
+/* Pinned host allocations for batch buffers. */
+int inq_alloc_pinned(size_t bytes, void **out);
+void inq_free_pinned(void *p);
+
+const char *inq_strerror(int code);
+const char *inq_backend_name(const inq_ctx_t *ctx); /* "hip:gfx950:<device name>" */
+const char *inq_last_error(const inq_ctx_t *ctx);   /* detail of the last INQ_ERR_HIP */
+int inq_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INQUISTR_HIP_H */

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def kat():
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", "kat_call.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The C oracle (test infrastructure)."""
+    from oracle import orc as _orc
+
+    _orc.build()
+    return _orc
