@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — loci/s of the `inquiSTR call` hot path on MI355X.
+
+One step = one pass of the hot path (every locus of one synthetic batch -> two medians) with
+the batch already resident in HBM.  N GPUs = N processes (torch.distributed, backend nccl = RCCL),
+loci sharded by rank with no data-path collective; the only exchange is the gather of the
+per-shard result rows to rank 0, overlapped with the next step on a second stream.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(wl, sample_loci: int):
+    """The oracle (CPU restatement, kind "port") on the first `sample_loci` loci of the same
+    workload, all host cores (OpenMP over loci = the reference's rayon par_bridge)."""
+    from inquistr_amd import synth
+    from oracle import orc
+
+    orc.build()
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    batch = synth.generate_numpy(wl, 0, sample_loci)
+    best = None
+    for _ in range(5):
+        t0 = time.perf_counter()
+        code, _res = orc.call_batch(batch, threads=threads)
+        dt = time.perf_counter() - t0
+        assert code == 0
+        best = dt if best is None else min(best, dt)
+    return {
+        "value": sample_loci / best,
+        "unit": "loci/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"first {sample_loci} loci of {wl.name} ({batch.n_pairs} reads, {int(batch.cigar_ops_per_pair().sum())} CIGAR ops), "
+        f"SoA already in host memory, best of 5, {best * 1e3:.1f} ms; arithmetic only (no BAM decode), "
+        "CPU restatement of the reference, not the Rust binary",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="unphased100k", help="phased10k | unphased100k | shard500k | expansion50k")
+    ap.add_argument("--loci-per-gpu", type=int, default=0, help="override the per-GPU shard size")
+    ap.add_argument("--cpu-sample-loci", type=int, default=10_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_latest.json"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from inquistr_amd import hipcall, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = synth.WORKLOADS[args.workload]
+    if args.workload == "shard500k":
+        # config #4: the 500k loci are the 8-GPU total; per-GPU shard fixed (weak scaling)
+        per_gpu = args.loci_per_gpu or wl.n_loci // 8
+    else:
+        per_gpu = args.loci_per_gpu or wl.n_loci
+    lo, hi = rank * per_gpu, (rank + 1) * per_gpu
+
+    ctx = hipcall.Context(local_rank)
+    shard = synth.DeviceBatch(wl, dev, lo, hi)
+    # results: two rotating [2, n] buffers (row 0 = H1, row 1 = H2) so the gather of step k overlaps step k+1
+    outs = [torch.empty(2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered = [torch.empty(world, 2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)] if (world > 1 and rank == 0) else None
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    main_stream = torch.cuda.current_stream()
+
+    from inquistr_amd.batch import InqResultC
+
+    def result_for(buf):
+        r = InqResultC()
+        r.phase1, r.phase2 = buf[0].data_ptr(), buf[1].data_ptr()
+        r.pair_call = r.pair_bits = None
+        return r
+
+    results = [result_for(b) for b in outs]
+    pending = []
+
+    def step(i):
+        k = i & 1
+        if world > 1 and len(pending) >= 2:
+            pending.pop(0).wait()  # buffer k is free again
+        ctx.call_batch_device(shard.c_batch, results[k], main_stream.cuda_stream)
+        if world > 1:
+            ev = torch.cuda.Event()
+            ev.record(main_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                glist = list(gathered[k].unbind(0)) if rank == 0 else None
+                pending.append(dist.gather(outs[k], glist, dst=0, async_op=True))
+
+    def drain():
+        while pending:
+            pending.pop(0).wait()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    rc, _ = ctx.status()
+    if rc != 0:
+        raise SystemExit(f"device status {rc}: {hipcall.strerror(rc)}")
+
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms, launches = ctx.timing_read(1)  # HIP events on the launch stream around the CIGAR-walk kernel
+    seq_ms, _ = ctx.timing_read(0)
+    ctx.timing_enable(False)
+    rc, ties = ctx.status()
+    if rc != 0:
+        raise SystemExit(f"device status {rc}: {hipcall.strerror(rc)}")
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    if rank == 0:
+        total_loci = per_gpu * world
+        alg_bytes = shard.algorithmic_bytes()
+        avg_kernel_s = kern_ms / 1e3 / max(1, launches)
+        achieved = alg_bytes / avg_kernel_s / 1e9
+        traffic = None
+        pmc_note = None
+        if os.path.exists(args.pmc_summary):
+            try:
+                pmc = json.load(open(args.pmc_summary))
+                if pmc.get("workload") == wl.name and pmc.get("loci_per_gpu") == per_gpu:
+                    traffic = pmc.get("hbm_bytes_per_launch")
+                    pmc_note = pmc.get("source")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "loci/sec genotyped (inquiSTR call hot path), bit-exact vs CPU oracle",
+            "value": total_loci * args.steps / dt_max,
+            "unit": "loci/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32/i64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{wl.name}: {per_gpu} loci/GPU x {wl.reads_per_locus} reads x ~{shard.n_ops_total / max(1, shard.n_pairs):.0f} CIGAR ops, "
+                + ("--unphased" if wl.unphased else "phased (HP)")
+                + ", device-resident SoA (L0)",
+                "loci_per_gpu": per_gpu,
+                "pairs_per_gpu": shard.n_pairs,
+                "cigar_ops_per_gpu": shard.n_ops_total,
+                "minlen": wl.minlen,
+                "support": wl.support,
+                "sharding": f"loci x {world} ranks, gather of 16 B/locus to rank 0 overlapped" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "locus_call_small",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_kernel_ms": avg_kernel_s * 1e3,
+                "avg_launch_sequence_ms": seq_ms / max(1, launches),
+                "launches_timed": launches,
+                "traffic_source": pmc_note,
+            },
+            "n_tie_loci": ties,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample_loci, per_gpu))
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

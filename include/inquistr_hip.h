@@ -152,7 +152,7 @@ int inq_ctx_timing_enable(inq_ctx_t *ctx, int on);
 int inq_ctx_timing_read(inq_ctx_t *ctx, int which, double *total_ms, uint64_t *launches);
 int inq_ctx_timing_reset(inq_ctx_t *ctx);
 
-/* Tuning / test knobs.  key: "path" = 0 auto, 1 fused wave-per-locus, 2 two-kernel. */
+/* Tuning knobs.  key: "grid_big" = workgroups launched for the deep-locus kernel (default 256). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);
 
 /* Pinned host allocations for batch buffers. */

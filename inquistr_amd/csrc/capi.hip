@@ -1,0 +1,345 @@
+// capi.hip — implementation of the C ABI in include/inquistr_hip.h on top of kernels.hip.
+// HIP only: there is no CPU fallback; without a gfx950 device every entry fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/inquistr_hip.h"
+#include "cigar_walk.h"
+#include "kernels.h"
+
+using namespace inq;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct EvTriple {
+    hipEvent_t e0, e1, e2;
+};
+
+}  // namespace
+
+struct inq_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string backend, last_err;
+    DevStatus *d_status = nullptr;
+    DevBuf worklist, sval, smeta;
+    // staging for the host-buffer entry
+    DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
+    uint32_t parity = 0;
+    uint32_t grid_big = 256;
+    bool timing = false;
+    std::vector<EvTriple> ev_pool;
+    size_t ev_used = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (ctx)->last_err = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+            return _e == hipErrorOutOfMemory ? INQ_ERR_NOMEM : INQ_ERR_HIP;                    \
+        }                                                                                      \
+    } while (0)
+
+static int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return INQ_OK;
+    if (b.p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIP_TRY(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return INQ_OK;
+}
+
+static int status_to_code(uint32_t st) {
+    if (st & ST_LOCUS) return INQ_ERR_LOCUS;
+    if (st & ST_INDEX) return INQ_ERR_INDEX;
+    if (st & ST_CIGAR_OP) return INQ_ERR_CIGAR_OP;
+    if (st & ST_RANGE) return INQ_ERR_RANGE;
+    if (st & ST_PHASE) return INQ_ERR_PHASE;
+    return INQ_OK;
+}
+
+extern "C" {
+
+int inq_abi_version(void) { return INQ_ABI_VERSION; }
+
+const char *inq_strerror(int code) {
+    switch (code) {
+    case INQ_OK: return "ok";
+    case INQ_ERR_ARG: return "invalid argument (null pointer, inconsistent sizes or non-monotone offsets)";
+    case INQ_ERR_SUPPORT_ZERO: return "support must be >= 1";
+    case INQ_ERR_PHASE: return "a read passing the phased filter has HP outside {0,1,2}";
+    case INQ_ERR_CIGAR_OP: return "CIGAR op code above 8";
+    case INQ_ERR_LOCUS: return "locus start < 10 or end < start";
+    case INQ_ERR_RANGE: return "read position plus reference span does not fit 31 bits";
+    case INQ_ERR_INDEX: return "pair or CIGAR index outside the batch buffers";
+    case INQ_ERR_HIP: return "HIP runtime error";
+    case INQ_ERR_NOMEM: return "out of device memory";
+    case INQ_ERR_NO_DEVICE: return "no gfx950 (MI355X) device available; this library has no CPU fallback";
+    default: return "unknown error";
+    }
+}
+
+int inq_ctx_create(int device_id, inq_ctx_t **out) {
+    if (!out) return INQ_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return INQ_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return INQ_ERR_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return INQ_ERR_HIP;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return INQ_ERR_NO_DEVICE;
+    inq_ctx *c = new (std::nothrow) inq_ctx();
+    if (!c) return INQ_ERR_NOMEM;
+    c->device = device_id;
+    c->backend = std::string("hip:") + prop.gcnArchName + ":" + prop.name;
+    auto fail = [&](int code) {
+        inq_ctx_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(device_id) != hipSuccess) return fail(INQ_ERR_HIP);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(INQ_ERR_HIP);
+    if (hipMalloc((void **)&c->d_status, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_NOMEM);
+    if (hipMemset(c->d_status, 0, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_HIP);
+    *out = c;
+    return INQ_OK;
+}
+
+void inq_ctx_destroy(inq_ctx_t *c) {
+    if (!c) return;
+    if (c->device >= 0) (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->worklist, &c->sval, &c->smeta, &c->cigar, &c->reads, &c->pair_read, &c->off, &c->lstart,
+                      &c->lend, &c->p1, &c->p2, &c->pcall, &c->pbits})
+        if (b->p) (void)hipFree(b->p);
+    for (auto &e : c->ev_pool) {
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+        (void)hipEventDestroy(e.e2);
+    }
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *inq_backend_name(const inq_ctx_t *c) { return c ? c->backend.c_str() : "none"; }
+const char *inq_last_error(const inq_ctx_t *c) { return c ? c->last_err.c_str() : ""; }
+
+static int check_scalars(const inq_batch_t *b, const inq_result_t *r) {
+    if (!b || !r) return INQ_ERR_ARG;
+    if (b->n_loci && (!r->phase1 || !r->phase2)) return INQ_ERR_ARG;
+    if (b->n_loci && (!b->locus_pair_off || !b->locus_start || !b->locus_end)) return INQ_ERR_ARG;
+    if (b->n_pairs && (!b->pair_read || !b->reads || !b->n_reads)) return INQ_ERR_ARG;
+    if (b->n_cigar_words && !b->cigar) return INQ_ERR_ARG;
+    if (b->n_cigar_words % 4 != 0 || b->reserved != 0 || b->unphased > 1) return INQ_ERR_ARG;
+    if (!b->n_loci && b->n_pairs) return INQ_ERR_ARG;
+    if (b->n_loci >= 0xfffffff0ull || b->n_pairs >= (1ull << 40)) return INQ_ERR_ARG;
+    if (b->support == 0) return INQ_ERR_SUPPORT_ZERO;
+    return INQ_OK;
+}
+
+int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream) {
+    if (!c) return INQ_ERR_ARG;
+    int rc = check_scalars(b, r);
+    if (rc != INQ_OK) return rc;
+    if (((uintptr_t)b->cigar & 15u) || ((uintptr_t)b->reads & 15u)) return INQ_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if ((rc = ensure(c, c->worklist, (size_t)b->n_loci * 4)) != INQ_OK) return rc;
+    if ((rc = ensure(c, c->sval, (size_t)b->n_pairs * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, c->smeta, (size_t)b->n_pairs)) != INQ_OK) return rc;
+
+    KArgs a;
+    a.cigar4 = (const uint4 *)b->cigar;
+    a.reads = (const uint4 *)b->reads;
+    a.pair_read = b->pair_read;
+    a.locus_pair_off = b->locus_pair_off;
+    a.locus_start = b->locus_start;
+    a.locus_end = b->locus_end;
+    a.n_reads = b->n_reads;
+    a.n_cigar4 = b->n_cigar_words / 4;
+    a.n_pairs = b->n_pairs;
+    a.n_loci = b->n_loci;
+    a.minlen = b->minlen;
+    a.support = b->support;
+    a.phase1 = r->phase1;
+    a.phase2 = r->phase2;
+    a.pair_call = r->pair_call;
+    a.pair_bits = r->pair_bits;
+    a.status = c->d_status;
+    a.worklist = (uint32_t *)c->worklist.p;
+    a.sval = (int64_t *)c->sval.p;
+    a.smeta = (uint8_t *)c->smeta.p;
+    a.parity = c->parity;
+    c->parity ^= 1u;
+    const uint64_t blocks = (b->n_loci + 3) / 4;
+    const uint32_t per_xcd = (uint32_t)((blocks + 7) / 8);
+    a.blocks_per_xcd = per_xcd;
+    const uint32_t grid_small = per_xcd * 8u;
+
+    EvTriple *ev = nullptr;
+    if (c->timing) {
+        if (c->ev_used == c->ev_pool.size()) {
+            EvTriple t;
+            HIP_TRY(c, hipEventCreate(&t.e0));
+            HIP_TRY(c, hipEventCreate(&t.e1));
+            HIP_TRY(c, hipEventCreate(&t.e2));
+            c->ev_pool.push_back(t);
+        }
+        ev = &c->ev_pool[c->ev_used++];
+        HIP_TRY(c, hipEventRecord(ev->e0, s));
+    }
+    launch_locus_call(a, b->unphased != 0, grid_small, c->grid_big, s, ev ? ev->e1 : nullptr);
+    HIP_TRY(c, hipGetLastError());
+    if (ev) HIP_TRY(c, hipEventRecord(ev->e2, s));
+    return INQ_OK;
+}
+
+int inq_ctx_status(inq_ctx_t *c, uint64_t *n_tie_loci) {
+    if (!c) return INQ_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    DevStatus h;
+    HIP_TRY(c, hipMemcpy(&h, c->d_status, sizeof h, hipMemcpyDeviceToHost));
+    if (n_tie_loci) *n_tie_loci = h.ties;
+    // clear err and ties, keep the work-list counters
+    HIP_TRY(c, hipMemsetAsync(&c->d_status->err, 0, sizeof(unsigned int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(&c->d_status->ties, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return status_to_code(h.err);
+}
+
+int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
+    if (!c) return INQ_ERR_ARG;
+    int rc = check_scalars(b, r);
+    if (rc != INQ_OK) return rc;
+    // host-side shape checks: everything the grid and the kernels' indexing assume
+    if (b->n_loci) {
+        if (b->locus_pair_off[0] != 0 || b->locus_pair_off[b->n_loci] != b->n_pairs) return INQ_ERR_ARG;
+        for (uint64_t j = 0; j < b->n_loci; ++j) {
+            if (b->locus_pair_off[j] > b->locus_pair_off[j + 1]) return INQ_ERR_ARG;
+            if (b->locus_start[j] < 10 || b->locus_end[j] < b->locus_start[j]) return INQ_ERR_LOCUS;
+        }
+    }
+    r->n_tie_loci = 0;
+    if (b->n_loci == 0) return INQ_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    struct Up {
+        DevBuf *d;
+        const void *h;
+        size_t bytes;
+    } ups[] = {
+        {&c->cigar, b->cigar, (size_t)b->n_cigar_words * 4},
+        {&c->reads, b->reads, (size_t)b->n_reads * sizeof(inq_read_t)},
+        {&c->pair_read, b->pair_read, (size_t)b->n_pairs * 4},
+        {&c->off, b->locus_pair_off, (size_t)(b->n_loci + 1) * 8},
+        {&c->lstart, b->locus_start, (size_t)b->n_loci * 4},
+        {&c->lend, b->locus_end, (size_t)b->n_loci * 4},
+    };
+    for (auto &u : ups) {
+        if ((rc = ensure(c, *u.d, u.bytes)) != INQ_OK) return rc;
+        if (u.bytes) HIP_TRY(c, hipMemcpyAsync(u.d->p, u.h, u.bytes, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = ensure(c, c->p1, (size_t)b->n_loci * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, c->p2, (size_t)b->n_loci * 8)) != INQ_OK) return rc;
+    if (r->pair_call && (rc = ensure(c, c->pcall, (size_t)b->n_pairs * 8)) != INQ_OK) return rc;
+    if (r->pair_bits && (rc = ensure(c, c->pbits, (size_t)b->n_pairs)) != INQ_OK) return rc;
+
+    inq_batch_t db = *b;
+    db.cigar = (const uint32_t *)c->cigar.p;
+    db.reads = (const inq_read_t *)c->reads.p;
+    db.pair_read = (const uint32_t *)c->pair_read.p;
+    db.locus_pair_off = (const uint64_t *)c->off.p;
+    db.locus_start = (const uint32_t *)c->lstart.p;
+    db.locus_end = (const uint32_t *)c->lend.p;
+    inq_result_t dr;
+    dr.phase1 = (double *)c->p1.p;
+    dr.phase2 = (double *)c->p2.p;
+    dr.pair_call = r->pair_call ? (int64_t *)c->pcall.p : nullptr;
+    dr.pair_bits = r->pair_bits ? (uint8_t *)c->pbits.p : nullptr;
+    dr.n_tie_loci = 0;
+    if ((rc = inq_call_batch_device(c, &db, &dr, s)) != INQ_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(r->phase1, dr.phase1, (size_t)b->n_loci * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(r->phase2, dr.phase2, (size_t)b->n_loci * 8, hipMemcpyDeviceToHost, s));
+    if (r->pair_call && b->n_pairs)
+        HIP_TRY(c, hipMemcpyAsync(r->pair_call, dr.pair_call, (size_t)b->n_pairs * 8, hipMemcpyDeviceToHost, s));
+    if (r->pair_bits && b->n_pairs)
+        HIP_TRY(c, hipMemcpyAsync(r->pair_bits, dr.pair_bits, (size_t)b->n_pairs, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    uint64_t ties = 0;
+    rc = inq_ctx_status(c, &ties);
+    r->n_tie_loci = ties;
+    return rc;
+}
+
+int inq_ctx_timing_enable(inq_ctx_t *c, int on) {
+    if (!c) return INQ_ERR_ARG;
+    c->timing = on != 0;
+    return INQ_OK;
+}
+
+int inq_ctx_timing_reset(inq_ctx_t *c) {
+    if (!c) return INQ_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    c->ev_used = 0;
+    return INQ_OK;
+}
+
+int inq_ctx_timing_read(inq_ctx_t *c, int which, double *total_ms, uint64_t *launches) {
+    if (!c || (which != 0 && which != 1)) return INQ_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    double tot = 0.0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        EvTriple &e = c->ev_pool[i];
+        HIP_TRY(c, hipEventSynchronize(e.e2));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, e.e0, which == 0 ? e.e2 : e.e1));
+        tot += (double)ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (uint64_t)c->ev_used;
+    return INQ_OK;
+}
+
+int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
+    if (!c || !key) return INQ_ERR_ARG;
+    if (std::strcmp(key, "grid_big") == 0) {
+        if (value < 1 || value > 65535) return INQ_ERR_ARG;
+        c->grid_big = (uint32_t)value;
+        return INQ_OK;
+    }
+    return INQ_ERR_ARG;
+}
+
+int inq_alloc_pinned(size_t bytes, void **out) {
+    if (!out) return INQ_ERR_ARG;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) return INQ_ERR_NOMEM;
+    if (e != hipSuccess) return INQ_ERR_NO_DEVICE;
+    return INQ_OK;
+}
+
+void inq_free_pinned(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"

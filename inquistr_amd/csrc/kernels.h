@@ -1,0 +1,42 @@
+// kernels.h — kernel argument block shared by kernels.hip and capi.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace inq {
+
+// Device-resident status block (one per ctx).
+struct DevStatus {
+    unsigned int err;           // ST_* bits OR-ed by the kernels
+    unsigned int big_count[2];  // work-list length, double-buffered by call parity
+    unsigned int pad;
+    unsigned long long ties;    // unphased loci whose split cuts mixed Span/Clip ties
+};
+
+struct KArgs {
+    // batch (device pointers)
+    const uint4 *cigar4;
+    const uint4 *reads;
+    const uint32_t *pair_read;
+    const uint64_t *locus_pair_off;
+    const uint32_t *locus_start;
+    const uint32_t *locus_end;
+    uint64_t n_reads, n_cigar4, n_pairs, n_loci;
+    uint32_t minlen, support;
+    // results
+    double *phase1, *phase2;
+    int64_t *pair_call;  // may be null
+    uint8_t *pair_bits;  // may be null
+    // ctx scratch
+    DevStatus *status;
+    uint32_t *worklist;  // [n_loci]
+    int64_t *sval;       // [n_pairs]
+    uint8_t *smeta;      // [n_pairs]
+    uint32_t parity;
+    uint32_t blocks_per_xcd;  // grid_small / 8
+};
+
+void launch_locus_call(const KArgs &a, bool unphased, uint32_t grid_small, uint32_t grid_big, hipStream_t s,
+                       hipEvent_t ev_mid);
+
+}  // namespace inq

@@ -1,0 +1,179 @@
+"""ctypes binding of the C ABI (include/inquistr_hip.h) — the only way Python reaches the
+HIP kernels.  No CPU fallback: if the shared library is missing, or no gfx950 device is
+visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .batch import (
+    INQ_ERR_NO_DEVICE,
+    INQ_OK,
+    Batch,
+    InqBatchC,
+    InqResultC,
+    Result,
+)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libinquistr_hip.so")
+
+# every symbol include/inquistr_hip.h declares
+ABI_SYMBOLS = (
+    "inq_ctx_create",
+    "inq_ctx_destroy",
+    "inq_call_batch",
+    "inq_call_batch_device",
+    "inq_ctx_status",
+    "inq_ctx_timing_enable",
+    "inq_ctx_timing_read",
+    "inq_ctx_timing_reset",
+    "inq_ctx_set_option",
+    "inq_alloc_pinned",
+    "inq_free_pinned",
+    "inq_strerror",
+    "inq_backend_name",
+    "inq_last_error",
+    "inq_abi_version",
+)
+
+
+class InqError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"inquistr_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads libinquistr_hip.so (built by `make -C inquistr_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.inq_ctx_create.restype = C.c_int
+    L.inq_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.inq_ctx_destroy.restype = None
+    L.inq_ctx_destroy.argtypes = [vp]
+    L.inq_call_batch.restype = C.c_int
+    L.inq_call_batch.argtypes = [vp, C.POINTER(InqBatchC), C.POINTER(InqResultC)]
+    L.inq_call_batch_device.restype = C.c_int
+    L.inq_call_batch_device.argtypes = [vp, C.POINTER(InqBatchC), C.POINTER(InqResultC), vp]
+    L.inq_ctx_status.restype = C.c_int
+    L.inq_ctx_status.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.inq_ctx_timing_enable.restype = C.c_int
+    L.inq_ctx_timing_enable.argtypes = [vp, C.c_int]
+    L.inq_ctx_timing_read.restype = C.c_int
+    L.inq_ctx_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.inq_ctx_timing_reset.restype = C.c_int
+    L.inq_ctx_timing_reset.argtypes = [vp]
+    L.inq_ctx_set_option.restype = C.c_int
+    L.inq_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.inq_alloc_pinned.restype = C.c_int
+    L.inq_alloc_pinned.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.inq_free_pinned.restype = None
+    L.inq_free_pinned.argtypes = [vp]
+    L.inq_strerror.restype = C.c_char_p
+    L.inq_strerror.argtypes = [C.c_int]
+    L.inq_backend_name.restype = C.c_char_p
+    L.inq_backend_name.argtypes = [vp]
+    L.inq_last_error.restype = C.c_char_p
+    L.inq_last_error.argtypes = [vp]
+    L.inq_abi_version.restype = C.c_int
+    L.inq_abi_version.argtypes = []
+    _lib = L
+    return L
+
+
+def strerror(code: int) -> str:
+    return load().inq_strerror(code).decode()
+
+
+class Context:
+    """One HIP device context (inq_ctx_t).  Raises InqError(INQ_ERR_NO_DEVICE) without an MI355X."""
+
+    def __init__(self, device_id: int = 0):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.inq_ctx_create(device_id, C.byref(self._h))
+        if rc != INQ_OK:
+            self._h = C.c_void_p()
+            raise InqError(rc, strerror(rc))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.inq_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def backend(self) -> str:
+        return self._L.inq_backend_name(self._h).decode()
+
+    def _raise(self, rc: int):
+        detail = self._L.inq_last_error(self._h).decode()
+        raise InqError(rc, strerror(rc) + (f" [{detail}]" if detail and rc == -8 else ""))
+
+    def call_batch(self, batch: Batch, debug: bool = False, check: bool = True) -> Tuple[int, Result]:
+        """Host-buffer entry (inq_call_batch).  Returns (code, Result); raises on error if check."""
+        res = Result.alloc(batch, debug=debug)
+        bc, rc_ = batch.as_c(), res.as_c()
+        rc = self._L.inq_call_batch(self._h, C.byref(bc), C.byref(rc_))
+        res.n_tie_loci = int(rc_.n_tie_loci)
+        if rc != INQ_OK and check:
+            self._raise(rc)
+        return rc, res
+
+    def call_batch_device(self, bc: InqBatchC, rc_: InqResultC, stream: Optional[int] = None) -> None:
+        """Device-resident entry: pointers in bc / rc_ are device pointers; enqueue only."""
+        rc = self._L.inq_call_batch_device(self._h, C.byref(bc), C.byref(rc_), C.c_void_p(stream or 0))
+        if rc != INQ_OK:
+            self._raise(rc)
+
+    def status(self) -> Tuple[int, int]:
+        ties = C.c_uint64(0)
+        rc = self._L.inq_ctx_status(self._h, C.byref(ties))
+        return rc, int(ties.value)
+
+    def timing_enable(self, on: bool = True):
+        self._L.inq_ctx_timing_enable(self._h, 1 if on else 0)
+
+    def timing_reset(self):
+        rc = self._L.inq_ctx_timing_reset(self._h)
+        if rc != INQ_OK:
+            self._raise(rc)
+
+    def timing_read(self, which: int = 0) -> Tuple[float, int]:
+        ms, n = C.c_double(0), C.c_uint64(0)
+        rc = self._L.inq_ctx_timing_read(self._h, which, C.byref(ms), C.byref(n))
+        if rc != INQ_OK:
+            self._raise(rc)
+        return float(ms.value), int(n.value)
+
+    def set_option(self, key: str, value: int):
+        rc = self._L.inq_ctx_set_option(self._h, key.encode(), value)
+        if rc != INQ_OK:
+            self._raise(rc)

@@ -1,0 +1,305 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X.
+
+Bit-exact bar: integer calls and flags equal, medians equal as f64 (NaN where the oracle has NaN).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from inquistr_amd import batch as B
+from inquistr_amd import synth
+from tests import gen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from inquistr_amd import hipcall
+
+    c = hipcall.Context(0)
+    assert c.backend.startswith("hip:gfx950")
+    yield c
+    c.close()
+
+
+def _assert_same(got, want, what=""):
+    assert gen.same_f64(got.phase1, want.phase1), f"phase1 differs {what}"
+    assert gen.same_f64(got.phase2, want.phase2), f"phase2 differs {what}"
+    if want.pair_call is not None and got.pair_call is not None:
+        bad = np.nonzero(got.pair_call != want.pair_call)[0]
+        assert bad.size == 0, f"pair_call differs at {bad[:8]} {what}"
+        bad = np.nonzero(got.pair_bits != want.pair_bits)[0]
+        assert bad.size == 0, f"pair_bits differs at {bad[:8]}: {got.pair_bits[bad[:8]]} vs {want.pair_bits[bad[:8]]} {what}"
+    assert got.n_tie_loci == want.n_tie_loci, what
+
+
+def test_kat_loci(ctx, orc, kat):
+    """The hand-derived locus vectors of tests/golden/kat_call.json, one batch per mode."""
+    from oracle import pyoracle as py
+    from tests.test_oracle_kat import _num, _pyrec
+
+    for mode in ("phased", "unphased"):
+        cases = [v for v in kat["loci"] if v["mode"] == mode]
+        by_params = {}
+        for v in cases:
+            by_params.setdefault((v["minlen"], v["support"]), []).append(v)
+        for (minlen, support), vs in by_params.items():
+            bb = B.BatchBuilder(minlen=minlen, support=support, unphased=(mode == "unphased"))
+            for v in vs:
+                idx = []
+                for r in v["reads"]:
+                    rec = _pyrec(r)
+                    idx.append(
+                        bb.add_read(rec.pos, B.encode_cigar(rec.cigar), mapq=rec.mapq, phase=py.get_phase(rec),
+                                    reverse=bool(rec.flag & 0x10), unmapped=bool(rec.flag & 0x4),
+                                    is_2d=py.is_accidental_2d(rec))
+                    )
+                bb.add_locus(v["start"], v["end"], idx)
+            batch = bb.build()
+            rc, got = ctx.call_batch(batch, debug=True)
+            assert rc == 0
+            for j, v in enumerate(vs):
+                want = [_num(x) for x in v["expect"]]
+                assert gen.same_f64(np.array([got.phase1[j], got.phase2[j]]), np.array(want)), v["name"]
+            assert got.n_tie_loci == sum(1 for v in vs if v.get("tie"))
+            _assert_same(got, orc.call_batch(batch, debug=True)[1], mode)
+
+
+def test_kat_call_from_cigar(ctx, kat):
+    """Every call_from_cigar vector as a one-read locus; the per-pair Call comes back through
+    the debug outputs of the ABI."""
+    from oracle import pyoracle as py
+    from tests.test_oracle_kat import _pyrec
+
+    groups = {}
+    for v in kat["call_from_cigar"]:
+        groups.setdefault(v["minlen"], []).append(v)
+    for minlen, vs in groups.items():
+        bb = B.BatchBuilder(minlen=minlen, support=1, unphased=False)
+        for v in vs:
+            rec = _pyrec(v)
+            ri = bb.add_read(rec.pos, B.encode_cigar(rec.cigar), phase=1, reverse=bool(rec.flag & 0x10),
+                             is_2d=py.is_accidental_2d(rec))
+            bb.add_locus(v["start"] + 10, v["end"] - 10, [ri])
+        batch = bb.build()
+        rc, got = ctx.call_batch(batch, debug=True)
+        assert rc == 0
+        for j, v in enumerate(vs):
+            kind, val = v["expect"]
+            assert got.pair_call[j] == val, v["name"]
+            assert bool(got.pair_bits[j] & B.INQ_PAIR_CLIP) == (kind == "Clip"), v["name"]
+
+
+@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("unphased", [False, True])
+def test_random_vs_oracle(ctx, orc, seed, unphased):
+    support = [3, 1, 2, 5][seed % 4]
+    minlen = [5, 0, 5, 12][seed % 4]
+    batch, _ = gen.random_case(seed, n_loci=60, unphased=unphased, minlen=minlen, support=support,
+                               long_every=5 if seed % 2 == 0 else 0)
+    rc, got = ctx.call_batch(batch, debug=True)
+    oc, want = orc.call_batch(batch, debug=True)
+    assert rc == oc == 0
+    _assert_same(got, want, f"seed={seed} unphased={unphased}")
+
+
+@pytest.mark.parametrize("unphased", [False, True])
+@pytest.mark.parametrize("max_reads", [64, 65, 130, 700])
+def test_deep_loci(ctx, orc, unphased, max_reads):
+    """Loci with more than 64 offered reads take the work-list kernel."""
+    batch, _ = gen.random_case(1000 + max_reads, n_loci=24, unphased=unphased, max_reads=max_reads,
+                               long_every=9, support=3)
+    assert int(np.diff(batch.locus_pair_off.astype(np.int64)).max()) >= max_reads
+    rc, got = ctx.call_batch(batch, debug=True)
+    oc, want = orc.call_batch(batch, debug=True)
+    assert rc == oc == 0
+    _assert_same(got, want, f"max_reads={max_reads}")
+
+
+def test_clip_heavy_ties(ctx, orc):
+    """Many equal values of mixed Span/Clip: exercises the clip ranking and the tie counter."""
+    import random
+
+    rng = random.Random(7)
+    for unphased in (False, True):
+        bb = B.BatchBuilder(minlen=5, support=3, unphased=unphased)
+        for j in range(200):
+            start = 5000 + 1000 * j
+            end = start + 40
+            idx = []
+            for k in range(rng.choice([4, 7, 12, 33, 64, 90])):
+                v = rng.choice([8, 8, 8, 20, 20, 31])
+                if rng.random() < 0.5:
+                    cig = [("M", 20), ("S", v), ("M", 200)]  # Clip(v) at refpos start_ext+21... inside window
+                    pos = start - 10
+                else:
+                    cig = [("M", 100), ("I", v), ("M", 200)]
+                    pos = start - 10 - 80
+                idx.append(bb.add_read(pos, B.encode_cigar(cig), phase=rng.choice([1, 2])))
+            bb.add_locus(start, end, idx)
+        batch = bb.build()
+        rc, got = ctx.call_batch(batch, debug=True)
+        oc, want = orc.call_batch(batch, debug=True)
+        assert rc == oc == 0
+        if unphased:
+            assert want.n_tie_loci > 0
+        _assert_same(got, want, f"unphased={unphased}")
+
+
+def test_empty_and_ragged(ctx, orc):
+    rc, res = ctx.call_batch(B.BatchBuilder().build())
+    assert rc == 0 and res.phase1.shape == (0,)
+    bb = B.BatchBuilder(support=1)
+    bb.add_locus(100, 200, [])
+    r0 = bb.add_read(50, np.zeros(0, dtype=np.uint32), phase=1)  # empty CIGAR: endpos = pos + 1
+    r1 = bb.add_read(150, B.encode_cigar([("M", 1)]), phase=2)
+    bb.add_locus(100, 200, [r0, r1])
+    bb.add_locus(300, 300, [r1])
+    batch = bb.build()
+    rc, got = ctx.call_batch(batch, debug=True)
+    oc, want = orc.call_batch(batch, debug=True)
+    assert rc == oc == 0
+    _assert_same(got, want)
+    assert np.isnan(got.phase1[0]) and np.isnan(got.phase2[0])
+
+
+def test_long_cigars(ctx, orc):
+    """Reads of 1 .. 70 000 ops (beyond the 65 535 a BAM record stores inline), chunk edges included."""
+    import random
+
+    rng = random.Random(3)
+    bb = B.BatchBuilder(support=1)
+    for n_ops in (1, 255, 256, 257, 511, 512, 513, 1024, 4097, 70_000):
+        cig = gen.random_cigar(rng, n_ops)
+        rlen = sum(l for o, l in cig if o in "MDN=X")
+        start = 1_000_000 + rlen // 2
+        idx = [bb.add_read(1_000_000, B.encode_cigar(cig), phase=1 + (k & 1)) for k in range(3)]
+        bb.add_locus(start, start + 200, idx)
+    batch = bb.build()
+    rc, got = ctx.call_batch(batch, debug=True)
+    oc, want = orc.call_batch(batch, debug=True)
+    assert rc == oc == 0
+    _assert_same(got, want)
+
+
+def test_domain_errors(ctx, orc):
+    def one(**kw):
+        bb = B.BatchBuilder(**{k: v for k, v in kw.items() if k in ("minlen", "support", "unphased")})
+        r = bb.add_read(pos=kw.get("pos", 900), cigar_words=kw.get("cigar", B.encode_cigar([("M", 300)])),
+                        phase=kw.get("phase", 1))
+        bb.add_locus(kw.get("start", 1010), kw.get("end", 1090), [r])
+        return bb.build()
+
+    def both(b):
+        rc, _ = ctx.call_batch(b, check=False)
+        assert rc == orc.call_batch(b)[0]
+        return rc
+
+    assert both(one(support=0)) == B.INQ_ERR_SUPPORT_ZERO
+    assert both(one(start=9, end=90)) == B.INQ_ERR_LOCUS
+    assert both(one(start=100, end=99)) == B.INQ_ERR_LOCUS
+    assert both(one(phase=3)) == B.INQ_ERR_PHASE
+    assert both(one(phase=3, unphased=True)) == B.INQ_OK
+    assert both(one(cigar=np.array([(300 << 4) | 9], dtype=np.uint32))) == B.INQ_ERR_CIGAR_OP
+    assert both(one(pos=2**31 - 200)) == B.INQ_ERR_RANGE
+    b = one()
+    b.pair_read[0] = 5
+    assert both(b) == B.INQ_ERR_INDEX
+    b = one()
+    b.reads["n_cigar"][0] = 9
+    assert both(b) == B.INQ_ERR_INDEX
+    b = one()
+    b.locus_pair_off[1] = 2
+    assert both(b) == B.INQ_ERR_ARG
+    # the ctx stays usable after an error
+    assert both(one()) == B.INQ_OK
+
+
+@pytest.mark.parametrize("name", ["phased10k", "unphased100k", "expansion50k"])
+def test_synthetic_workload_sample(ctx, orc, name):
+    wl = synth.WORKLOADS[name]
+    hi = 96 if wl.heavy_pct else 2000
+    batch = synth.generate_numpy(wl, 0, hi)
+    rc, got = ctx.call_batch(batch, debug=True)
+    oc, want = orc.call_batch(batch, debug=True, threads=8)
+    assert rc == oc == 0
+    _assert_same(got, want, name)
+
+
+def test_golden_random_fixture(ctx):
+    """Committed vectors (tests/golden/random_batches.npz, made by tests/golden/make_fixtures.py
+    from the CPU oracle): the GPU box needs neither the reference nor a rebuild to check them."""
+    p = os.path.join(os.path.dirname(__file__), "golden", "random_batches.npz")
+    z = np.load(p)
+    n = int(z["n_cases"])
+    for i in range(n):
+        batch = B.Batch(
+            cigar=z[f"c{i}_cigar"], reads=z[f"c{i}_reads"].view(B.READ_DTYPE).reshape(-1),
+            pair_read=z[f"c{i}_pair_read"], locus_pair_off=z[f"c{i}_off"], locus_start=z[f"c{i}_start"],
+            locus_end=z[f"c{i}_end"], minlen=int(z[f"c{i}_params"][0]), support=int(z[f"c{i}_params"][1]),
+            unphased=bool(z[f"c{i}_params"][2]),
+        )
+        rc, got = ctx.call_batch(batch, debug=True)
+        assert rc == 0
+        want = B.Result(phase1=z[f"c{i}_p1"], phase2=z[f"c{i}_p2"], pair_call=z[f"c{i}_pair_call"],
+                        pair_bits=z[f"c{i}_pair_bits"], n_tie_loci=int(z[f"c{i}_params"][3]))
+        _assert_same(got, want, f"fixture case {i}")
+
+
+def test_full_size_roofline_workload(ctx, orc):
+    """BASELINE config #3 at full size, device-resident (100k loci x 30 reads x ~200 ops, unphased):
+    exact against the oracle on three sampled locus ranges, plus size-independent properties —
+    idempotence, and invariance of every locus' result to which other loci share the batch."""
+    import torch
+
+    wl = synth.WORKLOADS["unphased100k"]
+    dev = torch.device("cuda:0")
+    full = synth.DeviceBatch(wl, dev, debug=False)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.call_batch_device(full.c_batch, full.c_result, stream)
+    rc, ties = ctx.status()
+    assert rc == 0
+    p1, p2 = full.phase1.cpu().numpy(), full.phase2.cpu().numpy()
+    # idempotence
+    full.phase1.fill_(123.0)
+    ctx.call_batch_device(full.c_batch, full.c_result, stream)
+    rc, ties2 = ctx.status()
+    assert rc == 0 and ties2 == ties
+    assert gen.same_f64(full.phase1.cpu().numpy(), p1) and gen.same_f64(full.phase2.cpu().numpy(), p2)
+    # exact on sampled ranges (the generator is counter based: numpy and torch agree per locus)
+    for lo, hi in ((0, 400), (50_000, 50_400), (99_600, 100_000)):
+        sub = synth.generate_numpy(wl, lo, hi)
+        oc, want = orc.call_batch(sub, threads=8)
+        assert oc == 0
+        assert gen.same_f64(p1[lo:hi], want.phase1) and gen.same_f64(p2[lo:hi], want.phase2), (lo, hi)
+    # every locus got a finite call in this workload and most medians are non-zero integers or halves
+    assert not np.isnan(p1).any() and not np.isnan(p2).any()
+    assert np.all(np.mod(p1 * 2, 1) == 0) and np.all(np.mod(p2 * 2, 1) == 0)
+    assert np.all(p1 <= p2)  # unphased: h1 is the lower half of the sorted calls
+    # a sub-batch resident on the device gives the same rows as the full batch
+    part = synth.DeviceBatch(wl, dev, 70_000, 71_000)
+    ctx.call_batch_device(part.c_batch, part.c_result, stream)
+    assert ctx.status()[0] == 0
+    assert gen.same_f64(part.phase1.cpu().numpy(), p1[70_000:71_000])
+    assert gen.same_f64(part.phase2.cpu().numpy(), p2[70_000:71_000])
+
+
+def test_timing_events(ctx):
+    import torch
+
+    wl = synth.WORKLOADS["phased10k"]
+    d = synth.DeviceBatch(wl, torch.device("cuda:0"), 0, 2000)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(3):
+        ctx.call_batch_device(d.c_batch, d.c_result, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ms_all, n = ctx.timing_read(0)
+    ms_k, n2 = ctx.timing_read(1)
+    ctx.timing_enable(False)
+    ctx.timing_reset()
+    assert n == n2 == 3 and 0 < ms_k <= ms_all
+    assert ctx.status()[0] == 0
