@@ -7,13 +7,23 @@
 //   fetch() overlap rule     src/call.rs:288,338   ([3P] htslib iterator)
 // Both CIGAR walks of the reference are fused into ONE pass over the packed ops.
 //
-// Data path: each lane loads 4 packed ops (one dwordx4, 16 B/lane, 1 KiB per wave
-// instruction, fully coalesced); the reference position of every op comes from a
-// 4-wide in-lane prefix + a DPP wave scan + a scalar carry between 256-op chunks.
+// Data path (per wave):
+//   * ops stream in as 256-op chunks: one buffer_load_dwordx4 per lane (16 B/lane, 1 KiB per wave
+//     instruction, coalesced).  The buffer descriptor's range check returns 0 (= `0M`, a no-op)
+//     past the read's end, so the load is never predicated.  Four chunk loads are always in
+//     flight per wave (flattened over reads and over the chunks of long reads).
+//   * reference positions: 4-wide in-lane prefix + DPP wave scan + scalar carry between chunks.
+//   * only the few lanes whose ops can start inside [start_ext, end_ext) matter for the call:
+//     they are compacted into an LDS queue and evaluated 64 at a time (one queue entry per
+//     lane), their signed lengths land in the owning read's LDS accumulator (ds_add_u64).
+//     The whole wave therefore pays the per-op window/minlen/sign logic once per ~64 window
+//     lanes instead of once per chunk.
 #pragma once
 #include "wave_primitives.h"
 
 namespace inq {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // device status word bits (mapped to INQ_ERR_* by the host, same precedence as the oracle)
 constexpr uint32_t ST_INDEX = 1u, ST_CIGAR_OP = 2u, ST_RANGE = 4u, ST_PHASE = 8u, ST_LOCUS = 16u;
@@ -25,7 +35,7 @@ constexpr uint32_t PM_CHOSEN = 64u;
 
 constexpr uint32_t RB_UNMAPPED = 1u, RB_REVERSE = 2u, RB_HAS_HP = 4u, RB_IS_2D = 8u;
 
-constexpr int kPrefetch = 4;  // first-chunk loads kept in flight per wave
+constexpr int kQueueCap = 128;  // window-lane queue entries per wave
 
 struct Window {
     uint32_t se;     // start_ext = start - 10            (src/call.rs:285,335)
@@ -41,6 +51,14 @@ struct BatchView {
     const uint32_t *pair_read;
     uint64_t n_reads;
     uint64_t n_cigar4;  // n_cigar_words / 4
+};
+
+// LDS owned by one wave
+struct WaveLds {
+    u32x4 qw[kQueueCap];       // queued lanes: their 4 packed ops
+    uint2 qi[kQueueCap];       // .x = reference position of the first op minus (start_ext+1); .y = read slot | is2d<<6
+    unsigned long long acc[64];  // per read slot: the Call value (two's complement)
+    unsigned int flags[64];      // per read slot: bit0 = a soft clip was counted
 };
 
 // Per-lane descriptor of the pair this lane "owns" inside a block of <= 64 pairs.
@@ -59,7 +77,7 @@ __device__ __forceinline__ PairMeta load_pair_meta(const BatchView &b, uint64_t 
         if ((uint64_t)ri < b.n_reads) {
             uint4 r = b.reads[ri];
             uint64_t n4 = ((uint64_t)r.y + 3u) >> 2;
-            if (r.y < 0x80000000u && (uint64_t)r.x + n4 <= b.n_cigar4) {
+            if (r.y < 0x10000000u && (uint64_t)r.x + n4 <= b.n_cigar4) {
                 m.off4 = r.x;
                 m.nc = r.y;
                 m.pos = r.z;
@@ -75,144 +93,188 @@ __device__ __forceinline__ PairMeta load_pair_meta(const BatchView &b, uint64_t 
     return m;
 }
 
-// One dwordx4 of chunk c of a read: lane -> ops [256c + 4*lane, +4).  Lanes past the read's
-// (4-padded) end get zeros = four `0M`, which are no-ops for every rule below.
-__device__ __forceinline__ uint4 load_chunk(const BatchView &b, uint32_t off4, uint32_t nc, uint32_t c, int lane) {
-    uint32_t i4 = c * 64u + (uint32_t)lane;
-    uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if (i4 * 4u < nc) w = b.cigar4[(uint64_t)off4 + i4];
-    return w;
+// ops that consume the reference: M D N = X -> bits 0,2,3,7,8 (src/call.rs:384-392,404)
+constexpr uint32_t kConsume = 0x18Du;
+
+// len if the op consumes the reference, else 0 (v_bfe_i32 + v_and)
+__device__ __forceinline__ uint32_t ref_advance(uint32_t op, uint32_t len) {
+    return len & (uint32_t)__builtin_amdgcn_sbfe((int)kConsume, op, 1u);
 }
 
-struct LaneAcc {
-    int64_t sum;      // this lane's share of `call`
-    uint32_t clip;    // a soft clip was counted
-    uint32_t maxop;   // largest op code seen
-    uint32_t range;   // bit 31 of any running reference position
-};
-
-// Processes 256 ops (4 per lane).  `carry` (wave-uniform) is the reference position before the
-// first op of the chunk, i.e. reference_position of src/call.rs:380 advanced over earlier chunks.
-__device__ __forceinline__ void walk_chunk(const uint4 w, const Window &W, uint32_t cand_mask, uint32_t &carry,
-                                           LaneAcc &A) {
-    const uint32_t op0 = w.x & 15u, op1 = w.y & 15u, op2 = w.z & 15u, op3 = w.w & 15u;
-    const uint32_t l0 = w.x >> 4, l1 = w.y >> 4, l2 = w.z >> 4, l3 = w.w >> 4;
-    // ops that consume the reference: M D N = X  -> bits 0,2,3,7,8 (src/call.rs:384-392,404)
-    constexpr uint32_t kConsume = 0x18Du;
-    const uint32_t a0 = ((kConsume >> op0) & 1u) ? l0 : 0u;
-    const uint32_t a1 = ((kConsume >> op1) & 1u) ? l1 : 0u;
-    const uint32_t a2 = ((kConsume >> op2) & 1u) ? l2 : 0u;
-    const uint32_t a3 = ((kConsume >> op3) & 1u) ? l3 : 0u;
-    const uint32_t e1 = a0, e2 = e1 + a1, e3 = e2 + a2, tot = e3 + a3;
-    const uint32_t incl = wave_inclusive_scan_u32(tot);
-    const uint32_t base = carry + (incl - tot);  // reference position at this lane's first op
-    A.range |= (carry + incl);
-    A.maxop = max(max(A.maxop, max(op0, op1)), max(op2, op3));
-    int32_t s = 0;
-    uint32_t clip = 0;
-#define INQ_OP(op, len, e)                                                                    \
-    {                                                                                         \
-        const bool hit = ((cand_mask >> (op)) & 1u) && (len) > W.minlen &&                    \
-                         ((base + (e)) - W.se1) < W.width;                                     \
-        const int32_t v = ((op) == 2u) ? -(int32_t)(len) : (int32_t)(len);                    \
-        s += hit ? v : 0;                                                                     \
-        clip |= (hit && (op) == 4u) ? 1u : 0u;                                                \
+// Evaluates the queued window lanes: entry e -> lane e.  src/call.rs:387-403 for 4 ops per lane.
+__device__ __forceinline__ void drain_queue(WaveLds &L, uint32_t &qcount, const Window &W, int lane) {
+    // single-wave LDS traffic: DS instructions of one wave execute in issue order, so the queue
+    // writes above are visible to the reads below without a fence; wave_barrier only pins the
+    // compiler's schedule
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < qcount; base += 64u) {
+        const uint32_t e = base + (uint32_t)lane;
+        if (e < qcount) {
+            const u32x4 w = L.qw[e];
+            const uint2 info = L.qi[e];
+            const uint32_t rel = info.x;
+            const uint32_t slot = info.y & 63u;
+            // soft clips of an accidental-2D read never count (src/call.rs:394): drop S from the candidates
+            const uint32_t cand_mask = (info.y & 64u) ? 0x06u : 0x16u;  // I=1, D=2, S=4
+            const uint32_t op0 = w.x & 15u, op1 = w.y & 15u, op2 = w.z & 15u, op3 = w.w & 15u;
+            const uint32_t l0 = w.x >> 4, l1 = w.y >> 4, l2 = w.z >> 4, l3 = w.w >> 4;
+            const uint32_t e1 = ref_advance(op0, l0), e2 = e1 + ref_advance(op1, l1), e3 = e2 + ref_advance(op2, l2);
+            int32_t s = 0;
+            uint32_t clip = 0;
+#define INQ_OP(op, len, ee_)                                                                              \
+    {                                                                                                     \
+        const bool hit = ((cand_mask >> (op)) & 1u) && (len) > W.minlen && (rel + (ee_)) < W.width;        \
+        const int32_t v = ((op) == 2u) ? -(int32_t)(len) : (int32_t)(len);                                \
+        s += hit ? v : 0;                                                                                 \
+        clip |= (hit && (op) == 4u) ? 1u : 0u;                                                            \
     }
-    INQ_OP(op0, l0, 0u)
-    INQ_OP(op1, l1, e1)
-    INQ_OP(op2, l2, e2)
-    INQ_OP(op3, l3, e3)
+            INQ_OP(op0, l0, 0u)
+            INQ_OP(op1, l1, e1)
+            INQ_OP(op2, l2, e2)
+            INQ_OP(op3, l3, e3)
 #undef INQ_OP
-    A.sum += (int64_t)s;  // |s| < 4 * 2^28
-    A.clip |= clip;
-    carry += readlane_u32(incl, 63);
+            if (s != 0) atomicAdd(&L.acc[slot], (unsigned long long)(long long)s);  // |s| < 4 * 2^28
+            if (clip) atomicOr(&L.flags[slot], 1u);
+        }
+    }
+    qcount = 0;
+    __builtin_amdgcn_wave_barrier();
 }
 
-// Wave-uniform outcome of one (locus, read) pair
-struct PairOut {
-    int64_t call;   // Call value                              src/call.rs:67-71
-    uint32_t meta;  // PM_CLIP | PM_FETCHED | PM_KEPT | group
-};
-
-// Walks the reads of pairs [0, cnt) described by `m` (lane k owns pair k) and hands each
-// pair's wave-uniform result to sink(k, PairOut).  First chunks of the next kPrefetch reads
-// are kept in flight while the current one is reduced.
-template <bool UNPHASED, class Sink>
+// Walks the reads of pairs [0, cnt) described by `m` (lane k owns pair k).  On return lane k holds
+// the pair's Call (src/call.rs:67-71) in `val` and PM_CLIP | PM_FETCHED | PM_KEPT | group in `meta`.
+template <bool UNPHASED>
 __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m, uint64_t valid_mask, int cnt,
-                                           const Window &W, int lane, uint32_t &status, Sink sink) {
-    uint4 q0, q1, q2, q3;
-    {
-        auto first = [&](int k) -> uint4 {
-            if (k < cnt) return load_chunk(b, readlane_u32(m.off4, k), readlane_u32(m.nc, k), 0u, lane);
-            return make_uint4(0u, 0u, 0u, 0u);
-        };
-        q0 = first(0);
-        q1 = first(1);
-        q2 = first(2);
-        q3 = first(3);
-    }
-    for (int k = 0; k < cnt; ++k) {
-        uint4 w = q0;
-        q0 = q1;
-        q1 = q2;
-        q2 = q3;
-        {
-            const int kn = k + kPrefetch;
-            q3 = make_uint4(0u, 0u, 0u, 0u);
-            if (kn < cnt) q3 = load_chunk(b, readlane_u32(m.off4, kn), readlane_u32(m.nc, kn), 0u, lane);
-        }
-        const uint32_t off4 = readlane_u32(m.off4, k);
-        const uint32_t nc = readlane_u32(m.nc, k);
-        const uint32_t pos = readlane_u32(m.pos, k);
-        const uint32_t misc = readlane_u32(m.misc, k);
-        const uint32_t mapq = misc & 0xffu, bits = (misc >> 8) & 0xffu, phase = (misc >> 16) & 0xffu;
-        const bool pvalid = (valid_mask >> k) & 1ull;
-        // soft clips of an accidental-2D read never count (src/call.rs:394): drop S from the candidates
-        const uint32_t cand_mask = (bits & RB_IS_2D) ? 0x06u : 0x16u;  // I=1, D=2, S=4
+                                           const Window &W, int lane, uint32_t &status, WaveLds &L, int64_t &val,
+                                           uint32_t &meta) {
+    val = 0;
+    meta = 0;
+    L.acc[lane] = 0ull;
+    L.flags[lane] = 0u;
+    uint32_t qcount = 0;
+    uint32_t lane_range = 0, lane_maxop = 0;
 
-        uint32_t carry = pos + 1u;  // (reference_start + 1) as u32, src/call.rs:380
-        LaneAcc A{0, 0u, 0u, carry};
-        const uint32_t nchunks = (nc + 255u) >> 8;
-        uint4 wn = make_uint4(0u, 0u, 0u, 0u);
-        if (nchunks > 1u) wn = load_chunk(b, off4, nc, 1u, lane);
-        for (uint32_t c = 0;;) {
-            walk_chunk(w, W, cand_mask, carry, A);
-            ++c;
-            if (c >= nchunks) break;
-            w = wn;
-            if (c + 1u < nchunks) wn = load_chunk(b, off4, nc, c + 1u, lane);
+    // ---- load cursor: runs 4 chunk loads ahead of the compute cursor ----
+    int hk = 0;
+    uint32_t hc = 0, h_nchunks = 1, h_off4 = 0, h_n4 = 0;
+    auto head_load = [&]() {
+        if (hk < cnt) {
+            h_off4 = readlane_u32(m.off4, hk);
+            const uint32_t nc = readlane_u32(m.nc, hk);
+            h_n4 = (nc + 3u) >> 2;
+            h_nchunks = max(1u, (nc + 255u) >> 8);
+        } else {
+            h_off4 = 0;
+            h_n4 = 0;
+            h_nchunks = 1;
         }
-        // ---- wave-uniform epilogue of the pair ----
-        const uint64_t nz = ballot64(A.sum != 0);
-        const int64_t call = nz ? wave_reduce_add_i64(A.sum) : 0;
-        const bool clipped = ballot64(A.clip != 0u) != 0ull;
-        if (ballot64(A.maxop > 8u)) status |= ST_CIGAR_OP;  // rust-htslib cigar() would panic
-        if (ballot64((A.range >> 31) != 0u)) status |= ST_RANGE;
-        // [3P] bam_endpos: rlen = unmapped ? 0 : sum(ref-consuming); rlen == 0 -> 1
-        uint32_t rlen = carry - (pos + 1u);
-        if ((bits & RB_UNMAPPED) || rlen == 0u) rlen = 1u;
-        const uint32_t rend = pos + rlen;  // reference_end() as u32
-        // fetch(): pos < end_ext && endpos > start_ext (signed pos, pos >= -1 inside the domain)
-        const bool fetched = pvalid && ((int32_t)pos < 0 || pos < W.ee) && rend > W.se;
-        bool skip;
-        if (UNPHASED)
-            skip = W.se < pos || rend < W.ee || mapq <= 10u;  // src/call.rs:297-302
-        else
-            skip = !(bits & RB_HAS_HP) || (W.se < pos && rend < W.ee) || mapq <= 10u;  // :349-355
-        const bool kept = fetched && !skip;
-        uint32_t grp = 0u;
-        if (!UNPHASED && kept) {
-            if (phase > 2u)
-                status |= ST_PHASE;  // calls.get_mut(&phase).unwrap() panics, src/call.rs:358
+    };
+    auto issue = [&]() -> u32x4 {
+        // raw buffer load: offsets at or beyond num_records return 0, no exec masking needed
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(b.cigar4 + h_off4), (short)0, (int)(h_n4 * 16u), 0x00020000);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((hc * 64u + (uint32_t)lane) * 16u), 0, 0);
+        ++hc;
+        if (hc >= h_nchunks) {
+            ++hk;
+            hc = 0;
+            head_load();
+        }
+        return v;
+    };
+    head_load();
+    u32x4 qa = issue(), qb = issue(), qc = issue(), qd = issue();
+
+    // ---- compute cursor ----
+    int tk = 0;
+    uint32_t tc = 0, t_nchunks = 1, t_pos = 0, t_misc = 0, carry = 0;
+    auto tail_load = [&]() {
+        if (tk < cnt) {
+            const uint32_t nc = readlane_u32(m.nc, tk);
+            t_nchunks = max(1u, (nc + 255u) >> 8);
+            t_pos = readlane_u32(m.pos, tk);
+            t_misc = readlane_u32(m.misc, tk);
+            carry = t_pos + 1u;  // (reference_start + 1) as u32, src/call.rs:380
+            lane_range |= carry;
+        }
+    };
+    tail_load();
+
+    auto step = [&](const u32x4 w) {
+        const uint32_t op0 = w.x & 15u, op1 = w.y & 15u, op2 = w.z & 15u, op3 = w.w & 15u;
+        const uint32_t e1 = ref_advance(op0, w.x >> 4);
+        const uint32_t e2 = e1 + ref_advance(op1, w.y >> 4);
+        const uint32_t e3 = e2 + ref_advance(op2, w.z >> 4);
+        const uint32_t tot = e3 + ref_advance(op3, w.w >> 4);
+        const uint32_t incl = wave_inclusive_scan_u32(tot);
+        const uint32_t rel = carry + (incl - tot) - W.se1;  // this lane's first op, relative to start_ext + 1
+        lane_range |= carry + incl;
+        lane_maxop = max(lane_maxop, max(max(op0, op1), max(op2, op3)));
+        // a lane can only contribute if one of its ops may start inside the window and is not M
+        const bool nonM = ((w.x | w.y | w.z | w.w) & 15u) != 0u;
+        const bool inw = nonM && (int32_t)(rel + tot) >= 0 && (int32_t)rel < (int32_t)W.width;
+        const uint64_t mask = ballot64(inw);
+        if (mask) {
+            const uint32_t slot = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (inw) {
+                L.qw[slot] = w;
+                L.qi[slot] = make_uint2(rel, (uint32_t)tk | ((t_misc & (RB_IS_2D << 8)) ? 64u : 0u));
+            }
+            qcount += (uint32_t)__popcll(mask);
+            if (qcount > 64u) drain_queue(L, qcount, W, lane);
+        }
+        carry += readlane_u32(incl, 63);
+        ++tc;
+        if (tc >= t_nchunks) {
+            // ---- wave-uniform epilogue of the pair (scalar unit) ----
+            const uint32_t pos = t_pos;
+            const uint32_t mapq = t_misc & 0xffu, bits = (t_misc >> 8) & 0xffu, phase = (t_misc >> 16) & 0xffu;
+            const bool pvalid = (valid_mask >> tk) & 1ull;
+            // [3P] bam_endpos: rlen = unmapped ? 0 : sum(ref-consuming); rlen == 0 -> 1
+            uint32_t rlen = carry - (pos + 1u);
+            if ((bits & RB_UNMAPPED) || rlen == 0u) rlen = 1u;
+            const uint32_t rend = pos + rlen;  // reference_end() as u32
+            // fetch(): pos < end_ext && endpos > start_ext (signed pos, pos >= -1 inside the domain)
+            const bool fetched = pvalid && ((int32_t)pos < 0 || pos < W.ee) && rend > W.se;
+            bool skip;
+            if (UNPHASED)
+                skip = W.se < pos || rend < W.ee || mapq <= 10u;  // src/call.rs:297-302
             else
-                grp = phase;
+                skip = !(bits & RB_HAS_HP) || (W.se < pos && rend < W.ee) || mapq <= 10u;  // :349-355
+            const bool kept = fetched && !skip;
+            uint32_t grp = 0u;
+            if (!UNPHASED && kept) {
+                if (phase > 2u)
+                    status |= ST_PHASE;  // calls.get_mut(&phase).unwrap() panics, src/call.rs:358
+                else
+                    grp = phase;
+            }
+            const uint32_t pm = pvalid ? ((fetched ? PM_FETCHED : 0u) | (kept ? PM_KEPT : 0u) | (grp << PM_GRP_SHIFT)) : 0u;
+            if (lane == tk) meta = pm;
+            ++tk;
+            tc = 0;
+            tail_load();
         }
-        PairOut o;
-        o.call = pvalid ? call : 0;
-        o.meta = pvalid ? ((clipped ? PM_CLIP : 0u) | (fetched ? PM_FETCHED : 0u) | (kept ? PM_KEPT : 0u) |
-                           (grp << PM_GRP_SHIFT))
-                        : 0u;
-        sink(k, o);
+    };
+
+    // four named buffers, no register rotation: each step waits only for its own load (vmcnt(3))
+    while (tk < cnt) {
+        step(qa);
+        qa = issue();
+        if (tk < cnt) step(qb);
+        qb = issue();
+        if (tk < cnt) step(qc);
+        qc = issue();
+        if (tk < cnt) step(qd);
+        qd = issue();
+    }
+    if (qcount) drain_queue(L, qcount, W, lane);
+    if (ballot64(lane_maxop > 8u)) status |= ST_CIGAR_OP;  // rust-htslib cigar() would panic
+    if (ballot64((lane_range >> 31) != 0u)) status |= ST_RANGE;
+    const bool pvalid = (valid_mask >> lane) & 1ull;
+    if (lane < cnt && pvalid) {
+        val = (int64_t)L.acc[lane];
+        meta |= (L.flags[lane] & 1u) ? PM_CLIP : 0u;
     }
 }
 

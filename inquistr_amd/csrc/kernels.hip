@@ -71,6 +71,7 @@ __device__ __forceinline__ double median_in_lanes(uint64_t gmask, uint64_t clipm
 
 template <bool UNPHASED>
 __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
+    __shared__ WaveLds lds[4];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lb = xcd_remap(blockIdx.x, a.blocks_per_xcd);
@@ -111,14 +112,9 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
     const PairMeta m = load_pair_meta(b, p0, n, lane, status, valid);
     const uint64_t valid_mask = ballot64(valid);
 
-    int64_t val = 0;
-    uint32_t meta = 0;
-    walk_pairs<UNPHASED>(b, m, valid_mask, n, W, lane, status, [&](int k, const PairOut &o) {
-        if (lane == k) {
-            val = o.call;
-            meta = o.meta;
-        }
-    });
+    int64_t val;
+    uint32_t meta;
+    walk_pairs<UNPHASED>(b, m, valid_mask, n, W, lane, status, lds[wave], val, meta);
     if (a.pair_call && lane < n) a.pair_call[p0 + lane] = val;
     if (a.pair_bits && lane < n) a.pair_bits[p0 + lane] = (uint8_t)(meta & 7u);
 
@@ -255,6 +251,7 @@ __device__ void big_group_median(const KArgs &a, uint64_t p0, uint32_t n, int g,
 template <bool UNPHASED>
 __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
     __shared__ BigShared sh;
+    __shared__ WaveLds lds[4];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_big = a.status->big_count[a.parity];
@@ -288,14 +285,9 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
             bool valid;
             const PairMeta m = load_pair_meta(b, first, cnt, lane, status, valid);
             const uint64_t valid_mask = ballot64(valid);
-            int64_t val = 0;
-            uint32_t meta = 0;
-            walk_pairs<UNPHASED>(b, m, valid_mask, cnt, W, lane, status, [&](int k, const PairOut &o) {
-                if (lane == k) {
-                    val = o.call;
-                    meta = o.meta;
-                }
-            });
+            int64_t val;
+            uint32_t meta;
+            walk_pairs<UNPHASED>(b, m, valid_mask, cnt, W, lane, status, lds[wave], val, meta);
             if (lane < cnt) {
                 a.sval[first + lane] = val;
                 a.smeta[first + lane] = (uint8_t)meta;
