@@ -54,9 +54,13 @@ struct BatchView {
 };
 
 // LDS owned by one wave
+struct QueueEntry {
+    u32x4 w;     // the lane's 4 packed ops
+    uint2 info;  // .x = reference position of the first op minus (start_ext+1); .y = read slot | is2d<<6
+    uint2 pad;   // 32-byte stride: one address register serves both stores
+};
 struct WaveLds {
-    u32x4 qw[kQueueCap];       // queued lanes: their 4 packed ops
-    uint2 qi[kQueueCap];       // .x = reference position of the first op minus (start_ext+1); .y = read slot | is2d<<6
+    QueueEntry q[kQueueCap];
     unsigned long long acc[64];  // per read slot: the Call value (two's complement)
     unsigned int flags[64];      // per read slot: bit0 = a soft clip was counted
 };
@@ -100,6 +104,14 @@ constexpr uint32_t kConsume = 0x18Du;
 __device__ __forceinline__ uint32_t ref_advance(uint32_t op, uint32_t len) {
     return len & (uint32_t)__builtin_amdgcn_sbfe((int)kConsume, op, 1u);
 }
+// Same from the raw packed word, without extracting the op: v_bfe_i32 takes its bit offset from
+// the low FIVE bits of the word (op | len&1 << 4), so the 9-entry table is laid down twice.
+constexpr uint32_t kConsume32 = kConsume | (kConsume << 16);
+__device__ __forceinline__ uint32_t ref_advance_raw(uint32_t w) {
+    return (w >> 4) & (uint32_t)__builtin_amdgcn_sbfe((int)kConsume32, w, 1u);
+}
+// bit 0 of (kBadOp32 >> (w & 31)) is set iff the op code is 9..15 (rust-htslib cigar() panics)
+constexpr uint32_t kBadOp32 = 0xFE00FE00u;
 
 // Evaluates the queued window lanes: entry e -> lane e.  src/call.rs:387-403 for 4 ops per lane.
 __device__ __forceinline__ void drain_queue(WaveLds &L, uint32_t &qcount, const Window &W, int lane) {
@@ -110,8 +122,8 @@ __device__ __forceinline__ void drain_queue(WaveLds &L, uint32_t &qcount, const 
     for (uint32_t base = 0; base < qcount; base += 64u) {
         const uint32_t e = base + (uint32_t)lane;
         if (e < qcount) {
-            const u32x4 w = L.qw[e];
-            const uint2 info = L.qi[e];
+            const u32x4 w = L.q[e].w;
+            const uint2 info = L.q[e].info;
             const uint32_t rel = info.x;
             const uint32_t slot = info.y & 63u;
             // soft clips of an accidental-2D read never count (src/call.rs:394): drop S from the candidates
@@ -144,15 +156,15 @@ __device__ __forceinline__ void drain_queue(WaveLds &L, uint32_t &qcount, const 
 // Walks the reads of pairs [0, cnt) described by `m` (lane k owns pair k).  On return lane k holds
 // the pair's Call (src/call.rs:67-71) in `val` and PM_CLIP | PM_FETCHED | PM_KEPT | group in `meta`.
 template <bool UNPHASED>
-__device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m, uint64_t valid_mask, int cnt,
+__device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m, bool valid, int cnt,
                                            const Window &W, int lane, uint32_t &status, WaveLds &L, int64_t &val,
                                            uint32_t &meta) {
-    val = 0;
-    meta = 0;
     L.acc[lane] = 0ull;
     L.flags[lane] = 0u;
     uint32_t qcount = 0;
-    uint32_t lane_range = 0, lane_maxop = 0;
+    uint32_t lane_range = 0, lane_bad = 0;
+    uint32_t end_carry = 0;  // lane k: reference_position after the last op of read k
+    const uint32_t lane4 = (uint32_t)lane * 4u;
 
     // ---- load cursor: runs 4 chunk loads ahead of the compute cursor ----
     int hk = 0;
@@ -187,70 +199,47 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
 
     // ---- compute cursor ----
     int tk = 0;
-    uint32_t tc = 0, t_nchunks = 1, t_pos = 0, t_misc = 0, carry = 0;
+    uint32_t tc = 0, t_nchunks = 1, t_rem = 0, t_info = 0, carry = 0;
     auto tail_load = [&]() {
         if (tk < cnt) {
-            const uint32_t nc = readlane_u32(m.nc, tk);
-            t_nchunks = max(1u, (nc + 255u) >> 8);
-            t_pos = readlane_u32(m.pos, tk);
-            t_misc = readlane_u32(m.misc, tk);
-            carry = t_pos + 1u;  // (reference_start + 1) as u32, src/call.rs:380
+            t_rem = readlane_u32(m.nc, tk);  // ops of this read not yet consumed
+            t_nchunks = max(1u, (t_rem + 255u) >> 8);
+            carry = readlane_u32(m.pos, tk) + 1u;  // (reference_start + 1) as u32, src/call.rs:380
+            t_info = (uint32_t)tk | ((readlane_u32(m.misc, tk) & (RB_IS_2D << 8)) ? 64u : 0u);
             lane_range |= carry;
         }
     };
     tail_load();
 
     auto step = [&](const u32x4 w) {
-        const uint32_t op0 = w.x & 15u, op1 = w.y & 15u, op2 = w.z & 15u, op3 = w.w & 15u;
-        const uint32_t e1 = ref_advance(op0, w.x >> 4);
-        const uint32_t e2 = e1 + ref_advance(op1, w.y >> 4);
-        const uint32_t e3 = e2 + ref_advance(op2, w.z >> 4);
-        const uint32_t tot = e3 + ref_advance(op3, w.w >> 4);
+        const uint32_t e1 = ref_advance_raw(w.x);
+        const uint32_t e2 = e1 + ref_advance_raw(w.y);
+        const uint32_t e3 = e2 + ref_advance_raw(w.z);
+        const uint32_t tot = e3 + ref_advance_raw(w.w);
         const uint32_t incl = wave_inclusive_scan_u32(tot);
-        const uint32_t rel = carry + (incl - tot) - W.se1;  // this lane's first op, relative to start_ext + 1
+        lane_bad |= (kBadOp32 >> (w.x & 31u)) | (kBadOp32 >> (w.y & 31u)) | (kBadOp32 >> (w.z & 31u)) |
+                    (kBadOp32 >> (w.w & 31u));
         lane_range |= carry + incl;
-        lane_maxop = max(lane_maxop, max(max(op0, op1), max(op2, op3)));
-        // a lane can only contribute if one of its ops may start inside the window and is not M
-        const bool nonM = ((w.x | w.y | w.z | w.w) & 15u) != 0u;
-        const bool inw = nonM && (int32_t)(rel + tot) >= 0 && (int32_t)rel < (int32_t)W.width;
+        // x = position after this lane's ops, relative to start_ext + 1.  One of the lane's ops can start
+        // inside the window only if 0 <= x and x - tot < width  <=>  x <u width + tot  (all < 2^31 inside
+        // the parity domain).  Lanes past the read's last op (zero fill) are left out.
+        const uint32_t x = (carry - W.se1) + incl;
+        const bool inw = x < W.width + tot && lane4 < t_rem;
         const uint64_t mask = ballot64(inw);
         if (mask) {
-            const uint32_t slot = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, qcount));
             if (inw) {
-                L.qw[slot] = w;
-                L.qi[slot] = make_uint2(rel, (uint32_t)tk | ((t_misc & (RB_IS_2D << 8)) ? 64u : 0u));
+                L.q[slot].w = w;
+                L.q[slot].info = make_uint2(x - tot, t_info);
             }
             qcount += (uint32_t)__popcll(mask);
             if (qcount > 64u) drain_queue(L, qcount, W, lane);
         }
         carry += readlane_u32(incl, 63);
         ++tc;
+        t_rem -= min(t_rem, 256u);
         if (tc >= t_nchunks) {
-            // ---- wave-uniform epilogue of the pair (scalar unit) ----
-            const uint32_t pos = t_pos;
-            const uint32_t mapq = t_misc & 0xffu, bits = (t_misc >> 8) & 0xffu, phase = (t_misc >> 16) & 0xffu;
-            const bool pvalid = (valid_mask >> tk) & 1ull;
-            // [3P] bam_endpos: rlen = unmapped ? 0 : sum(ref-consuming); rlen == 0 -> 1
-            uint32_t rlen = carry - (pos + 1u);
-            if ((bits & RB_UNMAPPED) || rlen == 0u) rlen = 1u;
-            const uint32_t rend = pos + rlen;  // reference_end() as u32
-            // fetch(): pos < end_ext && endpos > start_ext (signed pos, pos >= -1 inside the domain)
-            const bool fetched = pvalid && ((int32_t)pos < 0 || pos < W.ee) && rend > W.se;
-            bool skip;
-            if (UNPHASED)
-                skip = W.se < pos || rend < W.ee || mapq <= 10u;  // src/call.rs:297-302
-            else
-                skip = !(bits & RB_HAS_HP) || (W.se < pos && rend < W.ee) || mapq <= 10u;  // :349-355
-            const bool kept = fetched && !skip;
-            uint32_t grp = 0u;
-            if (!UNPHASED && kept) {
-                if (phase > 2u)
-                    status |= ST_PHASE;  // calls.get_mut(&phase).unwrap() panics, src/call.rs:358
-                else
-                    grp = phase;
-            }
-            const uint32_t pm = pvalid ? ((fetched ? PM_FETCHED : 0u) | (kept ? PM_KEPT : 0u) | (grp << PM_GRP_SHIFT)) : 0u;
-            if (lane == tk) meta = pm;
+            end_carry = (lane == tk) ? carry : end_carry;
             ++tk;
             tc = 0;
             tail_load();
@@ -269,12 +258,39 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
         qd = issue();
     }
     if (qcount) drain_queue(L, qcount, W, lane);
-    if (ballot64(lane_maxop > 8u)) status |= ST_CIGAR_OP;  // rust-htslib cigar() would panic
+    if (ballot64((lane_bad & 1u) != 0u)) status |= ST_CIGAR_OP;  // rust-htslib cigar() would panic
     if (ballot64((lane_range >> 31) != 0u)) status |= ST_RANGE;
-    const bool pvalid = (valid_mask >> lane) & 1ull;
-    if (lane < cnt && pvalid) {
+
+    // ---- per-read epilogue, one read per lane ----
+    val = 0;
+    meta = 0;
+    if (lane < cnt && valid) {
+        const uint32_t pos = m.pos;
+        const uint32_t mapq = m.misc & 0xffu, bits = (m.misc >> 8) & 0xffu, phase = (m.misc >> 16) & 0xffu;
+        // [3P] bam_endpos: rlen = unmapped ? 0 : sum(ref-consuming); rlen == 0 -> 1
+        uint32_t rlen = end_carry - (pos + 1u);
+        if ((bits & RB_UNMAPPED) || rlen == 0u) rlen = 1u;
+        const uint32_t rend = pos + rlen;  // reference_end() as u32
+        // fetch(): pos < end_ext && endpos > start_ext (signed pos, pos >= -1 inside the domain)
+        const bool fetched = ((int32_t)pos < 0 || pos < W.ee) && rend > W.se;
+        bool skip;
+        if (UNPHASED)
+            skip = W.se < pos || rend < W.ee || mapq <= 10u;  // src/call.rs:297-302
+        else
+            skip = !(bits & RB_HAS_HP) || (W.se < pos && rend < W.ee) || mapq <= 10u;  // :349-355
+        const bool kept = fetched && !skip;
+        uint32_t grp = 0u;
+        bool bad_phase = false;
+        if (!UNPHASED && kept) {
+            if (phase > 2u)
+                bad_phase = true;  // calls.get_mut(&phase).unwrap() panics, src/call.rs:358
+            else
+                grp = phase;
+        }
+        if (bad_phase) status |= ST_PHASE;
         val = (int64_t)L.acc[lane];
-        meta |= (L.flags[lane] & 1u) ? PM_CLIP : 0u;
+        meta = ((L.flags[lane] & 1u) ? PM_CLIP : 0u) | (fetched ? PM_FETCHED : 0u) | (kept ? PM_KEPT : 0u) |
+               (grp << PM_GRP_SHIFT);
     }
 }
 

@@ -110,11 +110,10 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
     BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
     bool valid;
     const PairMeta m = load_pair_meta(b, p0, n, lane, status, valid);
-    const uint64_t valid_mask = ballot64(valid);
 
     int64_t val;
     uint32_t meta;
-    walk_pairs<UNPHASED>(b, m, valid_mask, n, W, lane, status, lds[wave], val, meta);
+    walk_pairs<UNPHASED>(b, m, valid, n, W, lane, status, lds[wave], val, meta);
     if (a.pair_call && lane < n) a.pair_call[p0 + lane] = val;
     if (a.pair_bits && lane < n) a.pair_bits[p0 + lane] = (uint8_t)(meta & 7u);
 
@@ -171,9 +170,9 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
     if (lane == 0) {
         a.phase1[j] = out1;
         a.phase2[j] = out2;
-        if (status) atomicOr(&a.status->err, status);
         if (tie) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
     }
+    if (status) atomicOr(&a.status->err, status);  // per lane: index / phase errors belong to the lane's read
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,10 +283,9 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
             const int cnt = (int)min((uint32_t)kBigPairsPerWave, n - blk * kBigPairsPerWave);
             bool valid;
             const PairMeta m = load_pair_meta(b, first, cnt, lane, status, valid);
-            const uint64_t valid_mask = ballot64(valid);
-            int64_t val;
+                    int64_t val;
             uint32_t meta;
-            walk_pairs<UNPHASED>(b, m, valid_mask, cnt, W, lane, status, lds[wave], val, meta);
+            walk_pairs<UNPHASED>(b, m, valid, cnt, W, lane, status, lds[wave], val, meta);
             if (lane < cnt) {
                 a.sval[first + lane] = val;
                 a.smeta[first + lane] = (uint8_t)meta;
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
                 if (a.pair_bits) a.pair_bits[first + lane] = (uint8_t)(meta & 7u);
             }
         }
-        if (status && lane == 0) atomicOr(&a.status->err, status);
+        if (status) atomicOr(&a.status->err, status);
         __threadfence();
         __syncthreads();
 
