@@ -25,6 +25,19 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def host_threads() -> int:
+    """Host cores this process may really use: cgroup CPU quota if one is set, else the affinity
+    mask, capped at 16 (the per-GPU CPU share of the measurement box)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("INQ_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(wl, sample_loci: int):
     """The oracle (CPU restatement, kind "port") on the first `sample_loci` loci of the same
     workload, all host cores (OpenMP over loci = the reference's rayon par_bridge)."""
@@ -32,7 +45,7 @@ def cpu_baseline(wl, sample_loci: int):
     from oracle import orc
 
     orc.build()
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = host_threads()
     batch = synth.generate_numpy(wl, 0, sample_loci)
     best = None
     for _ in range(5):

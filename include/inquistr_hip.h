@@ -152,7 +152,9 @@ int inq_ctx_timing_enable(inq_ctx_t *ctx, int on);
 int inq_ctx_timing_read(inq_ctx_t *ctx, int which, double *total_ms, uint64_t *launches);
 int inq_ctx_timing_reset(inq_ctx_t *ctx);
 
-/* Tuning knobs.  key: "grid_big" = workgroups launched for the deep-locus kernel (default 256). */
+/* Tuning knobs.  key: "grid_big" = workgroups launched for the deep-locus kernel (default 256);
+ * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
+ * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);
 
 /* Pinned host allocations for batch buffers. */

@@ -38,6 +38,7 @@ struct inq_ctx {
     DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
     uint32_t parity = 0;
     uint32_t grid_big = 256;
+    int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
     bool timing = false;
     std::vector<EvTriple> ev_pool;
     size_t ev_used = 0;
@@ -193,6 +194,9 @@ int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, v
     a.blocks_per_xcd = per_xcd;
     const uint32_t grid_small = per_xcd * 8u;
 
+    // CIGAR words of a read referenced by one locus only are read exactly once: stream them past the
+    // caches (nt).  Reads shared by neighbouring loci keep the default policy so the second locus hits L2.
+    const bool nt = c->nt_loads < 0 ? (b->n_pairs <= b->n_reads) : (c->nt_loads != 0);
     EvTriple *ev = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -205,7 +209,7 @@ int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, v
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->e0, s));
     }
-    launch_locus_call(a, b->unphased != 0, grid_small, c->grid_big, s, ev ? ev->e1 : nullptr);
+    launch_locus_call(a, b->unphased != 0, nt, grid_small, c->grid_big, s, ev ? ev->e1 : nullptr);
     HIP_TRY(c, hipGetLastError());
     if (ev) HIP_TRY(c, hipEventRecord(ev->e2, s));
     return INQ_OK;
@@ -324,6 +328,10 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     if (std::strcmp(key, "grid_big") == 0) {
         if (value < 1 || value > 65535) return INQ_ERR_ARG;
         c->grid_big = (uint32_t)value;
+        return INQ_OK;
+    }
+    if (std::strcmp(key, "nt_loads") == 0) {
+        c->nt_loads = value < 0 ? -1 : (value != 0);
         return INQ_OK;
     }
     return INQ_ERR_ARG;

@@ -83,7 +83,7 @@ __device__ __forceinline__ PairMeta load_pair_meta(const BatchView &b, uint64_t 
             uint64_t n4 = ((uint64_t)r.y + 3u) >> 2;
             if (r.y < 0x10000000u && (uint64_t)r.x + n4 <= b.n_cigar4) {
                 m.off4 = r.x;
-                m.nc = r.y;
+                m.nc = r.y | ((r.w & (RB_IS_2D << 8)) ? 0x80000000u : 0u);  // bit 31 = is_accidental_2d
                 m.pos = r.z;
                 m.misc = r.w;
                 valid = true;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void drain_queue(WaveLds &L, uint32_t &qcount, const 
 
 // Walks the reads of pairs [0, cnt) described by `m` (lane k owns pair k).  On return lane k holds
 // the pair's Call (src/call.rs:67-71) in `val` and PM_CLIP | PM_FETCHED | PM_KEPT | group in `meta`.
-template <bool UNPHASED>
+template <bool UNPHASED, int AUX>
 __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m, bool valid, int cnt,
                                            const Window &W, int lane, uint32_t &status, WaveLds &L, int64_t &val,
                                            uint32_t &meta) {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
     auto head_load = [&]() {
         if (hk < cnt) {
             h_off4 = readlane_u32(m.off4, hk);
-            const uint32_t nc = readlane_u32(m.nc, hk);
+            const uint32_t nc = readlane_u32(m.nc, hk) & 0x7fffffffu;
             h_n4 = (nc + 3u) >> 2;
             h_nchunks = max(1u, (nc + 255u) >> 8);
         } else {
@@ -185,7 +185,7 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
         // raw buffer load: offsets at or beyond num_records return 0, no exec masking needed
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)(b.cigar4 + h_off4), (short)0, (int)(h_n4 * 16u), 0x00020000);
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((hc * 64u + (uint32_t)lane) * 16u), 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((hc * 64u + (uint32_t)lane) * 16u), 0, AUX);
         ++hc;
         if (hc >= h_nchunks) {
             ++hk;
@@ -199,13 +199,14 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
 
     // ---- compute cursor ----
     int tk = 0;
-    uint32_t tc = 0, t_nchunks = 1, t_rem = 0, t_info = 0, carry = 0;
+    uint32_t tc = 0, t_nchunks = 1, t_nc = 0, t_info = 0, carry = 0;
     auto tail_load = [&]() {
         if (tk < cnt) {
-            t_rem = readlane_u32(m.nc, tk);  // ops of this read not yet consumed
-            t_nchunks = max(1u, (t_rem + 255u) >> 8);
+            const uint32_t ncp = readlane_u32(m.nc, tk);
+            t_nc = ncp & 0x7fffffffu;
+            t_nchunks = max(1u, (t_nc + 255u) >> 8);
             carry = readlane_u32(m.pos, tk) + 1u;  // (reference_start + 1) as u32, src/call.rs:380
-            t_info = (uint32_t)tk | ((readlane_u32(m.misc, tk) & (RB_IS_2D << 8)) ? 64u : 0u);
+            t_info = (uint32_t)tk | ((ncp >> 31) << 6);
             lane_range |= carry;
         }
     };
@@ -224,6 +225,7 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
         // inside the window only if 0 <= x and x - tot < width  <=>  x <u width + tot  (all < 2^31 inside
         // the parity domain).  Lanes past the read's last op (zero fill) are left out.
         const uint32_t x = (carry - W.se1) + incl;
+        const uint32_t t_rem = t_nc - (tc << 8);  // ops of this read from this chunk on (scalar)
         const bool inw = x < W.width + tot && lane4 < t_rem;
         const uint64_t mask = ballot64(inw);
         if (mask) {
@@ -237,9 +239,11 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
         }
         carry += readlane_u32(incl, 63);
         ++tc;
-        t_rem -= min(t_rem, 256u);
         if (tc >= t_nchunks) {
-            end_carry = (lane == tk) ? carry : end_carry;
+            // lane tk <- carry: v_writelane takes the value from an SGPR and the lane select from M0
+            // (constant-bus limit: one SGPR).  M0 is a reserved register hipcc never keeps live on
+            // gfx950 (LDS needs no M0 init on GFX9+), so it is free to use inside one asm statement.
+            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(end_carry) : "s"(carry), "s"(tk));
             ++tk;
             tc = 0;
             tail_load();

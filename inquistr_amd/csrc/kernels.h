@@ -36,7 +36,7 @@ struct KArgs {
     uint32_t blocks_per_xcd;  // grid_small / 8
 };
 
-void launch_locus_call(const KArgs &a, bool unphased, uint32_t grid_small, uint32_t grid_big, hipStream_t s,
-                       hipEvent_t ev_mid);
+void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_big,
+                       hipStream_t s, hipEvent_t ev_mid);
 
 }  // namespace inq

@@ -32,10 +32,56 @@ __device__ __forceinline__ bool before(int64_t vj, int j, int64_t v, int i) {
 // real data) meet in the same L2.  Speed only: any placement computes the same result.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t per_xcd) { return (b & 7u) * per_xcd + (b >> 3); }
 
+// Order of the per-read Calls inside one wave (one read per lane).  Every rank below orders by
+// (value, file order).  When every kept value fits 25 bits the pair is packed into ONE i32 key
+// (value << 6 | lane) so a rank costs one v_readlane + one v_cmp per element; otherwise the
+// comparison is done on the i64 value with the lane as tie-break.
+template <bool FIT>
+struct LaneOrder {
+    int64_t val;
+    int32_t key_asc;   // (val << 6) | lane
+    int32_t key_desc;  // (val << 6) | (63 - lane): "larger value first, then earlier read"
+    int lane;
+    __device__ __forceinline__ LaneOrder(int64_t v, int l) : val(v), lane(l) {
+        key_asc = (int32_t)(((uint32_t)(int32_t)v << 6) | (uint32_t)l);
+        key_desc = (int32_t)(((uint32_t)(int32_t)v << 6) | (uint32_t)(63 - l));
+    }
+    // number of lanes j in `mask` whose (value, j) sorts before this lane's
+    __device__ __forceinline__ uint32_t rank_asc(uint64_t mask) const {
+        uint32_t r = 0;
+        for (uint64_t mk = mask; mk; mk &= mk - 1) {
+            const int j = __builtin_ctzll(mk);
+            if (FIT) {
+                r += ((int32_t)readlane_u32((uint32_t)key_asc, j) < key_asc) ? 1u : 0u;
+            } else {
+                const int64_t vj = readlane_i64(val, j);
+                r += before(vj, j, val, lane) ? 1u : 0u;
+            }
+        }
+        return r;
+    }
+    // number of lanes j in `mask` with a larger value (ties: earlier read first)
+    __device__ __forceinline__ uint32_t rank_desc(uint64_t mask) const {
+        uint32_t r = 0;
+        for (uint64_t mk = mask; mk; mk &= mk - 1) {
+            const int j = __builtin_ctzll(mk);
+            if (FIT) {
+                r += ((int32_t)readlane_u32((uint32_t)key_desc, j) > key_desc) ? 1u : 0u;
+            } else {
+                const int64_t vj = readlane_i64(val, j);
+                r += (vj > val || (vj == val && j < lane)) ? 1u : 0u;
+            }
+        }
+        return r;
+    }
+};
+
 // median_str_length (src/call.rs:497-522) for the elements flagged in `gmask`, one element per
 // lane.  Wave-uniform result.
-__device__ __forceinline__ double median_in_lanes(uint64_t gmask, uint64_t clipmask, int64_t val, int lane,
+template <bool FIT>
+__device__ __forceinline__ double median_in_lanes(uint64_t gmask, uint64_t clipmask, const LaneOrder<FIT> &o,
                                                   uint32_t support) {
+    const int lane = o.lane;
     const uint32_t ng = (uint32_t)__popcll(gmask);
     if (ng < support) return qnan();  // :498-500
     const uint64_t cm = gmask & clipmask, sm = gmask & ~clipmask;
@@ -44,32 +90,71 @@ __device__ __forceinline__ double median_in_lanes(uint64_t gmask, uint64_t clipm
     if (ns <= support && cm != 0ull) {  // :509-513: add the largest (support - ns) clipped values
         const uint32_t take = support - ns;
         if (take > 0u) {
-            uint32_t drank = 0;
-            for (uint64_t mk = cm; mk; mk &= mk - 1) {
-                const int j = __builtin_ctzll(mk);
-                const int64_t vj = readlane_i64(val, j);
-                drank += (vj > val || (vj == val && j < lane)) ? 1u : 0u;
-            }
+            const uint32_t drank = o.rank_desc(cm);
             chosen |= ballot64(((cm >> lane) & 1ull) && drank < take);
         }
     }
     const uint32_t M = (uint32_t)__popcll(chosen);  // >= 1 because support >= 1
-    uint32_t arank = 0;
-    for (uint64_t mk = chosen; mk; mk &= mk - 1) {
-        const int j = __builtin_ctzll(mk);
-        const int64_t vj = readlane_i64(val, j);
-        arank += before(vj, j, val, lane) ? 1u : 0u;
-    }
+    const uint32_t arank = o.rank_asc(chosen);
     const bool mine = (chosen >> lane) & 1ull;
     const int lhi = __builtin_ctzll(ballot64(mine && arank == M / 2u));
-    const int64_t vhi = readlane_i64(val, lhi);
+    const int64_t vhi = readlane_i64(o.val, lhi);
     if (M & 1u) return (double)vhi;  // :520
     const int llo = __builtin_ctzll(ballot64(mine && arank == M / 2u - 1u));
-    const int64_t vlo = readlane_i64(val, llo);
+    const int64_t vlo = readlane_i64(o.val, llo);
     return (double)(vlo + vhi) / 2.0;  // :515-518
 }
 
-template <bool UNPHASED>
+// The two medians of one locus from the per-read (val, meta) held one per lane.
+template <bool UNPHASED, bool FIT>
+__device__ __forceinline__ void reduce_locus_in_lanes(int64_t val, uint32_t meta, int lane, uint32_t support,
+                                                      double &out1, double &out2, bool &tie) {
+    const LaneOrder<FIT> o(val, lane);
+    const uint64_t kept = ballot64(meta & PM_KEPT);
+    const uint64_t clipmask = ballot64((meta & PM_KEPT) && (meta & PM_CLIP));
+    tie = false;
+    if (UNPHASED) {
+        // src/call.rs:311-313: sort by value (ties: file order), h1 = lower n/2, h2 = the rest
+        const uint32_t mcount = (uint32_t)__popcll(kept);
+        const uint32_t ks = mcount / 2u;
+        const uint32_t rank = o.rank_asc(kept);
+        const bool mine = (kept >> lane) & 1ull;
+        auto pick = [&](uint32_t r) -> int64_t {
+            return readlane_i64(val, __builtin_ctzll(ballot64(mine && rank == r)));
+        };
+        if (clipmask == 0ull) {
+            // no soft-clipped call at this locus: every group member is "spanning", so the
+            // within-group order is the global order and the medians can be read off `rank`
+            auto med = [&](uint32_t base, uint32_t cnt) -> double {
+                if (cnt < support) return qnan();
+                if (cnt & 1u) return (double)pick(base + cnt / 2u);
+                return (double)(pick(base + cnt / 2u - 1u) + pick(base + cnt / 2u)) / 2.0;
+            };
+            out1 = med(0u, ks);
+            out2 = med(ks, mcount - ks);
+        } else {
+            const uint64_t g1 = ballot64(mine && rank < ks);
+            const uint64_t g2 = kept & ~g1;
+            if (ks >= 1u && ks < mcount) {
+                const int64_t va = pick(ks - 1u), vb = pick(ks);
+                if (va == vb) {
+                    const uint64_t eq = ballot64(mine && val == va);
+                    tie = (eq & clipmask) != 0ull && (eq & ~clipmask) != 0ull;
+                }
+            }
+            out1 = median_in_lanes<FIT>(g1, clipmask, o, support);
+            out2 = median_in_lanes<FIT>(g2, clipmask, o, support);
+        }
+    } else {
+        const uint64_t g1 = ballot64(((meta >> PM_GRP_SHIFT) & 3u) == 1u);
+        const uint64_t g2 = ballot64(((meta >> PM_GRP_SHIFT) & 3u) == 2u);
+        out1 = median_in_lanes<FIT>(g1, clipmask, o, support);  // src/call.rs:367
+        out2 = median_in_lanes<FIT>(g2, clipmask, o, support);  // src/call.rs:368
+    }
+}
+
+// AUX: cache policy of the CIGAR stream loads (0 = default, 2 = nt: read-once data)
+template <bool UNPHASED, int AUX>
 __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
     __shared__ WaveLds lds[4];
     const int lane = threadIdx.x & 63;
@@ -113,60 +198,17 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
 
     int64_t val;
     uint32_t meta;
-    walk_pairs<UNPHASED>(b, m, valid, n, W, lane, status, lds[wave], val, meta);
+    walk_pairs<UNPHASED, AUX>(b, m, valid, n, W, lane, status, lds[wave], val, meta);
     if (a.pair_call && lane < n) a.pair_call[p0 + lane] = val;
     if (a.pair_bits && lane < n) a.pair_bits[p0 + lane] = (uint8_t)(meta & 7u);
 
-    const uint64_t kept = ballot64(meta & PM_KEPT);
-    const uint64_t clipmask = ballot64((meta & PM_KEPT) && (meta & PM_CLIP));
-    uint64_t g1, g2;
-    bool tie = false;
+    bool tie;
     double out1, out2;
-    if (UNPHASED) {
-        // src/call.rs:311-313: sort by value (ties: file order), h1 = lower n/2, h2 = the rest
-        const uint32_t mcount = (uint32_t)__popcll(kept);
-        const uint32_t ks = mcount / 2u;
-        uint32_t rank = 0;
-        for (uint64_t mk = kept; mk; mk &= mk - 1) {
-            const int jj = __builtin_ctzll(mk);
-            const int64_t vj = readlane_i64(val, jj);
-            rank += before(vj, jj, val, lane) ? 1u : 0u;
-        }
-        const bool mine = (kept >> lane) & 1ull;
-        g1 = ballot64(mine && rank < ks);
-        g2 = kept & ~g1;
-        if (clipmask == 0ull) {
-            // no soft-clipped call at this locus: every group member is "spanning", so the
-            // within-group order is the global order and the medians can be read off `rank`
-            auto pick = [&](uint32_t r) -> int64_t {
-                const int l = __builtin_ctzll(ballot64(mine && rank == r));
-                return readlane_i64(val, l);
-            };
-            auto med = [&](uint32_t base, uint32_t cnt) -> double {
-                if (cnt < a.support) return qnan();
-                if (cnt & 1u) return (double)pick(base + cnt / 2u);
-                return (double)(pick(base + cnt / 2u - 1u) + pick(base + cnt / 2u)) / 2.0;
-            };
-            out1 = med(0u, ks);
-            out2 = med(ks, mcount - ks);
-        } else {
-            if (ks >= 1u && ks < mcount) {
-                const int64_t va = readlane_i64(val, __builtin_ctzll(ballot64(mine && rank == ks - 1u)));
-                const int64_t vb = readlane_i64(val, __builtin_ctzll(ballot64(mine && rank == ks)));
-                if (va == vb) {
-                    const uint64_t eq = ballot64(mine && val == va);
-                    tie = (eq & clipmask) != 0ull && (eq & ~clipmask) != 0ull;
-                }
-            }
-            out1 = median_in_lanes(g1, clipmask, val, lane, a.support);
-            out2 = median_in_lanes(g2, clipmask, val, lane, a.support);
-        }
-    } else {
-        g1 = ballot64(((meta >> PM_GRP_SHIFT) & 3u) == 1u);
-        g2 = ballot64(((meta >> PM_GRP_SHIFT) & 3u) == 2u);
-        out1 = median_in_lanes(g1, clipmask, val, lane, a.support);  // src/call.rs:367
-        out2 = median_in_lanes(g2, clipmask, val, lane, a.support);  // src/call.rs:368
-    }
+    const bool big_value = (meta & PM_KEPT) && (val < -(1ll << 24) || val >= (1ll << 24));
+    if (ballot64(big_value) == 0ull)
+        reduce_locus_in_lanes<UNPHASED, true>(val, meta, lane, a.support, out1, out2, tie);
+    else
+        reduce_locus_in_lanes<UNPHASED, false>(val, meta, lane, a.support, out1, out2, tie);
     if (lane == 0) {
         a.phase1[j] = out1;
         a.phase2[j] = out2;
@@ -247,7 +289,7 @@ __device__ void big_group_median(const KArgs &a, uint64_t p0, uint32_t n, int g,
     __syncthreads();
 }
 
-template <bool UNPHASED>
+template <bool UNPHASED, int AUX>
 __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
     __shared__ BigShared sh;
     __shared__ WaveLds lds[4];
@@ -285,7 +327,7 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
             const PairMeta m = load_pair_meta(b, first, cnt, lane, status, valid);
                     int64_t val;
             uint32_t meta;
-            walk_pairs<UNPHASED>(b, m, valid, cnt, W, lane, status, lds[wave], val, meta);
+            walk_pairs<UNPHASED, AUX>(b, m, valid, cnt, W, lane, status, lds[wave], val, meta);
             if (lane < cnt) {
                 a.sval[first + lane] = val;
                 a.smeta[first + lane] = (uint8_t)meta;
@@ -366,19 +408,26 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
 }
 
 // ---- launchers (called from capi.hip) ----
-void launch_locus_call(const KArgs &a, bool unphased, uint32_t grid_small, uint32_t grid_big, hipStream_t s,
-                       hipEvent_t ev_mid) {
-    if (grid_small) {
-        if (unphased)
-            hipLaunchKernelGGL(locus_call_small<true>, dim3(grid_small), dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL(locus_call_small<false>, dim3(grid_small), dim3(256), 0, s, a);
-    }
+template <bool UNPHASED, int AUX>
+static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid) {
+    if (grid_small) hipLaunchKernelGGL((locus_call_small<UNPHASED, AUX>), dim3(grid_small), dim3(256), 0, s, a);
     if (ev_mid) (void)hipEventRecord(ev_mid, s);
-    if (unphased)
-        hipLaunchKernelGGL(locus_call_big<true>, dim3(grid_big), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(locus_call_big<false>, dim3(grid_big), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((locus_call_big<UNPHASED, AUX>), dim3(grid_big), dim3(256), 0, s, a);
+}
+
+void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_big,
+                       hipStream_t s, hipEvent_t ev_mid) {
+    if (unphased) {
+        if (nt_loads)
+            launch_t<true, 2>(a, grid_small, grid_big, s, ev_mid);
+        else
+            launch_t<true, 0>(a, grid_small, grid_big, s, ev_mid);
+    } else {
+        if (nt_loads)
+            launch_t<false, 2>(a, grid_small, grid_big, s, ev_mid);
+        else
+            launch_t<false, 0>(a, grid_small, grid_big, s, ev_mid);
+    }
 }
 
 }  // namespace inq

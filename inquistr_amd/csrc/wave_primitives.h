@@ -71,6 +71,6 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int l) {
     uint32_t hi = readlane_u32((uint32_t)((uint64_t)v >> 32), l);
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 }  // namespace inq

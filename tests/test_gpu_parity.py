@@ -149,6 +149,37 @@ def test_clip_heavy_ties(ctx, orc):
         _assert_same(got, want, f"unphased={unphased}")
 
 
+@pytest.mark.parametrize("unphased", [False, True])
+def test_huge_values(ctx, orc, unphased):
+    """Calls beyond 25 and beyond 32 bits: the i64 ranking path (28-bit op lengths, several per read)."""
+    import random
+
+    rng = random.Random(11)
+    big = (1 << 28) - 1
+    bb = B.BatchBuilder(minlen=5, support=2, unphased=unphased)
+    for j in range(40):
+        start = 10_000 + 3000 * j
+        idx = []
+        for k in range(rng.choice([4, 9, 16, 31])):
+            n_big = rng.choice([0, 1, 1, 3, 9, 17, 40])
+            cig = [("M", 100)]
+            for i in range(n_big):
+                # insertions do not advance the reference, so all of them start inside the window; a
+                # deletion may only come last (it moves everything behind it out of the window)
+                op = "D" if (i == n_big - 1 and rng.random() < 0.4) else "I"
+                cig += [(op, big if n_big == 40 else rng.choice([big, big - 1, 1 << 24, (1 << 24) - 1, 1 << 26])), ("M", 1)]
+            cig += [("I", rng.choice([6, 7, 8])), ("M", 300)]
+            idx.append(bb.add_read(start - 10 - 80, B.encode_cigar(cig), phase=1 + (k & 1),
+                                   is_2d=False))
+        bb.add_locus(start, start + 60, idx)
+    batch = bb.build()
+    rc, got = ctx.call_batch(batch, debug=True)
+    oc, want = orc.call_batch(batch, debug=True)
+    assert rc == oc == 0
+    assert np.abs(want.pair_call).max() > (1 << 32)
+    _assert_same(got, want, f"huge unphased={unphased}")
+
+
 def test_empty_and_ragged(ctx, orc):
     rc, res = ctx.call_batch(B.BatchBuilder().build())
     assert rc == 0 and res.phase1.shape == (0,)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""A/B of ctx options in ONE process, interleaved rounds (cdna_hip_programming.md §5.4 rule 24).
+usage: python tools/ab_options.py key=v1,v2 [--workload unphased100k] [--rounds 8] [--steps 10]"""
+import argparse, os, sys, time, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from inquistr_amd import hipcall, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("spec")
+ap.add_argument("--workload", default="unphased100k")
+ap.add_argument("--loci", type=int, default=0)
+ap.add_argument("--rounds", type=int, default=8)
+ap.add_argument("--steps", type=int, default=10)
+a = ap.parse_args()
+key, vals = a.spec.split("=")
+vals = [int(v) for v in vals.split(",")]
+wl = synth.WORKLOADS[a.workload]
+dev = torch.device("cuda:0")
+d = synth.DeviceBatch(wl, dev, 0, a.loci or wl.n_loci)
+ctx = hipcall.Context(0)
+st = torch.cuda.current_stream().cuda_stream
+res = {v: [] for v in vals}
+ctx.timing_enable(True)
+for r in range(a.rounds + 1):
+    for v in vals:
+        ctx.set_option(key, v)
+        ctx.timing_reset()
+        for _ in range(a.steps):
+            ctx.call_batch_device(d.c_batch, d.c_result, st)
+        torch.cuda.synchronize()
+        ms, n = ctx.timing_read(1)
+        if r:  # round 0 = warm-up
+            res[v].append(ms / n)
+assert ctx.status()[0] == 0
+ab = d.algorithmic_bytes()
+for v in vals:
+    m = statistics.median(res[v]); mn = min(res[v])
+    print(f"{key}={v}: median {m*1e3:.1f} us  min {mn*1e3:.1f} us  -> {ab/m/1e6:.0f} GB/s median, {ab/mn/1e6:.0f} GB/s best")
