@@ -1,0 +1,80 @@
+/*
+ * inquistr_host.h — C ABI of the host side of `inquiSTR call` (libinquistr_host.so).
+ *
+ * Mirrors the reference's one entry point for this path,
+ *     call::genotype_repeats(bamp, region, region_file, minlen, support, threads, unphased,
+ *                            sample_name, reference)                      src/call.rs:76-86
+ * with the same argument meaning and the same observable behaviour: `.inq` text on the output
+ * stream, diagnostics on stderr, and an exit status (0, 1 for the reference's explicit
+ * `exit(1)` paths, 101 where the reference panics).  The hot path itself is delegated to
+ * libinquistr_hip.so (include/inquistr_hip.h); there is no CPU implementation of it here.
+ *
+ * The front-end entry points below expose the BAM -> batch stage on its own (what
+ * bam.fetch()/rc_records() + record accessors do in the reference, src/call.rs:288-299,338-352)
+ * so that it can be tested without a GPU and driven by another host.
+ */
+#ifndef INQUISTR_HOST_H
+#define INQUISTR_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "inquistr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* clap arguments of `inquiSTR call`, src/main.rs:27-64 */
+typedef struct inq_call_args {
+    const char *bam;         /* positional */
+    const char *region;      /* -r, NULL if absent */
+    const char *region_file; /* -R, NULL if absent */
+    uint32_t minlen;         /* -m, default 5 */
+    uint64_t support;        /* -s, default 3 */
+    uint64_t threads;        /* -t, default 1: 1 = rows in BED order, >1 = rows sorted (src/call.rs:141) */
+    int32_t unphased;        /* -u */
+    const char *sample_name; /* --sample-name, NULL if absent */
+    const char *reference;   /* --reference (CRAM only; CRAM is not supported here) */
+    int32_t device;          /* HIP device ordinal (not a reference argument) */
+    int32_t reserved;
+} inq_call_args_t;
+
+#define INQ_EXIT_OK 0
+#define INQ_EXIT_ERROR 1   /* the reference's std::process::exit(1) paths          */
+#define INQ_EXIT_PANIC 101 /* the reference's panic!/expect/unwrap paths          */
+
+/* Runs the whole command; writes header + rows to out_fd.  Returns the exit status; a message
+ * for non-zero statuses is copied to errbuf (and printed to stderr by the CLI). */
+int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap);
+
+/* ---- BAM -> batch front end (no GPU involved) ---- */
+typedef struct inq_frontend inq_frontend_t;
+int inq_frontend_open(const inq_call_args_t *args, inq_frontend_t **out, char *errbuf, size_t errcap);
+uint64_t inq_frontend_n_targets(const inq_frontend_t *fe);
+int inq_frontend_target(const inq_frontend_t *fe, uint64_t i, const char **chrom, uint32_t *start, uint32_t *end);
+const char *inq_frontend_sample(const inq_frontend_t *fe);
+/* Next batch: 1 = *batch filled (host pointers, valid until the next call), 0 = no more, <0 = exit
+ * status negated.  locus_index[j] = position of batch locus j in the target list. */
+int inq_frontend_next(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **locus_index, char *errbuf,
+                      size_t errcap);
+void inq_frontend_set_batch_words(inq_frontend_t *fe, uint64_t max_cigar_words);
+void inq_frontend_close(inq_frontend_t *fe);
+
+/* ---- text side (src/call.rs:27-65, 91-101) ---- */
+size_t inq_host_format_f64(double v, char *buf, size_t cap);
+size_t inq_host_format_row(const char *chrom, uint32_t start, uint32_t end, double p1, double p2, char *buf, size_t cap);
+size_t inq_host_format_header(const char *sample, char *buf, size_t cap);
+size_t inq_host_sample_name(const char *bam_path, char *buf, size_t cap);
+int inq_host_human_compare(const char *a, const char *b);
+/* RepeatIntervalIterator::from_string against a one-contig length table; 0 ok, 101 panic */
+int inq_host_parse_region(const char *reg, const char *chrom_name, uint64_t chrom_len, char *chrom_out, size_t cap,
+                          uint32_t *start, uint32_t *end);
+/* BAI facts (for fixtures): number of references, and mapped/unmapped counts of one */
+int inq_host_bai_stats(const char *bai_path, uint32_t *n_ref, int32_t tid, uint64_t *n_mapped, uint64_t *n_unmapped,
+                       uint64_t *n_bins, uint64_t *n_intv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+"""Host-side mirror of the reference's `call::genotype_repeats` (src/call.rs:76-159).
+
+Same argument list and meaning; the work is done by libinquistr_host.so (C++ BAM front end +
+driver) which drives the HIP library.  The `.inq` text goes to `out` (default: stdout), a
+non-zero status raises `CallError` carrying the exit code the reference process would have had
+(1 for its explicit `exit(1)` paths, 101 for its panics).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+from typing import Iterator, Optional, Tuple
+
+import numpy as np
+
+from .batch import READ_DTYPE, Batch, InqBatchC
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_PKG, "lib", "libinquistr_host.so")
+CLI_PATH = os.path.join(_PKG, "lib", "inquistr")
+
+HOST_ABI_SYMBOLS = (
+    "inq_genotype_repeats",
+    "inq_frontend_open",
+    "inq_frontend_n_targets",
+    "inq_frontend_target",
+    "inq_frontend_sample",
+    "inq_frontend_next",
+    "inq_frontend_set_batch_words",
+    "inq_frontend_close",
+    "inq_host_format_f64",
+    "inq_host_format_row",
+    "inq_host_format_header",
+    "inq_host_sample_name",
+    "inq_host_human_compare",
+    "inq_host_parse_region",
+    "inq_host_bai_stats",
+)
+
+
+class CallArgsC(C.Structure):
+    _fields_ = [
+        ("bam", C.c_char_p),
+        ("region", C.c_char_p),
+        ("region_file", C.c_char_p),
+        ("minlen", C.c_uint32),
+        ("support", C.c_uint64),
+        ("threads", C.c_uint64),
+        ("unphased", C.c_int32),
+        ("sample_name", C.c_char_p),
+        ("reference", C.c_char_p),
+        ("device", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class CallError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"inquistr call failed (exit status {status}): {message}")
+        self.status, self.message = status, message
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} not found: run __graft_entry__.build()")
+        L = C.CDLL(HOST_LIB_PATH)
+        vp = C.c_void_p
+        L.inq_genotype_repeats.restype = C.c_int
+        L.inq_genotype_repeats.argtypes = [C.POINTER(CallArgsC), C.c_int, C.c_char_p, C.c_size_t]
+        L.inq_frontend_open.restype = C.c_int
+        L.inq_frontend_open.argtypes = [C.POINTER(CallArgsC), C.POINTER(vp), C.c_char_p, C.c_size_t]
+        L.inq_frontend_n_targets.restype = C.c_uint64
+        L.inq_frontend_n_targets.argtypes = [vp]
+        L.inq_frontend_target.restype = C.c_int
+        L.inq_frontend_target.argtypes = [vp, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.inq_frontend_sample.restype = C.c_char_p
+        L.inq_frontend_sample.argtypes = [vp]
+        L.inq_frontend_next.restype = C.c_int
+        L.inq_frontend_next.argtypes = [vp, C.POINTER(InqBatchC), C.POINTER(C.POINTER(C.c_uint32)), C.c_char_p, C.c_size_t]
+        L.inq_frontend_set_batch_words.restype = None
+        L.inq_frontend_set_batch_words.argtypes = [vp, C.c_uint64]
+        L.inq_frontend_close.restype = None
+        L.inq_frontend_close.argtypes = [vp]
+        L.inq_host_format_f64.restype = C.c_size_t
+        L.inq_host_format_f64.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
+        L.inq_host_format_row.restype = C.c_size_t
+        L.inq_host_format_row.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_char_p, C.c_size_t]
+        L.inq_host_format_header.restype = C.c_size_t
+        L.inq_host_format_header.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.inq_host_sample_name.restype = C.c_size_t
+        L.inq_host_sample_name.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.inq_host_human_compare.restype = C.c_int
+        L.inq_host_human_compare.argtypes = [C.c_char_p, C.c_char_p]
+        L.inq_host_parse_region.restype = C.c_int
+        L.inq_host_parse_region.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.inq_host_bai_stats.restype = C.c_int
+        L.inq_host_bai_stats.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, reference, device=0) -> CallArgsC:
+    a = CallArgsC()
+    a.bam = os.fspath(bamp).encode()
+    a.region = region.encode() if region is not None else None
+    a.region_file = os.fspath(region_file).encode() if region_file is not None else None
+    a.minlen, a.support, a.threads = int(minlen), int(support), int(threads)
+    a.unphased = 1 if unphased else 0
+    a.sample_name = sample_name.encode() if sample_name is not None else None
+    a.reference = reference.encode() if reference is not None else None
+    a.device = device
+    return a
+
+
+def genotype_repeats(bamp: str, region: Optional[str], region_file: Optional[str], minlen: int = 5, support: int = 3,
+                     threads: int = 1, unphased: bool = False, sample_name: Optional[str] = None,
+                     reference: Optional[str] = None, out=None, device: int = 0) -> None:
+    """src/call.rs:76-86: same parameters, same output; raises CallError instead of exiting."""
+    L = load()
+    a = _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, reference, device)
+    err = C.create_string_buffer(2048)
+    out = sys.stdout if out is None else out
+    out.flush()
+    fd = out.fileno()
+    rc = L.inq_genotype_repeats(C.byref(a), fd, err, len(err))
+    if rc != 0:
+        raise CallError(rc, err.value.decode(errors="replace"))
+
+
+class FrontEnd:
+    """BAM + targets -> batches (the fetch()/rc_records() stage), no GPU involved."""
+
+    def __init__(self, bamp, region=None, region_file=None, minlen=5, support=3, threads=1, unphased=False,
+                 sample_name=None, max_batch_words: int = 0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self._args = _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, None)
+        err = C.create_string_buffer(2048)
+        rc = self._L.inq_frontend_open(C.byref(self._args), C.byref(self._h), err, len(err))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise CallError(rc, err.value.decode(errors="replace"))
+        if max_batch_words:
+            self._L.inq_frontend_set_batch_words(self._h, max_batch_words)
+
+    @property
+    def sample(self) -> str:
+        return self._L.inq_frontend_sample(self._h).decode()
+
+    def targets(self):
+        out = []
+        for i in range(self._L.inq_frontend_n_targets(self._h)):
+            c, s, e = C.c_char_p(), C.c_uint32(), C.c_uint32()
+            self._L.inq_frontend_target(self._h, i, C.byref(c), C.byref(s), C.byref(e))
+            out.append((c.value.decode(), s.value, e.value))
+        return out
+
+    def batches(self) -> Iterator[Tuple[Batch, np.ndarray]]:
+        """Yields (Batch copy, locus_index) until the BAM is exhausted."""
+        while True:
+            bc = InqBatchC()
+            idx = C.POINTER(C.c_uint32)()
+            err = C.create_string_buffer(2048)
+            rc = self._L.inq_frontend_next(self._h, C.byref(bc), C.byref(idx), err, len(err))
+            if rc < 0:
+                raise CallError(-rc, err.value.decode(errors="replace"))
+            if rc == 0:
+                return
+
+            def arr(ptr, n, dt):
+                if not n:
+                    return np.zeros(0, dtype=dt)
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
+
+            b = Batch(
+                cigar=arr(bc.cigar, bc.n_cigar_words, np.uint32),
+                reads=arr(bc.reads, bc.n_reads, READ_DTYPE),
+                pair_read=arr(bc.pair_read, bc.n_pairs, np.uint32),
+                locus_pair_off=arr(bc.locus_pair_off, bc.n_loci + 1, np.uint64),
+                locus_start=arr(bc.locus_start, bc.n_loci, np.uint32),
+                locus_end=arr(bc.locus_end, bc.n_loci, np.uint32),
+                minlen=bc.minlen, support=bc.support, unphased=bool(bc.unphased),
+            )
+            yield b, np.ctypeslib.as_array(idx, shape=(max(int(bc.n_loci), 1),))[: int(bc.n_loci)].copy()
+
+    def close(self):
+        if self._h and self._h.value:
+            self._L.inq_frontend_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

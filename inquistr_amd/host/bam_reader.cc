@@ -1,0 +1,318 @@
+#include "bam_reader.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace inqhost {
+
+static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+// ---------------- BAI ----------------
+
+bool BaiIndex::load(const std::string &path, std::string *err) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) {
+        if (err) *err = "cannot open index " + path;
+        return false;
+    }
+    std::vector<uint8_t> d;
+    uint8_t tmp[1 << 16];
+    size_t n;
+    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) d.insert(d.end(), tmp, tmp + n);
+    std::fclose(f);
+    size_t p = 0;
+    auto need = [&](size_t k) { return p + k <= d.size(); };
+    if (!need(8) || std::memcmp(d.data(), "BAI\1", 4) != 0) {
+        if (err) *err = "not a BAI file: " + path;
+        return false;
+    }
+    p = 4;
+    uint32_t n_ref = le32(&d[p]);
+    p += 4;
+    refs.assign(n_ref, BaiRef());
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        BaiRef &R = refs[r];
+        if (!need(4)) goto trunc;
+        {
+            uint32_t n_bin = le32(&d[p]);
+            p += 4;
+            bool first = true;
+            for (uint32_t b = 0; b < n_bin; ++b) {
+                if (!need(8)) goto trunc;
+                uint32_t bin = le32(&d[p]);
+                uint32_t n_chunk = le32(&d[p + 4]);
+                p += 8;
+                if (!need((size_t)n_chunk * 16)) goto trunc;
+                if (bin == 37450 && n_chunk == 2) {  // htslib pseudo-bin: [file range], [mapped, unmapped]
+                    R.has_meta = true;
+                    R.n_mapped = le64(&d[p + 16]);
+                    R.n_unmapped = le64(&d[p + 24]);
+                } else {
+                    auto &v = R.bins[bin];
+                    for (uint32_t c = 0; c < n_chunk; ++c) {
+                        uint64_t beg = le64(&d[p + 16 * c]), end = le64(&d[p + 16 * c + 8]);
+                        v.emplace_back(beg, end);
+                        if (first || beg < R.min_offset) R.min_offset = beg;
+                        if (first || end > R.max_offset) R.max_offset = end;
+                        first = false;
+                    }
+                }
+                p += (size_t)n_chunk * 16;
+            }
+            if (!need(4)) goto trunc;
+            uint32_t n_intv = le32(&d[p]);
+            p += 4;
+            if (!need((size_t)n_intv * 8)) goto trunc;
+            R.ioffset.resize(n_intv);
+            for (uint32_t i = 0; i < n_intv; ++i) R.ioffset[i] = le64(&d[p + 8 * i]);
+            p += (size_t)n_intv * 8;
+        }
+    }
+    if (need(8)) n_no_coor = le64(&d[p]);
+    return true;
+trunc:
+    if (err) *err = "truncated BAI file: " + path;
+    return false;
+}
+
+uint64_t BaiIndex::scan_start(int tid, int64_t beg) const {
+    if (tid < 0 || (size_t)tid >= refs.size()) return 0;
+    const BaiRef &R = refs[tid];
+    if (R.bins.empty()) return 0;
+    if (beg < 0) beg = 0;
+    size_t w = (size_t)(beg >> 14);
+    if (w >= R.ioffset.size()) {
+        // no record overlaps any window at or beyond the last indexed one... except through the
+        // linear index being shorter than the data's reach; fall back to the bins
+        return R.ioffset.empty() ? R.min_offset : 0;
+    }
+    // the linear index holds, per 16 kb window, the smallest offset of a record overlapping it;
+    // empty windows are 0 in files written by some tools: look forward for the next filled one
+    // (records overlapping an empty window do not exist, later records start later in the file)
+    for (size_t i = w; i < R.ioffset.size(); ++i)
+        if (R.ioffset[i]) return R.ioffset[i];
+    return 0;
+}
+
+// ---------------- BAM ----------------
+
+int64_t bam_ref_span(const uint32_t *cigar, uint32_t n) {
+    int64_t rlen = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t op = cigar[i] & 0xf;
+        if ((0x18Du >> op) & 1u) rlen += cigar[i] >> 4;  // M D N = X
+    }
+    return rlen;
+}
+
+bool BamFile::open(const std::string &path, std::string *err) {
+    if (!bgzf_.open(path, err)) return false;
+    uint8_t m[8];
+    if (bgzf_.read(m, 8, err) != 8 || std::memcmp(m, "BAM\1", 4) != 0) {
+        if (err && err->empty()) *err = "not a BAM file: " + path;
+        return false;
+    }
+    uint32_t l_text = le32(m + 4);
+    text_.assign(l_text, '\0');
+    if (l_text && bgzf_.read(&text_[0], l_text, err) != (int64_t)l_text) return false;
+    while (!text_.empty() && text_.back() == '\0') text_.pop_back();
+    uint8_t nr[4];
+    if (bgzf_.read(nr, 4, err) != 4) return false;
+    uint32_t n_ref = le32(nr);
+    refs_.clear();
+    name2tid_.clear();
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        uint8_t l[4];
+        if (bgzf_.read(l, 4, err) != 4) return false;
+        uint32_t l_name = le32(l);
+        std::string name(l_name, '\0');
+        if (l_name && bgzf_.read(&name[0], l_name, err) != (int64_t)l_name) return false;
+        while (!name.empty() && name.back() == '\0') name.pop_back();
+        if (bgzf_.read(l, 4, err) != 4) return false;
+        refs_.push_back({name, (int64_t)le32(l)});
+        name2tid_.emplace(name, (int)i);  // first wins, like a hash built front to back
+    }
+    first_rec_ = bgzf_.tell();
+    std::string e1, e2;
+    if (!bai_.load(path + ".bai", &e1)) {
+        std::string alt = path;
+        size_t dot = alt.rfind('.');
+        if (dot != std::string::npos) alt = alt.substr(0, dot);
+        if (!bai_.load(alt + ".bai", &e2)) {
+            if (err) *err = "could not load index for " + path + " (" + e1 + ")";
+            return false;
+        }
+    }
+    return true;
+}
+
+int BamFile::tid(const std::string &name) const {
+    auto it = name2tid_.find(name);
+    return it == name2tid_.end() ? -1 : it->second;
+}
+
+std::map<std::string, uint64_t> BamFile::sq_lengths(std::string *err) const {
+    std::map<std::string, uint64_t> out;
+    size_t p = 0;
+    while (p < text_.size()) {
+        size_t e = text_.find('\n', p);
+        if (e == std::string::npos) e = text_.size();
+        std::string line = text_.substr(p, e - p);
+        p = e + 1;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.compare(0, 3, "@SQ") != 0) continue;
+        std::string sn, ln;
+        bool have_sn = false, have_ln = false;
+        size_t q = 3;
+        while (q < line.size()) {
+            size_t t = line.find('\t', q + 1);
+            if (t == std::string::npos) t = line.size();
+            std::string f = line.substr(q + 1, t - q - 1);
+            if (f.compare(0, 3, "SN:") == 0) sn = f.substr(3), have_sn = true;
+            if (f.compare(0, 3, "LN:") == 0) ln = f.substr(3), have_ln = true;
+            q = t;
+        }
+        if (!have_sn || !have_ln) {  // record["SN"] / record["LN"] index panics in the reference
+            if (err) *err = "@SQ line without SN or LN";
+            return {};
+        }
+        uint64_t v = 0;
+        if (ln.empty()) {
+            if (err) *err = "Failed to parse length of chromosome";
+            return {};
+        }
+        for (char c : ln) {
+            if (c < '0' || c > '9') {
+                if (err) *err = "Failed to parse length of chromosome";
+                return {};
+            }
+            v = v * 10 + (uint64_t)(c - '0');
+        }
+        out[sn] = v;
+    }
+    return out;
+}
+
+static size_t aux_value_size(char type, const uint8_t *p, const uint8_t *end, bool *ok) {
+    *ok = true;
+    switch (type) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'd': return 8;
+    case 'Z': case 'H': {
+        const uint8_t *q = p;
+        while (q < end && *q) ++q;
+        if (q >= end) { *ok = false; return 0; }
+        return (size_t)(q - p) + 1;
+    }
+    case 'B': {
+        if (p + 5 > end) { *ok = false; return 0; }
+        char st = (char)p[0];
+        uint32_t n = le32(p + 1);
+        size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+        return 5 + (size_t)n * es;
+    }
+    default: *ok = false; return 0;
+    }
+}
+
+int BamFile::next(BamRec &rec, std::string *err) {
+    uint64_t vo = bgzf_.tell();
+    uint8_t l[4];
+    std::string e;
+    int64_t g = bgzf_.read(l, 4, &e);
+    if (g == 0) return 0;
+    if (g != 4) {
+        if (err) *err = e.empty() ? "truncated BAM record" : e;
+        return -1;
+    }
+    uint32_t block_size = le32(l);
+    if (block_size < 32) {
+        if (err) *err = "corrupt BAM record";
+        return -1;
+    }
+    buf_.resize(block_size + 1);
+    if (bgzf_.read(buf_.data(), block_size, &e) != (int64_t)block_size) {
+        if (err) *err = e.empty() ? "truncated BAM record" : e;
+        return -1;
+    }
+    buf_[block_size] = 0;
+    const uint8_t *b = buf_.data();
+    rec.voffset = vo;
+    rec.tid = (int32_t)le32(b);
+    rec.pos = (int32_t)le32(b + 4);
+    uint8_t l_read_name = b[8];
+    rec.mapq = b[9];
+    uint16_t n_cigar = le16(b + 12);
+    rec.flag = le16(b + 14);
+    uint32_t l_seq = le32(b + 16);
+    size_t off_cigar = 32 + (size_t)l_read_name;
+    size_t off_seq = off_cigar + (size_t)n_cigar * 4;
+    size_t off_aux = off_seq + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if (off_aux > block_size) {
+        if (err) *err = "corrupt BAM record (field lengths)";
+        return -1;
+    }
+    rec.n_cigar = n_cigar;
+    rec.cigar = reinterpret_cast<const uint32_t *>(b + off_cigar);  // block payload starts 4-aligned in buf_
+    if ((off_cigar & 3) != 0) {  // read name length not a multiple of 4: take an aligned copy
+        cg_.resize(n_cigar);
+        std::memcpy(cg_.data(), b + off_cigar, (size_t)n_cigar * 4);
+        rec.cigar = cg_.data();
+    }
+    rec.hp_type = 0;
+    rec.hp_value = 0;
+    rec.sa_type = 0;
+    rec.sa = nullptr;
+    const uint8_t *cg_payload = nullptr;
+    uint32_t cg_len = 0;
+    bool cg_ok_type = false;
+    const uint8_t *p = b + off_aux, *end = b + block_size;
+    while (p + 3 <= end) {
+        char t0 = (char)p[0], t1 = (char)p[1], type = (char)p[2];
+        const uint8_t *v = p + 3;
+        bool ok;
+        size_t sz = aux_value_size(type, v, end, &ok);
+        if (!ok || v + sz > end) break;  // htslib stops at a malformed aux field
+        if (t0 == 'H' && t1 == 'P' && rec.hp_type == 0) {  // first match, like bam_aux_get
+            rec.hp_type = type;
+            switch (type) {
+            case 'c': rec.hp_value = (int8_t)v[0]; break;
+            case 'C': rec.hp_value = v[0]; break;
+            case 's': rec.hp_value = (int16_t)le16(v); break;
+            case 'S': rec.hp_value = le16(v); break;
+            case 'i': rec.hp_value = (int32_t)le32(v); break;
+            case 'I': rec.hp_value = le32(v); break;
+            default: break;
+            }
+        } else if (t0 == 'S' && t1 == 'A' && rec.sa_type == 0) {
+            rec.sa_type = type;
+            if (type == 'Z') rec.sa = reinterpret_cast<const char *>(v);
+        } else if (t0 == 'C' && t1 == 'G' && !cg_payload) {
+            if (type == 'B' && (v[0] == 'I' || v[0] == 'i')) {
+                cg_ok_type = true;
+                cg_len = le32(v + 1);
+                cg_payload = v + 5;
+            } else {
+                cg_payload = v;  // present but wrong type: htslib leaves the record alone
+            }
+        }
+        p = v + sz;
+    }
+    // [3P] bam_tag2cigar: real CIGAR in CG:B,I when the stored one is <l_seq>S<ref_len>N
+    if (cg_payload && cg_ok_type && n_cigar > 0 && rec.tid >= 0 && rec.pos >= 0) {
+        uint32_t c0 = rec.cigar[0];
+        if ((c0 & 0xf) == 4 && (c0 >> 4) == l_seq && cg_len >= n_cigar && cg_len < (1u << 29)) {
+            cg_.resize(cg_len);
+            std::memcpy(cg_.data(), cg_payload, (size_t)cg_len * 4);
+            rec.cigar = cg_.data();
+            rec.n_cigar = cg_len;
+        }
+    }
+    return 1;
+}
+
+}  // namespace inqhost

@@ -1,0 +1,95 @@
+// bam_reader.h — the slice of BAM/BAI the `inquiSTR call` path touches, on top of bgzf.h.
+//
+// Replaces rust-htslib / htslib on the reference's path:
+//   IndexedReader::from_path + header()        src/call.rs:161-163, 239, 337
+//   fetch((tid, beg, end)) / rc_records()      src/call.rs:288, 294, 338, 345   (BAI lookup, record decode)
+//   Record::{reference_start, mapq, cigar, aux(b"HP"), aux(b"SA"), is_reverse}   src/call.rs:297-299, 380-382, 423, 483
+// SEQ / QUAL are skipped, never copied.  Long CIGARs stored in the CG:B,I tag are swapped in as
+// htslib does ([3P] sam.c bam_tag2cigar).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "bgzf.h"
+
+namespace inqhost {
+
+struct BamRef {
+    std::string name;
+    int64_t len = 0;
+};
+
+struct BaiRef {
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> ioffset;  // 16 kb linear index
+    uint64_t n_mapped = 0, n_unmapped = 0;
+    bool has_meta = false;
+    uint64_t min_offset = 0, max_offset = 0;  // over real bins
+};
+
+struct BaiIndex {
+    std::vector<BaiRef> refs;
+    uint64_t n_no_coor = 0;
+    bool load(const std::string &path, std::string *err);
+    // smallest virtual offset from which a forward scan sees every record of `tid` overlapping
+    // positions >= beg; 0 when the contig has no records at or after beg.
+    uint64_t scan_start(int tid, int64_t beg) const;
+};
+
+// One decoded record: only the fields the path reads.
+struct BamRec {
+    int32_t tid = -1;
+    int32_t pos = -1;
+    uint8_t mapq = 0;
+    uint16_t flag = 0;
+    uint32_t n_cigar = 0;
+    const uint32_t *cigar = nullptr;  // into the reader's record buffer (or CG tag payload)
+    // aux
+    char hp_type = 0;   // 0 = absent, else BAM aux type char
+    int64_t hp_value = 0;
+    char sa_type = 0;   // 0 = absent
+    const char *sa = nullptr;  // NUL-terminated when sa_type == 'Z'
+    uint64_t voffset = 0;      // virtual offset of the record (identity for de-duplication)
+};
+
+class BamFile {
+public:
+    explicit BamFile(int n_threads = 1) : bgzf_(n_threads) {}
+    // Opens <path> and its index (<path>.bai, else <path minus .bam>.bai). Both are required, as for
+    // IndexedReader::from_path.
+    bool open(const std::string &path, std::string *err);
+    const std::vector<BamRef> &refs() const { return refs_; }
+    const std::string &header_text() const { return text_; }
+    int tid(const std::string &name) const;  // -1 if absent (header().tid())
+    // @SQ SN -> LN from the header TEXT, as get_chrom_lengths_from_bam_header (src/call.rs:161-180)
+    std::map<std::string, uint64_t> sq_lengths(std::string *err) const;
+    const BaiIndex &index() const { return bai_; }
+
+    bool seek(uint64_t voffset, std::string *err) { return bgzf_.seek(voffset, err); }
+    // Next record in file order. Returns 1 = record, 0 = end of file, -1 = error.
+    int next(BamRec &rec, std::string *err);
+    uint64_t first_record_voffset() const { return first_rec_; }
+
+private:
+    BgzfReader bgzf_;
+    std::vector<BamRef> refs_;
+    std::map<std::string, int> name2tid_;
+    std::string text_;
+    BaiIndex bai_;
+    std::vector<uint8_t> buf_;
+    std::vector<uint32_t> cg_;  // aligned copy of a CG tag payload
+    uint64_t first_rec_ = 0;
+};
+
+// [3P] htslib bam_endpos / bam_cigar2rlen on a decoded record (host needs it for the sweep join and
+// for is_accidental_2d; the device recomputes it for the filters).
+int64_t bam_ref_span(const uint32_t *cigar, uint32_t n);
+inline int64_t bam_endpos(const BamRec &r) {
+    int64_t rlen = (r.flag & 0x4) ? 0 : bam_ref_span(r.cigar, r.n_cigar);
+    if (rlen == 0) rlen = 1;
+    return (int64_t)r.pos + rlen;
+}
+
+}  // namespace inqhost

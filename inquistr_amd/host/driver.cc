@@ -1,0 +1,297 @@
+// driver.cc — `call::genotype_repeats` (src/call.rs:76-159) on top of the front end and the HIP library,
+// plus the C ABI of include/inquistr_host.h.
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/inquistr_host.h"
+#include "front_end.h"
+#include "inq_text.h"
+#include "sa2d.h"
+#include "targets.h"
+
+using namespace inqhost;
+
+namespace {
+
+void set_err(char *buf, size_t cap, const std::string &m) {
+    if (buf && cap) std::snprintf(buf, cap, "%s", m.c_str());
+}
+
+bool starts_with(const std::string &s, const char *p) { return s.compare(0, std::strlen(p), p) == 0; }
+bool ends_with(const std::string &s, const char *p) {
+    size_t n = std::strlen(p);
+    return s.size() >= n && s.compare(s.size() - n, n, p) == 0;
+}
+
+bool is_file(const std::string &p) {
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+struct Prepared {
+    std::unique_ptr<BamFile> bam;
+    std::vector<RepeatInterval> targets;
+    std::string sample;
+};
+
+// src/call.rs:87-102 + get_targets :182-202.  Returns an exit status.
+int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg) {
+    if (!a || !a->bam) {
+        msg = "no BAM given";
+        return INQ_EXIT_ERROR;
+    }
+    const std::string bamp = a->bam;
+    const bool remote = starts_with(bamp, "s3") || starts_with(bamp, "https://");
+    if (!is_file(bamp) && !remote) {  // :87-90
+        msg = "ERROR: path to bam file " + bamp + " is not valid!";
+        return INQ_EXIT_ERROR;
+    }
+    if (remote) {  // :227-240 needs libcurl + htslib network code: not in this build
+        msg = "remote inputs (s3://, https://) are not supported by this build";
+        return INQ_EXIT_ERROR;
+    }
+    if (ends_with(bamp, ".cram")) {  // :245-259 needs htslib's CRAM codecs: not in this build
+        msg = "CRAM input is not supported by this build (BAM + .bai only)";
+        return INQ_EXIT_ERROR;
+    }
+    P.sample = a->sample_name ? std::string(a->sample_name) : sample_name_from_path(bamp);  // :91-100
+    // get_chrom_lengths_from_bam_header opens the BAM before the target arguments are looked at (:187)
+    P.bam.reset(new BamFile((int)std::max<uint64_t>(1, std::min<uint64_t>(a->threads, 64))));
+    std::string e;
+    if (!P.bam->open(bamp, &e)) {
+        msg = "Error opening local BAM: " + e;  // :242-243
+        return INQ_EXIT_PANIC;
+    }
+    auto lengths = P.bam->sq_lengths(&e);
+    if (!e.empty()) {
+        msg = e;
+        return INQ_EXIT_PANIC;
+    }
+    TargetsResult tr;
+    if (a->region && !a->region_file)
+        tr = targets_from_string(a->region, lengths);  // :190
+    else if (!a->region && a->region_file)
+        tr = targets_from_bed(a->region_file, lengths);  // :192-195
+    else {
+        msg = "ERROR: Specify a region string (-r) or a region_file (-R)!";  // :197-200
+        return INQ_EXIT_ERROR;
+    }
+    if (tr.panicked) {
+        msg = tr.message;
+        return INQ_EXIT_PANIC;
+    }
+    for (const auto &t : tr.data) {
+        if (t.start < 10) {  // src/call.rs:285,335: `repeat.start - 10` underflows u32 -> fetch fails -> expect() panics
+            msg = "Failed to fetch region (" + t.chrom + ":" + std::to_string(t.start) + "-" + std::to_string(t.end) +
+                  ": start - 10 underflows)";
+            return INQ_EXIT_PANIC;
+        }
+    }
+    P.targets.swap(tr.data);
+    return INQ_EXIT_OK;
+}
+
+bool write_all(int fd, const std::string &s) {
+    size_t off = 0;
+    while (off < s.size()) {
+        ssize_t w = ::write(fd, s.data() + off, s.size() - off);
+        if (w <= 0) return false;
+        off += (size_t)w;
+    }
+    return true;
+}
+
+}  // namespace
+
+struct inq_frontend {
+    Prepared P;
+    std::unique_ptr<FrontEnd> fe;
+    HostBatch batch;
+    uint32_t minlen = 5, support = 3;
+    bool unphased = false;
+};
+
+extern "C" {
+
+int inq_frontend_open(const inq_call_args_t *args, inq_frontend_t **out, char *errbuf, size_t errcap) {
+    if (!out) return INQ_EXIT_ERROR;
+    *out = nullptr;
+    std::unique_ptr<inq_frontend> F(new inq_frontend());
+    std::string msg;
+    int rc = prepare(args, F->P, msg);
+    if (rc != INQ_EXIT_OK) {
+        set_err(errbuf, errcap, msg);
+        return rc;
+    }
+    F->minlen = args->minlen;
+    F->support = (uint32_t)std::min<uint64_t>(args->support, 0xffffffffull);
+    F->unphased = args->unphased != 0;
+    F->fe.reset(new FrontEnd(*F->P.bam, F->P.targets, F->unphased));
+    *out = F.release();
+    return INQ_EXIT_OK;
+}
+
+uint64_t inq_frontend_n_targets(const inq_frontend_t *fe) { return fe ? fe->P.targets.size() : 0; }
+
+int inq_frontend_target(const inq_frontend_t *fe, uint64_t i, const char **chrom, uint32_t *start, uint32_t *end) {
+    if (!fe || i >= fe->P.targets.size()) return -1;
+    if (chrom) *chrom = fe->P.targets[i].chrom.c_str();
+    if (start) *start = fe->P.targets[i].start;
+    if (end) *end = fe->P.targets[i].end;
+    return 0;
+}
+
+const char *inq_frontend_sample(const inq_frontend_t *fe) { return fe ? fe->P.sample.c_str() : ""; }
+
+void inq_frontend_set_batch_words(inq_frontend_t *fe, uint64_t w) {
+    if (fe) fe->fe->set_max_batch_words(w);
+}
+
+int inq_frontend_next(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **locus_index, char *errbuf,
+                      size_t errcap) {
+    if (!fe || !batch) return -INQ_EXIT_ERROR;
+    std::string err;
+    bool panic = false;
+    int rc = fe->fe->next(fe->batch, &err, &panic);
+    if (rc < 0) {
+        set_err(errbuf, errcap, err);
+        return panic ? -INQ_EXIT_PANIC : -INQ_EXIT_PANIC;  // read errors are expect()/unwrap() panics too (:294,346)
+    }
+    if (rc == 0) return 0;
+    fe->batch.view(batch, fe->minlen, fe->support, fe->unphased);
+    if (locus_index) *locus_index = fe->batch.locus_index.data();
+    return 1;
+}
+
+void inq_frontend_close(inq_frontend_t *fe) { delete fe; }
+
+int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
+    inq_frontend_t *F = nullptr;
+    int rc = inq_frontend_open(args, &F, errbuf, errcap);
+    if (rc != INQ_EXIT_OK) return rc;
+    std::unique_ptr<inq_frontend> guard(F);
+    const size_t n = F->P.targets.size();
+    std::vector<double> p1(n, NAN), p2(n, NAN);
+
+    inq_ctx_t *ctx = nullptr;
+    int hrc = inq_ctx_create(args->device, &ctx);
+    if (hrc != INQ_OK) {
+        set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
+        return INQ_EXIT_ERROR;
+    }
+    struct CtxGuard {
+        inq_ctx_t *c;
+        ~CtxGuard() { inq_ctx_destroy(c); }
+    } cg{ctx};
+
+    std::vector<double> b1, b2;
+    for (;;) {
+        inq_batch_t batch;
+        const uint32_t *index = nullptr;
+        int nb = inq_frontend_next(F, &batch, &index, errbuf, errcap);
+        if (nb < 0) return -nb;
+        if (nb == 0) break;
+        b1.assign(batch.n_loci, NAN);
+        b2.assign(batch.n_loci, NAN);
+        inq_result_t res;
+        std::memset(&res, 0, sizeof res);
+        res.phase1 = b1.data();
+        res.phase2 = b2.data();
+        hrc = inq_call_batch(ctx, &batch, &res);
+        if (hrc != INQ_OK) {
+            std::string m = std::string("device call failed: ") + inq_strerror(hrc);
+            if (hrc == INQ_ERR_HIP) m += std::string(" [") + inq_last_error(ctx) + "]";
+            set_err(errbuf, errcap, m);
+            // domain errors are the reference's panics (HP > 2, bad CIGAR op, ...)
+            return (hrc == INQ_ERR_HIP || hrc == INQ_ERR_NOMEM || hrc == INQ_ERR_NO_DEVICE) ? INQ_EXIT_ERROR : INQ_EXIT_PANIC;
+        }
+        for (uint64_t j = 0; j < batch.n_loci; ++j) {
+            p1[index[j]] = b1[j];
+            p2[index[j]] = b2[j];
+        }
+    }
+
+    // output, src/call.rs:137-157
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    if (args->threads > 1) {
+        // genotypes_vec.sort_unstable() with Ord = (human_compare(chrom), start), :33-38,141.  Equal keys
+        // are in completion order in the reference (nondeterministic); BED order is kept here.
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            int c = human_compare(F->P.targets[x].chrom, F->P.targets[y].chrom);
+            if (c != 0) return c < 0;
+            return F->P.targets[x].start < F->P.targets[y].start;
+        });
+    }
+    std::string text = format_header(F->P.sample) + "\n";
+    text.reserve(64 * (n + 1));
+    for (uint32_t i : order) {
+        const RepeatInterval &t = F->P.targets[i];
+        text += format_row(t.chrom, t.start, t.end, p1[i], p2[i]);
+        text += '\n';
+        if (text.size() > (1u << 20)) {
+            if (!write_all(out_fd, text)) {
+                set_err(errbuf, errcap, "Failed writing the result.");
+                return INQ_EXIT_PANIC;
+            }
+            text.clear();
+        }
+    }
+    if (!write_all(out_fd, text)) {
+        set_err(errbuf, errcap, "Failed writing the result.");
+        return INQ_EXIT_PANIC;
+    }
+    return INQ_EXIT_OK;
+}
+
+size_t inq_host_format_f64(double v, char *buf, size_t cap) { return (size_t)std::snprintf(buf, cap, "%s", format_f64(v).c_str()); }
+size_t inq_host_format_row(const char *chrom, uint32_t start, uint32_t end, double p1, double p2, char *buf, size_t cap) {
+    return (size_t)std::snprintf(buf, cap, "%s", format_row(chrom, start, end, p1, p2).c_str());
+}
+size_t inq_host_format_header(const char *sample, char *buf, size_t cap) {
+    return (size_t)std::snprintf(buf, cap, "%s", format_header(sample).c_str());
+}
+size_t inq_host_sample_name(const char *p, char *buf, size_t cap) {
+    return (size_t)std::snprintf(buf, cap, "%s", sample_name_from_path(p).c_str());
+}
+int inq_host_human_compare(const char *a, const char *b) { return human_compare(a, b); }
+
+int inq_host_parse_region(const char *reg, const char *chrom_name, uint64_t chrom_len, char *chrom_out, size_t cap,
+                          uint32_t *start, uint32_t *end) {
+    std::map<std::string, uint64_t> lens;
+    if (chrom_name) lens[chrom_name] = chrom_len;
+    TargetsResult r = targets_from_string(reg, lens);
+    if (r.panicked) {
+        if (chrom_out && cap) std::snprintf(chrom_out, cap, "%s", r.message.c_str());
+        return INQ_EXIT_PANIC;
+    }
+    if (chrom_out && cap) std::snprintf(chrom_out, cap, "%s", r.data[0].chrom.c_str());
+    if (start) *start = r.data[0].start;
+    if (end) *end = r.data[0].end;
+    return INQ_EXIT_OK;
+}
+
+int inq_host_bai_stats(const char *bai_path, uint32_t *n_ref, int32_t tid, uint64_t *n_mapped, uint64_t *n_unmapped,
+                       uint64_t *n_bins, uint64_t *n_intv) {
+    BaiIndex idx;
+    std::string e;
+    if (!idx.load(bai_path, &e)) return -1;
+    if (n_ref) *n_ref = (uint32_t)idx.refs.size();
+    if (tid >= 0 && (size_t)tid < idx.refs.size()) {
+        if (n_mapped) *n_mapped = idx.refs[tid].n_mapped;
+        if (n_unmapped) *n_unmapped = idx.refs[tid].n_unmapped;
+        if (n_bins) *n_bins = idx.refs[tid].bins.size();
+        if (n_intv) *n_intv = idx.refs[tid].ioffset.size();
+    }
+    return 0;
+}
+
+}  // extern "C"

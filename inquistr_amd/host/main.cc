@@ -1,0 +1,104 @@
+// main.cc — `inquistr call`: the CLI surface of the reference's `call` subcommand (src/main.rs:27-64),
+// same flags and defaults.  Other subcommands of the reference are out of scope.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/inquistr_host.h"
+
+static void usage(FILE *f) {
+    std::fputs(
+        "Call lengths\n\nUsage: inquistr call [OPTIONS] <BAM>\n\nArguments:\n  <BAM>  bam file to call STRs in\n\nOptions:\n"
+        "  -r, --region <REGION>            region string to genotype expansion in\n"
+        "  -R, --region-file <REGION_FILE>  Bed file with region(s) to genotype expansion(s) in\n"
+        "  -m, --minlen <MINLEN>            minimal length of insertion/deletion operation [default: 5]\n"
+        "  -s, --support <SUPPORT>          minimal number of supporting reads [default: 3]\n"
+        "  -t, --threads <THREADS>          Number of parallel threads to use [default: 1]\n"
+        "  -u, --unphased                   If reads have to be considered unphased\n"
+        "      --sample-name <SAMPLE_NAME>  sample name to use in output\n"
+        "      --reference <REFERENCE>      reference fasta for cram decoding\n"
+        "      --device <N>                 HIP device ordinal [default: 0]\n"
+        "  -h, --help                       Print help\n",
+        f);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2 || std::strcmp(argv[1], "call") != 0) {
+        if (argc >= 2 && (!std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help"))) {
+            std::puts("Tool to genotype STRs from long reads (MI355X build: `call` only)\n\nUsage: inquistr call [OPTIONS] <BAM>");
+            return 0;
+        }
+        std::fputs("error: this build provides the `call` subcommand only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
+        return 2;
+    }
+    if (argc == 2) {  // arg_required_else_help
+        usage(stderr);
+        return 2;
+    }
+    inq_call_args_t a;
+    std::memset(&a, 0, sizeof a);
+    a.minlen = 5;
+    a.support = 3;
+    a.threads = 1;
+    std::string bam;
+    auto need = [&](int &i) -> const char * {
+        if (i + 1 >= argc) {
+            std::fprintf(stderr, "error: a value is required for '%s' but none was supplied\n", argv[i]);
+            std::exit(2);
+        }
+        return argv[++i];
+    };
+    auto num = [&](const char *s, const char *flag) -> unsigned long long {
+        char *e = nullptr;
+        if (!*s || *s == '-') {
+            std::fprintf(stderr, "error: invalid value '%s' for '%s'\n", s, flag);
+            std::exit(2);
+        }
+        unsigned long long v = std::strtoull(s, &e, 10);
+        if (*e) {
+            std::fprintf(stderr, "error: invalid value '%s' for '%s'\n", s, flag);
+            std::exit(2);
+        }
+        return v;
+    };
+    for (int i = 2; i < argc; ++i) {
+        std::string s = argv[i];
+        auto eq = s.find('=');
+        std::string key = (s.size() > 2 && s[0] == '-' && s[1] == '-' && eq != std::string::npos) ? s.substr(0, eq) : s;
+        const char *inl = (key.size() != s.size()) ? argv[i] + eq + 1 : nullptr;
+        auto val = [&]() { return inl ? inl : need(i); };
+        if (key == "-r" || key == "--region") a.region = val();
+        else if (key == "-R" || key == "--region-file" || key == "--region_file") a.region_file = val();
+        else if (key == "-m" || key == "--minlen") a.minlen = (uint32_t)num(val(), "--minlen");
+        else if (key == "-s" || key == "--support") a.support = num(val(), "--support");
+        else if (key == "-t" || key == "--threads") a.threads = num(val(), "--threads");
+        else if (key == "-u" || key == "--unphased") a.unphased = 1;
+        else if (key == "--sample-name" || key == "--sample_name") a.sample_name = val();
+        else if (key == "--reference") a.reference = val();
+        else if (key == "--device") a.device = (int32_t)num(val(), "--device");
+        else if (key == "-h" || key == "--help") { usage(stdout); return 0; }
+        else if (!s.empty() && s[0] == '-' && s.size() > 1) {
+            std::fprintf(stderr, "error: unexpected argument '%s' found\n", s.c_str());
+            return 2;
+        } else if (bam.empty()) bam = s;
+        else {
+            std::fprintf(stderr, "error: unexpected argument '%s' found\n", s.c_str());
+            return 2;
+        }
+    }
+    if (bam.empty()) {
+        std::fputs("error: the following required arguments were not provided:\n  <BAM>\n", stderr);
+        return 2;
+    }
+    a.bam = bam.c_str();
+    char err[1024] = {0};
+    int rc = inq_genotype_repeats(&a, 1 /* stdout */, err, sizeof err);
+    if (rc != 0) {
+        if (rc == INQ_EXIT_PANIC)
+            std::fprintf(stderr, "thread 'main' panicked:\n%s\n", err);
+        else
+            std::fprintf(stderr, "%s\n", err);
+    }
+    return rc;
+}

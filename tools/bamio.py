@@ -1,0 +1,173 @@
+"""Minimal BAM + BAI writer (stdlib zlib + struct): test / benchmark plumbing, never the product.
+
+Writes what the C++ front end reads: BGZF blocks (records may span blocks), header with @SQ text and
+binary references, records with CIGAR / HP / SA / CG tags, SEQ '*' unless asked otherwise, and a
+.bai with bins, 16 kb linear index and the htslib metadata pseudo-bin.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+OPS = "MIDNSHP=X"
+BLOCK = 0xFF00
+
+EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def reg2bin(beg: int, end: int) -> int:
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def ref_span(cigar: Sequence[Tuple[str, int]]) -> int:
+    return sum(n for o, n in cigar if o in "MDN=X")
+
+
+def encode_aux(tags: Sequence[Tuple[str, str, object]]) -> bytes:
+    out = b""
+    for tag, typ, val in tags:
+        out += tag.encode() + typ.encode()
+        if typ == "A":
+            out += str(val).encode()[:1]
+        elif typ in "cCsSiI":
+            out += struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I"}[typ], val)
+        elif typ == "f":
+            out += struct.pack("<f", val)
+        elif typ in "ZH":
+            out += str(val).encode() + b"\0"
+        elif typ == "B":
+            sub, arr = val
+            out += sub.encode() + struct.pack("<I", len(arr))
+            out += struct.pack("<%d%s" % (len(arr), {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]), *arr)
+        else:
+            raise ValueError(typ)
+    return out
+
+
+def encode_record(name: str, flag: int, tid: int, pos: int, mapq: int, cigar: Sequence[Tuple[str, int]],
+                  tags: Sequence[Tuple[str, str, object]] = (), l_seq: int = 0) -> bytes:
+    """One BAM record (without the leading block_size).  CIGARs beyond 65535 ops go to CG:B,I."""
+    words = [(n << 4) | OPS.index(o) for o, n in cigar]
+    tags = list(tags)
+    end = pos + (ref_span(cigar) or 1 if not (flag & 4) else 1)
+    if len(words) > 65535:
+        tags.append(("CG", "B", ("I", words)))
+        words = [(l_seq << 4) | 4, (ref_span(cigar) << 4) | 3]
+    rn = name.encode() + b"\0"
+    core = struct.pack("<iiBBHHHIiii", tid, pos, len(rn), mapq, reg2bin(max(pos, 0), max(end, 1)), len(words), flag, l_seq, -1, -1, 0)
+    seq = b"\0" * ((l_seq + 1) // 2) + b"\xff" * l_seq
+    return core + rn + struct.pack("<%dI" % len(words), *words) + seq + encode_aux(tags)
+
+
+def bgzf_block(data: bytes, level: int = 1) -> bytes:
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = comp.compress(data) + comp.flush()
+    crc = zlib.crc32(data) & 0xFFFFFFFF
+    bsize = len(body) + 25
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + body + struct.pack("<II", crc, len(data)))
+
+
+class BamWriter:
+    def __init__(self, path: str, refs: Sequence[Tuple[str, int]], header_text: Optional[str] = None, level: int = 1):
+        self.path, self.refs, self.level = path, list(refs), level
+        if header_text is None:
+            header_text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
+        h = b"BAM\1" + struct.pack("<I", len(header_text)) + header_text.encode() + struct.pack("<I", len(refs))
+        for n, l in refs:
+            nb = n.encode() + b"\0"
+            h += struct.pack("<I", len(nb)) + nb + struct.pack("<I", l)
+        self.buf = bytearray(h)
+        self.recs: List[Tuple[int, int, int, int, int, int]] = []  # (ustart, uend, tid, beg, end, flag)
+
+    def add(self, name, flag, tid, pos, mapq, cigar, tags=(), l_seq=0):
+        body = encode_record(name, flag, tid, pos, mapq, cigar, tags, l_seq)
+        u0 = len(self.buf)
+        self.buf += struct.pack("<I", len(body)) + body
+        end = pos + (ref_span(cigar) or 1 if not (flag & 4) else 1)
+        self.recs.append((u0, len(self.buf), tid, pos, end, flag))
+
+    def add_raw(self, block: bytes, tid: int, beg: int, end: int, flag: int = 0):
+        """block = block_size + record bytes, already encoded (fast path of the synthetic generator)."""
+        u0 = len(self.buf)
+        self.buf += block
+        self.recs.append((u0, len(self.buf), tid, beg, end, flag))
+
+    def close(self, write_index: bool = True):
+        data = bytes(self.buf)
+        coff, out = [], bytearray()
+        for i in range(0, max(len(data), 1), BLOCK):
+            coff.append(len(out))
+            out += bgzf_block(data[i : i + BLOCK], self.level)
+        end_coff = len(out)
+        out += EOF_BLOCK
+        with open(self.path, "wb") as f:
+            f.write(out)
+
+        def vo(u):
+            blk, within = divmod(u, BLOCK)
+            if blk >= len(coff):
+                return end_coff << 16
+            return (coff[blk] << 16) | within
+
+        if write_index:
+            self._write_bai(vo)
+
+    def _write_bai(self, vo):
+        nref = len(self.refs)
+        bins: List[Dict[int, List[List[int]]]] = [dict() for _ in range(nref)]
+        lin: List[Dict[int, int]] = [dict() for _ in range(nref)]
+        meta = [[None, None, 0, 0] for _ in range(nref)]
+        n_no_coor = 0
+        for u0, u1, tid, beg, end, flag in self.recs:
+            if tid < 0:
+                n_no_coor += 1
+                continue
+            v0, v1 = vo(u0), vo(u1)
+            b = reg2bin(max(beg, 0), max(end, 1))
+            ch = bins[tid].setdefault(b, [])
+            if ch and ch[-1][1] == v0:
+                ch[-1][1] = v1
+            else:
+                ch.append([v0, v1])
+            for w in range(max(beg, 0) >> 14, ((max(end, 1) - 1) >> 14) + 1):
+                if w not in lin[tid]:
+                    lin[tid][w] = v0
+            m = meta[tid]
+            m[0] = v0 if m[0] is None else min(m[0], v0)
+            m[1] = v1 if m[1] is None else max(m[1], v1)
+            if flag & 4:
+                m[3] += 1
+            else:
+                m[2] += 1
+        out = bytearray(b"BAI\1" + struct.pack("<I", nref))
+        for t in range(nref):
+            nb = len(bins[t]) + (1 if meta[t][0] is not None else 0)
+            out += struct.pack("<I", nb)
+            for b in sorted(bins[t]):
+                out += struct.pack("<II", b, len(bins[t][b]))
+                for v0, v1 in bins[t][b]:
+                    out += struct.pack("<QQ", v0, v1)
+            if meta[t][0] is not None:
+                out += struct.pack("<II", 37450, 2) + struct.pack("<QQQQ", meta[t][0], meta[t][1], meta[t][2], meta[t][3])
+            nint = (max(lin[t]) + 1) if lin[t] else 0
+            out += struct.pack("<I", nint)
+            last = 0
+            for w in range(nint):
+                if w in lin[t]:
+                    last = lin[t][w]
+                out += struct.pack("<Q", last)  # htslib fills empty windows with the previous offset
+        out += struct.pack("<Q", n_no_coor)
+        with open(self.path + ".bai", "wb") as f:
+            f.write(out)
