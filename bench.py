@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--cpu-sample-loci", type=int, default=10_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_latest.json"))
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --same-device rehearses the N>1 control flow on a one-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -90,11 +93,16 @@ def main():
             raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     wl = synth.WORKLOADS[args.workload]
     if args.workload == "shard500k":
@@ -108,7 +116,9 @@ def main():
     shard = synth.DeviceBatch(wl, dev, lo, hi)
     # results: two rotating [2, n] buffers (row 0 = H1, row 1 = H2) so the gather of step k overlaps step k+1
     outs = [torch.empty(2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]
-    gathered = [torch.empty(world, 2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)] if (world > 1 and rank == 0) else None
+    gdev = dev if args.backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty(world, 2, per_gpu, dtype=torch.float64, device=gdev) for _ in range(2)] if (world > 1 and rank == 0) else None
+    stage = [torch.empty(2, per_gpu, dtype=torch.float64).pin_memory() for _ in range(2)] if (world > 1 and args.backend == "gloo") else None
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     main_stream = torch.cuda.current_stream()
 
@@ -134,7 +144,12 @@ def main():
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
                 glist = list(gathered[k].unbind(0)) if rank == 0 else None
-                pending.append(dist.gather(outs[k], glist, dst=0, async_op=True))
+                if args.backend == "nccl":
+                    pending.append(dist.gather(outs[k], glist, dst=0, async_op=True))
+                else:  # rehearsal: stage through pinned host memory, gather on gloo
+                    stage[k].copy_(outs[k], non_blocking=True)
+                    comm_stream.synchronize()
+                    pending.append(dist.gather(stage[k], glist, dst=0, async_op=True))
 
     def drain():
         while pending:
@@ -168,11 +183,18 @@ def main():
     if rc != 0:
         raise SystemExit(f"device status {rc}: {hipcall.strerror(rc)}")
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
+    if rank == 0 and world > 1:
+        # the last gathered buffer must hold rank 0's own rows in slot 0
+        last = (args.steps - 1) & 1
+        own = outs[last].to(gathered[last].device)
+        g0 = gathered[last][0]
+        if not bool(((own == g0) | (own.isnan() & g0.isnan())).all()):
+            raise SystemExit("gathered rows differ from the local result")
     if rank == 0:
         total_loci = per_gpu * world
         alg_bytes = shard.algorithmic_bytes()
@@ -210,7 +232,7 @@ def main():
                 "cigar_ops_per_gpu": shard.n_ops_total,
                 "minlen": wl.minlen,
                 "support": wl.support,
-                "sharding": f"loci x {world} ranks, gather of 16 B/locus to rank 0 overlapped" if world > 1 else "single GPU",
+                "sharding": f"loci x {world} ranks ({args.backend}), gather of 16 B/locus to rank 0 overlapped" if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",

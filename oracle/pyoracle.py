@@ -211,6 +211,7 @@ def genotype_repeat_unphased(recs, tid, start, end, minlen, support):
 
 def format_f64(v: float) -> str:
     """[3P] Rust `{}` for f64, restricted to what the path produces."""
+    v = float(v)
     if math.isnan(v):
         return "NaN"
     if v == int(v):
