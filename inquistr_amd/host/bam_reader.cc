@@ -1,5 +1,6 @@
 #include "bam_reader.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -94,6 +95,37 @@ uint64_t BaiIndex::scan_start(int tid, int64_t beg) const {
     for (size_t i = w; i < R.ioffset.size(); ++i)
         if (R.ioffset[i]) return R.ioffset[i];
     return 0;
+}
+
+std::vector<std::pair<uint64_t, uint64_t>> BaiIndex::query(int tid, int64_t beg, int64_t end) const {
+    std::vector<std::pair<uint64_t, uint64_t>> out;
+    if (tid < 0 || (size_t)tid >= refs.size() || beg >= end) return out;
+    const BaiRef &R = refs[tid];
+    if (beg < 0) beg = 0;
+    uint64_t min_off = 0;
+    if (!R.ioffset.empty()) {
+        size_t w = (size_t)(beg >> 14);
+        min_off = w < R.ioffset.size() ? R.ioffset[w] : R.ioffset.back();
+    }
+    // reg2bins over the 6 levels of the UCSC binning scheme (min_shift 14, depth 5)
+    int64_t e = end - 1;
+    const int shifts[6] = {29, 26, 23, 20, 17, 14};
+    const uint32_t firsts[6] = {0, 1, 9, 73, 585, 4681};
+    for (int l = 0; l < 6; ++l) {
+        uint32_t b0 = firsts[l] + (uint32_t)(beg >> shifts[l]), b1 = firsts[l] + (uint32_t)(e >> shifts[l]);
+        for (auto it = R.bins.lower_bound(b0); it != R.bins.end() && it->first <= b1; ++it)
+            for (auto &c : it->second)
+                if (c.second > min_off) out.emplace_back(c.first, c.second);
+    }
+    std::sort(out.begin(), out.end());
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    for (auto &c : out) {
+        if (!merged.empty() && (c.first >> 16) <= (merged.back().second >> 16)) {  // same or adjacent block
+            if (c.second > merged.back().second) merged.back().second = c.second;
+        } else
+            merged.push_back(c);
+    }
+    return merged;
 }
 
 // ---------------- BAM ----------------

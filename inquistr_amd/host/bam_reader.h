@@ -36,6 +36,9 @@ struct BaiIndex {
     // smallest virtual offset from which a forward scan sees every record of `tid` overlapping
     // positions >= beg; 0 when the contig has no records at or after beg.
     uint64_t scan_start(int tid, int64_t beg) const;
+    // [3P] htslib hts_itr_query for a BAI: the chunks a region query [beg, end) has to read, from the
+    // bins overlapping the region, cut below by the linear index, sorted and merged.
+    std::vector<std::pair<uint64_t, uint64_t>> query(int tid, int64_t beg, int64_t end) const;
 };
 
 // One decoded record: only the fields the path reads.

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Writes a synthetic workload (inquistr_amd/synth.py) as a coordinate-sorted BAM + .bai + BED:
+the end-to-end (L2) form of BASELINE.json's configs.  Measurement plumbing, never the product.
+10 000 loci per contig (chr1, chr2, ...), reads carry HP:C, SEQ is '*' (l_seq = 0).
+usage: tools/make_synth_bam.py <workload> <n_loci> <out_prefix>"""
+from __future__ import annotations
+
+import os
+import struct
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from inquistr_amd import synth  # noqa: E402
+from tools import bamio  # noqa: E402
+
+LOCI_PER_CONTIG = 10_000
+CONTIG_LEN = 50_000 + 20_000 * LOCI_PER_CONTIG + 400_000
+
+FIXED = np.dtype([("block_size", "<i4"), ("refID", "<i4"), ("pos", "<i4"), ("l_read_name", "u1"), ("mapq", "u1"),
+                  ("bin", "<u2"), ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_refID", "<i4"),
+                  ("next_pos", "<i4"), ("tlen", "<i4"), ("name", "S12")])
+assert FIXED.itemsize == 48
+
+
+def reg2bin_vec(beg, end):
+    end = end - 1
+    out = np.zeros_like(beg)
+    done = np.zeros(beg.shape, dtype=bool)
+    for shift, first in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        m = ~done & ((beg >> shift) == (end >> shift))
+        out[m] = first + (beg[m] >> shift)
+        done |= m
+    return out
+
+
+def records_for(batch, tid: int, first_read_id: int):
+    """(bytes of all records of the batch sorted by pos, per-record (size, beg, end))"""
+    r = batch.reads
+    n = len(r)
+    ncig = r["n_cigar"].astype(np.int64)
+    off = r["cigar_off4"].astype(np.int64) * 4
+    w = batch.cigar.astype(np.int64)
+    consumed = np.where(np.isin(w & 15, (0, 2, 3, 7, 8)), w >> 4, 0)
+    span = np.add.reduceat(consumed, off) if n else np.zeros(0, dtype=np.int64)
+    pos = r["pos"].astype(np.int64)
+    end = pos + np.maximum(span, 1)
+    order = np.argsort(pos, kind="stable")
+    sizes = 48 + 4 * ncig + 4
+    so = sizes[order]
+    starts = np.concatenate([[0], np.cumsum(so)])[:-1]
+    out = np.zeros(int(so.sum()), dtype=np.uint8)
+    fx = np.zeros(n, dtype=FIXED)
+    fx["block_size"] = so - 4
+    fx["refID"] = tid
+    fx["pos"] = pos[order]
+    fx["l_read_name"] = 12
+    fx["mapq"] = r["mapq"][order]
+    fx["bin"] = reg2bin_vec(pos[order], end[order])
+    fx["n_cigar"] = ncig[order]
+    fx["flag"] = 0
+    fx["l_seq"] = 0
+    fx["next_refID"] = -1
+    fx["next_pos"] = -1
+    ids = first_read_id + order
+    digits = ((ids[:, None] // 10 ** np.arange(9, -1, -1)) % 10 + 48).astype(np.uint8)
+    names = np.concatenate([np.full((n, 1), ord("r"), np.uint8), digits, np.zeros((n, 1), np.uint8)], axis=1)
+    fx["name"] = names.view("S12").reshape(n)
+    out[(starts[:, None] + np.arange(48)).reshape(-1)] = fx.view(np.uint8).reshape(-1)
+    # CIGAR words
+    nc_o = ncig[order]
+    tot = int(nc_o.sum())
+    within = np.arange(tot) - np.repeat(np.concatenate([[0], np.cumsum(nc_o)])[:-1], nc_o)
+    src = np.repeat(off[order], nc_o) + within
+    dst = np.repeat(starts + 48, nc_o) + 4 * within
+    words = batch.cigar[src].astype("<u4").view(np.uint8).reshape(-1, 4)
+    out[(dst[:, None] + np.arange(4)).reshape(-1)] = words.reshape(-1)
+    # HP:C:<phase>
+    aux = np.zeros((n, 4), dtype=np.uint8)
+    aux[:, 0], aux[:, 1], aux[:, 2] = ord("H"), ord("P"), ord("C")
+    aux[:, 3] = r["phase"][order]
+    out[((starts + 48 + 4 * nc_o)[:, None] + np.arange(4)).reshape(-1)] = aux.reshape(-1)
+    return out.tobytes(), so, pos[order], end[order]
+
+
+def write(workload: str, n_loci: int, prefix: str, level: int = 1):
+    wl = synth.WORKLOADS[workload]
+    n_contigs = (n_loci + LOCI_PER_CONTIG - 1) // LOCI_PER_CONTIG
+    refs = [(f"chr{c + 1}", CONTIG_LEN) for c in range(n_contigs)]
+    w = bamio.BamWriter(prefix + ".bam", refs, level=level)
+    bed = open(prefix + ".bed", "w")
+    step = 256 if wl.heavy_pct else 2000
+    rid = 0
+    for c in range(n_contigs):
+        c_lo, c_hi = c * LOCI_PER_CONTIG, min(n_loci, (c + 1) * LOCI_PER_CONTIG)
+        for g0 in range(c_lo, c_hi, step):
+            b = synth.generate_numpy(wl, g0, min(c_hi, g0 + step))
+            blob, sizes, beg, end = records_for(b, c, rid)
+            u0 = len(w.buf)
+            w.buf += blob
+            offs = u0 + np.concatenate([[0], np.cumsum(sizes)])
+            w.recs.extend(zip(offs[:-1].tolist(), offs[1:].tolist(), [c] * len(sizes), beg.tolist(), end.tolist(), [0] * len(sizes)))
+            rid += len(sizes)
+            for s, e in zip(b.locus_start.tolist(), b.locus_end.tolist()):
+                bed.write(f"chr{c + 1}\t{s}\t{e}\n")
+    bed.close()
+    w.close()
+    return rid
+
+
+if __name__ == "__main__":
+    n = write(sys.argv[1], int(sys.argv[2]), sys.argv[3])
+    print(f"wrote {sys.argv[3]}.bam/.bai/.bed: {n} reads, {os.path.getsize(sys.argv[3] + '.bam') / 1e6:.1f} MB")
