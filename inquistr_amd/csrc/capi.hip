@@ -33,6 +33,7 @@ struct inq_ctx {
     hipStream_t stream = nullptr;
     std::string backend, last_err;
     DevStatus *d_status = nullptr;
+    DevStatus *h_status = nullptr;  // pinned mirror for the host-buffer entry
     DevBuf worklist, sval, smeta;
     // staging for the host-buffer entry
     DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
@@ -61,7 +62,9 @@ static int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
         b.p = nullptr;
         b.cap = 0;
     }
-    size_t want = bytes < 256 ? 256 : bytes;
+    // grow with headroom: batches of a sweep vary in size, reallocating for each new maximum would
+    // put a device-wide free/malloc in front of most calls
+    size_t want = bytes < 256 ? 256 : bytes + bytes / 2 + (1u << 16);
     HIP_TRY(c, hipMalloc(&b.p, want));
     b.cap = want;
     return INQ_OK;
@@ -118,6 +121,7 @@ int inq_ctx_create(int device_id, inq_ctx_t **out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(INQ_ERR_HIP);
     if (hipMalloc((void **)&c->d_status, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_NOMEM);
     if (hipMemset(c->d_status, 0, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_HIP);
+    if (hipHostMalloc((void **)&c->h_status, sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) return fail(INQ_ERR_NOMEM);
     *out = c;
     return INQ_OK;
 }
@@ -135,6 +139,7 @@ void inq_ctx_destroy(inq_ctx_t *c) {
         (void)hipEventDestroy(e.e2);
     }
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -286,11 +291,14 @@ int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
         HIP_TRY(c, hipMemcpyAsync(r->pair_call, dr.pair_call, (size_t)b->n_pairs * 8, hipMemcpyDeviceToHost, s));
     if (r->pair_bits && b->n_pairs)
         HIP_TRY(c, hipMemcpyAsync(r->pair_bits, dr.pair_bits, (size_t)b->n_pairs, hipMemcpyDeviceToHost, s));
+    // status travels with the results: one synchronisation per call; the device copy is cleared on the
+    // same stream, i.e. before the next host-entry call's kernels
+    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemsetAsync(&c->d_status->err, 0, sizeof(unsigned int), s));
+    HIP_TRY(c, hipMemsetAsync(&c->d_status->ties, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    uint64_t ties = 0;
-    rc = inq_ctx_status(c, &ties);
-    r->n_tie_loci = ties;
-    return rc;
+    r->n_tie_loci = c->h_status->ties;
+    return status_to_code(c->h_status->err);
 }
 
 int inq_ctx_timing_enable(inq_ctx_t *c, int on) {

@@ -4,11 +4,18 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/inquistr_host.h"
@@ -111,6 +118,128 @@ bool write_all(int fd, const std::string &s) {
 
 }  // namespace
 
+// Several sweep workers, each with its own reader, over contiguous slices of the position-sorted
+// target list; batches flow to the caller through a bounded queue.  Replaces the reference's
+// rayon par_bridge over loci (src/call.rs:115-118) on the decode side.
+class ParallelFrontEnd {
+public:
+    struct Item {
+        HostBatch batch;
+        std::vector<uint32_t> index;  // position of each batch locus in the full target list
+    };
+    ParallelFrontEnd(const std::string &bam_path, BamFile &hdr, const std::vector<RepeatInterval> &targets, bool unphased,
+                     int n_workers)
+        : path_(bam_path), targets_(targets), unphased_(unphased) {
+        std::vector<uint32_t> order(targets.size());
+        for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            int ta = hdr.tid(targets[a].chrom), tb = hdr.tid(targets[b].chrom);
+            if (ta != tb) return ta < tb;
+            return targets[a].start < targets[b].start;
+        });
+        const size_t n = order.size();
+        const size_t n_slices = std::max<size_t>(1, std::min<size_t>(n, (size_t)n_workers * 3));
+        for (size_t k = 0; k < n_slices; ++k) {
+            size_t lo = n * k / n_slices, hi = n * (k + 1) / n_slices;
+            if (hi > lo) slices_.emplace_back(order.begin() + lo, order.begin() + hi);
+        }
+        live_ = n_workers;
+        for (int w = 0; w < n_workers; ++w) pool_.emplace_back([this] { work(); });
+    }
+    ~ParallelFrontEnd() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_space_.notify_all();
+        for (auto &t : pool_) t.join();
+    }
+    // hand a consumed item back so its vectors' capacity is reused (no mmap/munmap churn while the
+    // HIP runtime is pinning pages on another thread)
+    void recycle(Item &&it) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (free_.size() < 16) free_.push_back(std::move(it));
+    }
+    // 1 = item, 0 = done, -1 = error
+    int next(Item &out, std::string *err, bool *panic) {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_item_.wait(g, [&] { return !q_.empty() || live_ == 0 || failed_; });
+        if (failed_) {
+            *err = err_;
+            *panic = panic_;
+            return -1;
+        }
+        if (q_.empty()) return 0;
+        out = std::move(q_.front());
+        q_.pop_front();
+        cv_space_.notify_one();
+        return 1;
+    }
+
+private:
+    void work() {
+        BamFile bam(1);
+        std::string e;
+        bool ok = bam.open(path_, &e);
+        for (;;) {
+            size_t k = next_slice_.fetch_add(1);
+            if (!ok || k >= slices_.size()) break;
+            std::vector<RepeatInterval> sub;
+            sub.reserve(slices_[k].size());
+            for (uint32_t i : slices_[k]) sub.push_back(targets_[i]);
+            FrontEnd fe(bam, sub, unphased_);
+            for (;;) {
+                Item it;
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    if (!free_.empty()) {
+                        it = std::move(free_.back());
+                        free_.pop_back();
+                    }
+                }
+                bool panic = false;
+                int rc = fe.next(it.batch, &e, &panic);
+                if (rc < 0) {
+                    std::lock_guard<std::mutex> g(mu_);
+                    if (!failed_) failed_ = true, err_ = e, panic_ = panic;
+                    ok = false;
+                    break;
+                }
+                if (rc == 0) break;
+                it.index.resize(it.batch.locus_index.size());
+                for (size_t j = 0; j < it.index.size(); ++j) it.index[j] = slices_[k][it.batch.locus_index[j]];
+                std::unique_lock<std::mutex> g(mu_);
+                cv_space_.wait(g, [&] { return q_.size() < 8 || stop_; });
+                if (stop_) return;
+                q_.push_back(std::move(it));
+                cv_item_.notify_one();
+            }
+            if (!ok) break;
+        }
+        if (!ok && !e.empty()) {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!failed_) failed_ = true, err_ = e, panic_ = true;
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        --live_;
+        cv_item_.notify_all();
+    }
+
+    std::string path_;
+    const std::vector<RepeatInterval> &targets_;
+    bool unphased_;
+    std::vector<std::vector<uint32_t>> slices_;
+    std::atomic<size_t> next_slice_{0};
+    std::vector<std::thread> pool_;
+    std::mutex mu_;
+    std::condition_variable cv_item_, cv_space_;
+    std::deque<Item> q_;
+    std::vector<Item> free_;
+    int live_ = 0;
+    bool stop_ = false, failed_ = false, panic_ = false;
+    std::string err_;
+};
+
 struct inq_frontend {
     Prepared P;
     std::unique_ptr<FrontEnd> fe;
@@ -174,6 +303,11 @@ int inq_frontend_next(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **l
 void inq_frontend_close(inq_frontend_t *fe) { delete fe; }
 
 int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
+    using clk = std::chrono::steady_clock;
+    const bool timing = std::getenv("INQ_TIMING") != nullptr;
+    auto t_start = clk::now();
+    double t_front = 0, t_dev = 0;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     inq_frontend_t *F = nullptr;
     int rc = inq_frontend_open(args, &F, errbuf, errcap);
     if (rc != INQ_EXIT_OK) return rc;
@@ -181,43 +315,119 @@ int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, 
     const size_t n = F->P.targets.size();
     std::vector<double> p1(n, NAN), p2(n, NAN);
 
+    auto t_prep = clk::now();
+    // HIP runtime start-up (~0.2 s) overlaps the first BAM sweeps
     inq_ctx_t *ctx = nullptr;
-    int hrc = inq_ctx_create(args->device, &ctx);
-    if (hrc != INQ_OK) {
-        set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
-        return INQ_EXIT_ERROR;
-    }
+    int hrc = INQ_OK;
+    std::thread ctx_thread([&] { hrc = inq_ctx_create(args->device, &ctx); });
     struct CtxGuard {
-        inq_ctx_t *c;
-        ~CtxGuard() { inq_ctx_destroy(c); }
-    } cg{ctx};
+        inq_ctx_t *&c;
+        std::thread &t;
+        ~CtxGuard() {
+            if (t.joinable()) t.join();
+            inq_ctx_destroy(c);
+        }
+    } cg{ctx, ctx_thread};
+    bool ctx_ready = false;
+    auto need_ctx = [&]() -> bool {
+        if (!ctx_ready) {
+            ctx_thread.join();
+            ctx_ready = true;
+        }
+        if (hrc != INQ_OK) {
+            set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
+            return false;
+        }
+        return true;
+    };
 
+    // -t N: N-1 sweep workers + this thread (which feeds the GPU and spins in the HIP runtime while waiting)
+    // pinned staging: the device copies come from page-locked memory this thread fills, never from the
+    // workers' pageable vectors (on-the-fly pinning contends with their page faults: 25 ms stalls)
+    struct Pinned {
+        void *p = nullptr;
+        size_t cap = 0;
+        ~Pinned() { inq_free_pinned(p); }
+        void *fit(size_t bytes) {
+            if (bytes > cap) {
+                inq_free_pinned(p);
+                p = nullptr;
+                cap = bytes + bytes / 2 + (1u << 20);
+                if (inq_alloc_pinned(cap, &p) != INQ_OK) p = nullptr, cap = 0;
+            }
+            return p;
+        }
+    } pin;
+    const int n_workers = (int)std::max<uint64_t>(1, std::min<uint64_t>(args->threads > 1 ? args->threads - 1 : 1, 64));
+    ParallelFrontEnd pfe(args->bam, *F->P.bam, F->P.targets, F->unphased, n_workers);
+    auto t_ctx = clk::now();
     std::vector<double> b1, b2;
     for (;;) {
-        inq_batch_t batch;
-        const uint32_t *index = nullptr;
-        int nb = inq_frontend_next(F, &batch, &index, errbuf, errcap);
-        if (nb < 0) return -nb;
+        ParallelFrontEnd::Item item;
+        std::string ferr;
+        bool fpanic = false;
+        auto ta = clk::now();
+        int nb = pfe.next(item, &ferr, &fpanic);
+        auto tb = clk::now();
+        t_front += secs(ta, tb);
+        if (nb < 0) {
+            set_err(errbuf, errcap, ferr);
+            return INQ_EXIT_PANIC;  // read errors are expect()/unwrap() panics in the reference (:294,346)
+        }
         if (nb == 0) break;
+        if (!need_ctx()) return INQ_EXIT_ERROR;
+        inq_batch_t batch;
+        item.batch.view(&batch, F->minlen, F->support, F->unphased);
+        {
+            auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t s0 = al(batch.n_cigar_words * 4), s1 = al(batch.n_reads * sizeof(inq_read_t)),
+                         s2 = al(batch.n_pairs * 4), s3 = al((batch.n_loci + 1) * 8), s4 = al(batch.n_loci * 4);
+            char *base = (char *)pin.fit(s0 + s1 + s2 + s3 + 2 * s4);
+            if (!base) {
+                set_err(errbuf, errcap, "cannot allocate pinned host memory");
+                return INQ_EXIT_ERROR;
+            }
+            auto put = [&](const void *src, size_t bytes, size_t &off, size_t slot) {
+                void *dst = base + off;
+                if (bytes) std::memcpy(dst, src, bytes);
+                off += slot;
+                return dst;
+            };
+            size_t off = 0;
+            batch.cigar = (const uint32_t *)put(batch.cigar, batch.n_cigar_words * 4, off, s0);
+            batch.reads = (const inq_read_t *)put(batch.reads, batch.n_reads * sizeof(inq_read_t), off, s1);
+            batch.pair_read = (const uint32_t *)put(batch.pair_read, batch.n_pairs * 4, off, s2);
+            batch.locus_pair_off = (const uint64_t *)put(batch.locus_pair_off, (batch.n_loci + 1) * 8, off, s3);
+            batch.locus_start = (const uint32_t *)put(batch.locus_start, batch.n_loci * 4, off, s4);
+            batch.locus_end = (const uint32_t *)put(batch.locus_end, batch.n_loci * 4, off, s4);
+        }
         b1.assign(batch.n_loci, NAN);
         b2.assign(batch.n_loci, NAN);
         inq_result_t res;
         std::memset(&res, 0, sizeof res);
         res.phase1 = b1.data();
         res.phase2 = b2.data();
-        hrc = inq_call_batch(ctx, &batch, &res);
-        if (hrc != INQ_OK) {
-            std::string m = std::string("device call failed: ") + inq_strerror(hrc);
-            if (hrc == INQ_ERR_HIP) m += std::string(" [") + inq_last_error(ctx) + "]";
+        auto tc = clk::now();
+        int rc2 = inq_call_batch(ctx, &batch, &res);
+        t_dev += secs(tb, clk::now());
+        if (timing && std::getenv("INQ_TIMING")[0] == '2')
+            std::fprintf(stderr, "[inq batch] loci %llu pairs %llu cigar %.1f MB  wait-ctx %.2f ms  call %.2f ms\n",
+                         (unsigned long long)batch.n_loci, (unsigned long long)batch.n_pairs, batch.n_cigar_words * 4 / 1e6,
+                         secs(tb, tc) * 1e3, secs(tc, clk::now()) * 1e3);
+        if (rc2 != INQ_OK) {
+            std::string m = std::string("device call failed: ") + inq_strerror(rc2);
+            if (rc2 == INQ_ERR_HIP) m += std::string(" [") + inq_last_error(ctx) + "]";
             set_err(errbuf, errcap, m);
             // domain errors are the reference's panics (HP > 2, bad CIGAR op, ...)
-            return (hrc == INQ_ERR_HIP || hrc == INQ_ERR_NOMEM || hrc == INQ_ERR_NO_DEVICE) ? INQ_EXIT_ERROR : INQ_EXIT_PANIC;
+            return (rc2 == INQ_ERR_HIP || rc2 == INQ_ERR_NOMEM || rc2 == INQ_ERR_NO_DEVICE) ? INQ_EXIT_ERROR : INQ_EXIT_PANIC;
         }
         for (uint64_t j = 0; j < batch.n_loci; ++j) {
-            p1[index[j]] = b1[j];
-            p2[index[j]] = b2[j];
+            p1[item.index[j]] = b1[j];
+            p2[item.index[j]] = b2[j];
         }
+        pfe.recycle(std::move(item));
     }
+    if (!need_ctx()) return INQ_EXIT_ERROR;  // no GPU is an error even for an empty target list
 
     // output, src/call.rs:137-157
     std::vector<uint32_t> order(n);
@@ -249,6 +459,9 @@ int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, 
         set_err(errbuf, errcap, "Failed writing the result.");
         return INQ_EXIT_PANIC;
     }
+    if (timing)
+        std::fprintf(stderr, "[inq timing] open+targets %.3fs  hip ctx %.3fs  front end %.3fs  device calls %.3fs  total %.3fs\n",
+                     secs(t_start, t_prep), secs(t_prep, t_ctx), t_front, t_dev, secs(t_start, clk::now()));
     return INQ_EXIT_OK;
 }
 
