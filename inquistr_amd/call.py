@@ -17,7 +17,7 @@ import numpy as np
 from .batch import READ_DTYPE, Batch, InqBatchC
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(_PKG, "lib", "libinquistr_host.so")
+HOST_LIB_PATH = os.environ.get("INQ_HOST_LIB") or os.path.join(_PKG, "lib", "libinquistr_host.so")  # INQ_HOST_LIB: sanitizer build in CI
 CLI_PATH = os.path.join(_PKG, "lib", "inquistr")
 
 HOST_ABI_SYMBOLS = (

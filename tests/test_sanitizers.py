@@ -1,0 +1,35 @@
+"""ASan + UBSan builds of the CPU-side native code (GPU sanitizers are not available on the pool):
+the host front end tests and the oracle KAT tests re-run in a child process with the instrumented
+libraries preloaded."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _san_libs():
+    out = []
+    for name in ("libasan.so", "libubsan.so"):
+        p = subprocess.run(["gcc", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+        if not os.path.isabs(p) or not os.path.exists(p):
+            return None
+        out.append(p)
+    return out
+
+
+@pytest.mark.skipif(_san_libs() is None, reason="sanitizer runtimes not installed")
+def test_host_front_end_under_asan_ubsan():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "inquistr_amd", "host"), "../lib/libinquistr_host_asan.so"],
+                          stdout=subprocess.DEVNULL)
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = " ".join(_san_libs())
+    env["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=1"
+    env["UBSAN_OPTIONS"] = "halt_on_error=1:print_stacktrace=1"
+    env["INQ_HOST_LIB"] = os.path.join(ROOT, "inquistr_amd", "lib", "libinquistr_host_asan.so")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_host_frontend.py", "-x", "-q", "-k", "not cli",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "passed" in r.stdout
