@@ -69,6 +69,9 @@ def load():
     if _lib is None:
         if not os.path.exists(HOST_LIB_PATH):
             raise ImportError(f"{HOST_LIB_PATH} not found: run __graft_entry__.build()")
+        from . import hipcall
+
+        hipcall.load()  # HIP runtime load order (see hipcall.load) + the library this one links against
         L = C.CDLL(HOST_LIB_PATH)
         vp = C.c_void_p
         L.inq_genotype_repeats.restype = C.c_int

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional, Tuple
 
 import numpy as np
@@ -56,6 +57,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own libamdhip64.so.7; both it and /opt/rocm's carry the same SONAME, so
+    # the first one loaded serves the whole process.  With ours first, torch later reports "No HIP GPUs
+    # are available"; with torch's first, both work.  So when torch is installed (it provides device
+    # memory and streams to bench.py and the tests) let it bring its runtime in before we load ours.
+    if "torch" not in sys.modules and os.environ.get("INQ_SKIP_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP extension first "

@@ -271,7 +271,10 @@ class DeviceBatch:
     """The same buffers resident in HBM as torch tensors + the inq_batch_t / inq_result_t that
     point at them (device pointers)."""
 
-    def __init__(self, wl: Workload, device, lo: int = 0, hi: int = None, debug: bool = False):
+    def __init__(self, wl: Workload, device, lo: int = 0, hi: int = None, debug: bool = False, neighbors: int = 0):
+        """neighbors = k also offers every locus the reads of its k neighbours on each side (in file
+        order).  Those reads do not overlap the locus, so htslib's overlap rule on the device drops
+        them: results must not change, while every CIGAR is now walked 2k+1 times (shared reads)."""
         import torch
 
         from .batch import InqBatchC, InqResultC
@@ -291,18 +294,30 @@ class DeviceBatch:
         self.wl, self.lo, self.hi = wl, lo, hi
         self.n_loci = hi - lo
         R = wl.reads_per_locus
-        self.n_pairs = self.n_reads = self.n_loci * R
+        self.n_reads = self.n_loci * R
         self.cigar = torch.cat(cig).contiguous()
         self.reads = torch.cat(rds).contiguous()  # [n_reads, 4] int32 == inq_read_t
-        self.pair_read = torch.arange(self.n_pairs, dtype=torch.int32, device=device)
-        self.locus_pair_off = torch.arange(self.n_loci + 1, dtype=torch.int64, device=device) * R
+        if neighbors == 0:
+            self.n_pairs = self.n_reads
+            self.pair_read = torch.arange(self.n_pairs, dtype=torch.int32, device=device)
+            self.locus_pair_off = torch.arange(self.n_loci + 1, dtype=torch.int64, device=device) * R
+        else:
+            j = torch.arange(self.n_loci, dtype=torch.int64, device=device)
+            first = torch.clamp(j - neighbors, min=0) * R
+            last = torch.clamp(j + neighbors + 1, max=self.n_loci) * R
+            cnt = last - first
+            self.locus_pair_off = torch.zeros(self.n_loci + 1, dtype=torch.int64, device=device)
+            torch.cumsum(cnt, 0, out=self.locus_pair_off[1:])
+            self.n_pairs = int(self.locus_pair_off[-1].item())
+            within = torch.arange(self.n_pairs, dtype=torch.int64, device=device) - torch.repeat_interleave(self.locus_pair_off[:-1], cnt)
+            self.pair_read = (torch.repeat_interleave(first, cnt) + within).to(torch.int32)
         self.locus_start = torch.cat(ls).contiguous()
         self.locus_end = torch.cat(le).contiguous()
         self.phase1 = torch.full((self.n_loci,), float("nan"), dtype=torch.float64, device=device)
         self.phase2 = torch.full((self.n_loci,), float("nan"), dtype=torch.float64, device=device)
         self.pair_call = torch.zeros(self.n_pairs, dtype=torch.int64, device=device) if debug else None
         self.pair_bits = torch.zeros(self.n_pairs, dtype=torch.uint8, device=device) if debug else None
-        self.n_ops_total = int(self.reads[:, 1].to(torch.int64).sum().item())
+        self.n_ops_total = int(self.reads[:, 1].to(torch.int64)[self.pair_read.to(torch.int64)].sum().item())  # over pairs
 
         b = InqBatchC()
         b.n_reads, b.n_cigar_words = self.n_reads, int(self.cigar.numel())

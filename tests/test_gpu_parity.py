@@ -318,6 +318,37 @@ def test_full_size_roofline_workload(ctx, orc):
     assert gen.same_f64(part.phase2.cpu().numpy(), p2[70_000:71_000])
 
 
+def test_superset_of_candidates_changes_nothing(ctx):
+    """The ABI lets the host offer more reads than fetch() would yield (one sweep over the file instead
+    of an index query per locus): the device applies htslib's overlap rule.  Offering every locus the
+    reads of its 1 / 2 neighbours on both sides (90 / 150 reads: the deep-locus kernel) must reproduce
+    the exact rows of the plain batch, with every read now shared by 3 / 5 loci."""
+    import torch
+
+    wl = synth.WORKLOADS["phased10k"]
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    base = synth.DeviceBatch(wl, dev, 0, 3000)
+    ctx.call_batch_device(base.c_batch, base.c_result, st)
+    assert ctx.status()[0] == 0
+    p1, p2 = base.phase1.cpu().numpy(), base.phase2.cpu().numpy()
+    for k in (1, 2):
+        sup = synth.DeviceBatch(wl, dev, 0, 3000, neighbors=k)
+        assert sup.n_pairs > (2 * k) * base.n_pairs
+        ctx.call_batch_device(sup.c_batch, sup.c_result, st)
+        assert ctx.status()[0] == 0
+        assert gen.same_f64(sup.phase1.cpu().numpy(), p1) and gen.same_f64(sup.phase2.cpu().numpy(), p2)
+    # 1 neighbour on each side of 20 reads/locus keeps every locus at <= 60 reads: the wave-per-locus kernel
+    wl20 = synth.Workload("p20", 3000, reads_per_locus=20, seed=9)
+    b20 = synth.DeviceBatch(wl20, dev, 0, 3000)
+    s20 = synth.DeviceBatch(wl20, dev, 0, 3000, neighbors=1)
+    for d in (b20, s20):
+        ctx.call_batch_device(d.c_batch, d.c_result, st)
+    assert ctx.status()[0] == 0
+    assert gen.same_f64(b20.phase1.cpu().numpy(), s20.phase1.cpu().numpy())
+    assert gen.same_f64(b20.phase2.cpu().numpy(), s20.phase2.cpu().numpy())
+
+
 def test_timing_events(ctx):
     import torch
 

@@ -12,12 +12,18 @@ ap.add_argument("--workload", default="unphased100k")
 ap.add_argument("--loci", type=int, default=0)
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--neighbors", type=int, default=0)
+ap.add_argument("--reads-per-locus", type=int, default=0)
 a = ap.parse_args()
 key, vals = a.spec.split("=")
 vals = [int(v) for v in vals.split(",")]
 wl = synth.WORKLOADS[a.workload]
+if a.reads_per_locus:
+    import dataclasses
+    wl = dataclasses.replace(wl, reads_per_locus=a.reads_per_locus)
 dev = torch.device("cuda:0")
-d = synth.DeviceBatch(wl, dev, 0, a.loci or wl.n_loci)
+d = synth.DeviceBatch(wl, dev, 0, a.loci or wl.n_loci, neighbors=a.neighbors)
+print(f"pairs {d.n_pairs} reads {d.n_reads} algorithmic GB {d.algorithmic_bytes()/1e9:.3f}")
 ctx = hipcall.Context(0)
 st = torch.cuda.current_stream().cuda_stream
 res = {v: [] for v in vals}
