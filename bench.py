@@ -113,6 +113,7 @@ def main():
     lo, hi = rank * per_gpu, (rank + 1) * per_gpu
 
     ctx = hipcall.Context(local_rank)
+    ctx.set_option("max_reads_hint", wl.reads_per_locus)  # the generator's fixed depth: no deep-locus launches needed
     shard = synth.DeviceBatch(wl, dev, lo, hi)
     # results: two rotating [2, n] buffers (row 0 = H1, row 1 = H2) so the gather of step k overlaps step k+1
     outs = [torch.empty(2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]

@@ -152,7 +152,10 @@ int inq_ctx_timing_enable(inq_ctx_t *ctx, int on);
 int inq_ctx_timing_read(inq_ctx_t *ctx, int which, double *total_ms, uint64_t *launches);
 int inq_ctx_timing_reset(inq_ctx_t *ctx);
 
-/* Tuning knobs.  key: "grid_big" = workgroups launched for the deep-locus kernel (default 256);
+/* Tuning knobs.  key: "grid_medium" / "grid_big" = workgroups launched for the 65..256-read and the
+ * deeper-locus kernels (defaults 8192 / 1024); "max_reads_hint" = N > 0 promises that no locus of the
+ * following batches is offered more than N reads (N <= 64 skips both extra launches; a violated promise
+ * is reported as INQ_ERR_ARG), 0 (default) = unknown;
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);

@@ -2,6 +2,7 @@
 // HIP only: there is no CPU fallback; without a gfx950 device every entry fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -38,7 +39,10 @@ struct inq_ctx {
     // staging for the host-buffer entry
     DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
     uint32_t parity = 0;
-    uint32_t grid_big = 256;
+    uint32_t grid_big = 1024;
+    uint32_t grid_medium = 8192;
+    uint32_t max_reads_hint = 0;  // 0 = unknown; else the caller's bound on reads per locus
+    uint32_t call_hint = 0;       // set by the host-buffer entry, which sees the offsets, for its own launch
     int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
     bool timing = false;
     std::vector<EvTriple> ev_pool;
@@ -71,6 +75,7 @@ static int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
 }
 
 static int status_to_code(uint32_t st) {
+    if (st & ST_HINT) return INQ_ERR_ARG;
     if (st & ST_LOCUS) return INQ_ERR_LOCUS;
     if (st & ST_INDEX) return INQ_ERR_INDEX;
     if (st & ST_CIGAR_OP) return INQ_ERR_CIGAR_OP;
@@ -167,7 +172,11 @@ int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, v
     if (((uintptr_t)b->cigar & 15u) || ((uintptr_t)b->reads & 15u)) return INQ_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    if ((rc = ensure(c, c->worklist, (size_t)b->n_loci * 4)) != INQ_OK) return rc;
+    const uint64_t blocks = (b->n_loci + 3) / 4;
+    const uint32_t per_xcd = (uint32_t)((blocks + 7) / 8);
+    const uint32_t grid_small = per_xcd * 8u;
+    const uint32_t shard_cap = (grid_small / kListShards + 1u) * 4u;
+    if ((rc = ensure(c, c->worklist, (size_t)shard_cap * kListShards * 2 * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->sval, (size_t)b->n_pairs * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->smeta, (size_t)b->n_pairs)) != INQ_OK) return rc;
 
@@ -193,11 +202,14 @@ int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, v
     a.sval = (int64_t *)c->sval.p;
     a.smeta = (uint8_t *)c->smeta.p;
     a.parity = c->parity;
-    c->parity ^= 1u;
-    const uint64_t blocks = (b->n_loci + 3) / 4;
-    const uint32_t per_xcd = (uint32_t)((blocks + 7) / 8);
     a.blocks_per_xcd = per_xcd;
-    const uint32_t grid_small = per_xcd * 8u;
+    a.shard_cap = shard_cap;
+    const uint32_t hint = c->call_hint ? c->call_hint : c->max_reads_hint;
+    c->call_hint = 0;
+    a.only_small = (hint > 0 && hint <= 64) ? 1u : 0u;
+    // the last deep-locus kernel of a sequence clears the OTHER parity's counters; a sequence without the
+    // deep kernels appends nothing and must leave the parity alone
+    if (!a.only_small) c->parity ^= 1u;
 
     // CIGAR words of a read referenced by one locus only are read exactly once: stream them past the
     // caches (nt).  Reads shared by neighbouring loci keep the default policy so the second locus hits L2.
@@ -214,7 +226,7 @@ int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, v
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->e0, s));
     }
-    launch_locus_call(a, b->unphased != 0, nt, grid_small, c->grid_big, s, ev ? ev->e1 : nullptr);
+    launch_locus_call(a, b->unphased != 0, nt, grid_small, c->grid_medium, c->grid_big, s, ev ? ev->e1 : nullptr);
     HIP_TRY(c, hipGetLastError());
     if (ev) HIP_TRY(c, hipEventRecord(ev->e2, s));
     return INQ_OK;
@@ -239,11 +251,13 @@ int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
     int rc = check_scalars(b, r);
     if (rc != INQ_OK) return rc;
     // host-side shape checks: everything the grid and the kernels' indexing assume
+    uint64_t max_reads = 0;
     if (b->n_loci) {
         if (b->locus_pair_off[0] != 0 || b->locus_pair_off[b->n_loci] != b->n_pairs) return INQ_ERR_ARG;
         for (uint64_t j = 0; j < b->n_loci; ++j) {
             if (b->locus_pair_off[j] > b->locus_pair_off[j + 1]) return INQ_ERR_ARG;
             if (b->locus_start[j] < 10 || b->locus_end[j] < b->locus_start[j]) return INQ_ERR_LOCUS;
+            max_reads = std::max<uint64_t>(max_reads, b->locus_pair_off[j + 1] - b->locus_pair_off[j]);
         }
     }
     r->n_tie_loci = 0;
@@ -284,6 +298,7 @@ int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
     dr.pair_call = r->pair_call ? (int64_t *)c->pcall.p : nullptr;
     dr.pair_bits = r->pair_bits ? (uint8_t *)c->pbits.p : nullptr;
     dr.n_tie_loci = 0;
+    c->call_hint = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(max_reads, 1), 0xffffffffull);  // skips the deep-locus launches when no locus needs them
     if ((rc = inq_call_batch_device(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(r->phase1, dr.phase1, (size_t)b->n_loci * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(r->phase2, dr.phase2, (size_t)b->n_loci * 8, hipMemcpyDeviceToHost, s));
@@ -336,6 +351,16 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     if (std::strcmp(key, "grid_big") == 0) {
         if (value < 1 || value > 65535) return INQ_ERR_ARG;
         c->grid_big = (uint32_t)value;
+        return INQ_OK;
+    }
+    if (std::strcmp(key, "grid_medium") == 0) {
+        if (value < 1 || value > 65535) return INQ_ERR_ARG;
+        c->grid_medium = (uint32_t)value;
+        return INQ_OK;
+    }
+    if (std::strcmp(key, "max_reads_hint") == 0) {
+        if (value < 0 || value > 0xffffffffll) return INQ_ERR_ARG;
+        c->max_reads_hint = (uint32_t)value;
         return INQ_OK;
     }
     if (std::strcmp(key, "nt_loads") == 0) {

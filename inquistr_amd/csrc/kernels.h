@@ -6,10 +6,16 @@
 namespace inq {
 
 // Device-resident status block (one per ctx).
+constexpr int kListShards = 32;
+
 struct DevStatus {
     unsigned int err;           // ST_* bits OR-ed by the kernels
-    unsigned int big_count[2];  // work-list length, double-buffered by call parity
     unsigned int pad;
+    // work-list lengths [call parity][kind: 0 = medium (65..256 reads), 1 = big][shard].  Every counter
+    // sits on its own 128-byte line: returning atomics on one line serialise at ~11 ns each.
+    struct alignas(128) Counter {
+        unsigned int n;
+    } list_count[2][2][kListShards];
     unsigned long long ties;    // unphased loci whose split cuts mixed Span/Clip ties
 };
 
@@ -29,14 +35,16 @@ struct KArgs {
     uint8_t *pair_bits;  // may be null
     // ctx scratch
     DevStatus *status;
-    uint32_t *worklist;  // [n_loci]
+    uint32_t *worklist;  // [kind][kListShards][shard_cap]
     int64_t *sval;       // [n_pairs]
     uint8_t *smeta;      // [n_pairs]
     uint32_t parity;
     uint32_t blocks_per_xcd;  // grid_small / 8
+    uint32_t shard_cap;       // loci one shard can list: every locus whose block has blockIdx % kListShards == shard
+    uint32_t only_small;      // caller's promise: no locus has more than 64 offered reads
 };
 
-void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_big,
-                       hipStream_t s, hipEvent_t ev_mid);
+void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,
+                       uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid);
 
 }  // namespace inq

@@ -32,126 +32,239 @@ __device__ __forceinline__ bool before(int64_t vj, int j, int64_t v, int i) {
 // real data) meet in the same L2.  Speed only: any placement computes the same result.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t per_xcd) { return (b & 7u) * per_xcd + (b >> 3); }
 
-// Order of the per-read Calls inside one wave (one read per lane).  Every rank below orders by
-// (value, file order).  When every kept value fits 25 bits the pair is packed into ONE i32 key
-// (value << 6 | lane) so a rank costs one v_readlane + one v_cmp per element; otherwise the
-// comparison is done on the i64 value with the lane as tie-break.
-template <bool FIT>
-struct LaneOrder {
-    int64_t val;
-    int32_t key_asc;   // (val << 6) | lane
-    int32_t key_desc;  // (val << 6) | (63 - lane): "larger value first, then earlier read"
-    int lane;
-    __device__ __forceinline__ LaneOrder(int64_t v, int l) : val(v), lane(l) {
-        key_asc = (int32_t)(((uint32_t)(int32_t)v << 6) | (uint32_t)l);
-        key_desc = (int32_t)(((uint32_t)(int32_t)v << 6) | (uint32_t)(63 - l));
+// A wave holds the per-read Calls of one locus in registers: element (slot s, lane l) is read
+// 64*s + l of the locus, E slots per lane (E = 1: up to 64 reads, E = 4: up to 256).
+template <int E>
+struct Masks {
+    uint64_t m[E];
+    __device__ __forceinline__ uint32_t count() const {
+        uint32_t c = 0;
+#pragma unroll
+        for (int s = 0; s < E; ++s) c += (uint32_t)__popcll(m[s]);
+        return c;
     }
-    // number of lanes j in `mask` whose (value, j) sorts before this lane's
-    __device__ __forceinline__ uint32_t rank_asc(uint64_t mask) const {
-        uint32_t r = 0;
-        for (uint64_t mk = mask; mk; mk &= mk - 1) {
-            const int j = __builtin_ctzll(mk);
-            if (FIT) {
-                r += ((int32_t)readlane_u32((uint32_t)key_asc, j) < key_asc) ? 1u : 0u;
-            } else {
-                const int64_t vj = readlane_i64(val, j);
-                r += before(vj, j, val, lane) ? 1u : 0u;
-            }
-        }
-        return r;
-    }
-    // number of lanes j in `mask` with a larger value (ties: earlier read first)
-    __device__ __forceinline__ uint32_t rank_desc(uint64_t mask) const {
-        uint32_t r = 0;
-        for (uint64_t mk = mask; mk; mk &= mk - 1) {
-            const int j = __builtin_ctzll(mk);
-            if (FIT) {
-                r += ((int32_t)readlane_u32((uint32_t)key_desc, j) > key_desc) ? 1u : 0u;
-            } else {
-                const int64_t vj = readlane_i64(val, j);
-                r += (vj > val || (vj == val && j < lane)) ? 1u : 0u;
-            }
-        }
-        return r;
+    __device__ __forceinline__ bool any() const {
+        uint64_t o = 0;
+#pragma unroll
+        for (int s = 0; s < E; ++s) o |= m[s];
+        return o != 0ull;
     }
 };
 
-// median_str_length (src/call.rs:497-522) for the elements flagged in `gmask`, one element per
-// lane.  Wave-uniform result.
-template <bool FIT>
-__device__ __forceinline__ double median_in_lanes(uint64_t gmask, uint64_t clipmask, const LaneOrder<FIT> &o,
-                                                  uint32_t support) {
-    const int lane = o.lane;
-    const uint32_t ng = (uint32_t)__popcll(gmask);
-    if (ng < support) return qnan();  // :498-500
-    const uint64_t cm = gmask & clipmask, sm = gmask & ~clipmask;
-    const uint32_t ns = (uint32_t)__popcll(sm);
-    uint64_t chosen = sm;
-    if (ns <= support && cm != 0ull) {  // :509-513: add the largest (support - ns) clipped values
-        const uint32_t take = support - ns;
-        if (take > 0u) {
-            const uint32_t drank = o.rank_desc(cm);
-            chosen |= ballot64(((cm >> lane) & 1ull) && drank < take);
+// Order of the Calls.  Every rank below orders by (value, file order).  When every kept value fits
+// the key, (value << IDX_BITS | index) is packed into ONE i32 so a rank step costs one v_readlane + one
+// v_cmp per own element; otherwise the i64 value is compared with the index as tie-break.
+template <bool FIT, int E>
+struct LaneOrder {
+    static constexpr int IDX_BITS = (E == 1) ? 6 : 8;
+    int64_t val[E];
+    int32_t key_asc[E];   // (val << IDX_BITS) | index
+    int32_t key_desc[E];  // (val << IDX_BITS) | (max_index - index): "larger value first, then earlier read"
+    int lane;
+    __device__ __forceinline__ LaneOrder(const int64_t (&v)[E], int l) : lane(l) {
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            val[s] = v[s];
+            const uint32_t idx = (uint32_t)(s * 64 + l);
+            key_asc[s] = (int32_t)(((uint32_t)(int32_t)v[s] << IDX_BITS) | idx);
+            key_desc[s] = (int32_t)(((uint32_t)(int32_t)v[s] << IDX_BITS) | ((uint32_t)(E * 64 - 1) - idx));
         }
     }
-    const uint32_t M = (uint32_t)__popcll(chosen);  // >= 1 because support >= 1
-    const uint32_t arank = o.rank_asc(chosen);
-    const bool mine = (chosen >> lane) & 1ull;
-    const int lhi = __builtin_ctzll(ballot64(mine && arank == M / 2u));
-    const int64_t vhi = readlane_i64(o.val, lhi);
+    // r[t] = number of elements in `mask` that sort before own element t
+    __device__ __forceinline__ void rank_asc(const Masks<E> &mask, uint32_t (&r)[E]) const {
+#pragma unroll
+        for (int t = 0; t < E; ++t) r[t] = 0;
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            for (uint64_t mk = mask.m[s]; mk; mk &= mk - 1) {
+                const int j = __builtin_ctzll(mk);
+                if (FIT) {
+                    const int32_t kj = (int32_t)readlane_u32((uint32_t)key_asc[s], j);
+#pragma unroll
+                    for (int t = 0; t < E; ++t) r[t] += (kj < key_asc[t]) ? 1u : 0u;
+                } else {
+                    const int64_t vj = readlane_i64(val[s], j);
+#pragma unroll
+                    for (int t = 0; t < E; ++t) r[t] += before(vj, s * 64 + j, val[t], t * 64 + lane) ? 1u : 0u;
+                }
+            }
+        }
+    }
+    // r[t] = number of elements in `mask` with a larger value than own element t (ties: earlier read first)
+    __device__ __forceinline__ void rank_desc(const Masks<E> &mask, uint32_t (&r)[E]) const {
+#pragma unroll
+        for (int t = 0; t < E; ++t) r[t] = 0;
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            for (uint64_t mk = mask.m[s]; mk; mk &= mk - 1) {
+                const int j = __builtin_ctzll(mk);
+                if (FIT) {
+                    const int32_t kj = (int32_t)readlane_u32((uint32_t)key_desc[s], j);
+#pragma unroll
+                    for (int t = 0; t < E; ++t) r[t] += (kj > key_desc[t]) ? 1u : 0u;
+                } else {
+                    const int64_t vj = readlane_i64(val[s], j);
+#pragma unroll
+                    for (int t = 0; t < E; ++t)
+                        r[t] += (vj > val[t] || (vj == val[t] && s * 64 + j < t * 64 + lane)) ? 1u : 0u;
+                }
+            }
+        }
+    }
+    // value of the element of `mask` whose rank (as computed in r) equals `want`; wave-uniform
+    __device__ __forceinline__ int64_t pick(const Masks<E> &mask, const uint32_t (&r)[E], uint32_t want) const {
+        int64_t out = 0;
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            const uint64_t b = ballot64(((mask.m[s] >> lane) & 1ull) && r[s] == want);
+            if (b) out = readlane_i64(val[s], __builtin_ctzll(b));
+        }
+        return out;
+    }
+};
+
+// median_str_length (src/call.rs:497-522) for the elements flagged in `g`.  Wave-uniform result.
+template <bool FIT, int E>
+__device__ __forceinline__ double median_in_lanes(const Masks<E> &g, const Masks<E> &clip, const LaneOrder<FIT, E> &o,
+                                                  uint32_t support) {
+    const int lane = o.lane;
+    const uint32_t ng = g.count();
+    if (ng < support) return qnan();  // :498-500
+    Masks<E> cm, chosen;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        cm.m[s] = g.m[s] & clip.m[s];
+        chosen.m[s] = g.m[s] & ~clip.m[s];
+    }
+    const uint32_t ns = chosen.count();
+    if (ns <= support && cm.any()) {  // :509-513: add the largest (support - ns) clipped values
+        const uint32_t take = support - ns;
+        if (take > 0u) {
+            uint32_t drank[E];
+            o.rank_desc(cm, drank);
+#pragma unroll
+            for (int s = 0; s < E; ++s) chosen.m[s] |= ballot64(((cm.m[s] >> lane) & 1ull) && drank[s] < take);
+        }
+    }
+    const uint32_t M = chosen.count();  // >= 1 because support >= 1
+    uint32_t arank[E];
+    o.rank_asc(chosen, arank);
+    const int64_t vhi = o.pick(chosen, arank, M / 2u);
     if (M & 1u) return (double)vhi;  // :520
-    const int llo = __builtin_ctzll(ballot64(mine && arank == M / 2u - 1u));
-    const int64_t vlo = readlane_i64(o.val, llo);
+    const int64_t vlo = o.pick(chosen, arank, M / 2u - 1u);
     return (double)(vlo + vhi) / 2.0;  // :515-518
 }
 
-// The two medians of one locus from the per-read (val, meta) held one per lane.
-template <bool UNPHASED, bool FIT>
-__device__ __forceinline__ void reduce_locus_in_lanes(int64_t val, uint32_t meta, int lane, uint32_t support,
-                                                      double &out1, double &out2, bool &tie) {
-    const LaneOrder<FIT> o(val, lane);
-    const uint64_t kept = ballot64(meta & PM_KEPT);
-    const uint64_t clipmask = ballot64((meta & PM_KEPT) && (meta & PM_CLIP));
+// The two medians of one locus from the per-read (val, meta) held in registers.
+template <bool UNPHASED, bool FIT, int E>
+__device__ __forceinline__ void reduce_locus_in_lanes(const int64_t (&val)[E], const uint32_t (&meta)[E], int lane,
+                                                      uint32_t support, double &out1, double &out2, bool &tie) {
+    const LaneOrder<FIT, E> o(val, lane);
+    Masks<E> kept, clip;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        kept.m[s] = ballot64(meta[s] & PM_KEPT);
+        clip.m[s] = ballot64((meta[s] & PM_KEPT) && (meta[s] & PM_CLIP));
+    }
     tie = false;
     if (UNPHASED) {
         // src/call.rs:311-313: sort by value (ties: file order), h1 = lower n/2, h2 = the rest
-        const uint32_t mcount = (uint32_t)__popcll(kept);
+        const uint32_t mcount = kept.count();
         const uint32_t ks = mcount / 2u;
-        const uint32_t rank = o.rank_asc(kept);
-        const bool mine = (kept >> lane) & 1ull;
-        auto pick = [&](uint32_t r) -> int64_t {
-            return readlane_i64(val, __builtin_ctzll(ballot64(mine && rank == r)));
-        };
-        if (clipmask == 0ull) {
+        uint32_t rank[E];
+        o.rank_asc(kept, rank);
+        if (!clip.any()) {
             // no soft-clipped call at this locus: every group member is "spanning", so the
             // within-group order is the global order and the medians can be read off `rank`
             auto med = [&](uint32_t base, uint32_t cnt) -> double {
                 if (cnt < support) return qnan();
-                if (cnt & 1u) return (double)pick(base + cnt / 2u);
-                return (double)(pick(base + cnt / 2u - 1u) + pick(base + cnt / 2u)) / 2.0;
+                if (cnt & 1u) return (double)o.pick(kept, rank, base + cnt / 2u);
+                return (double)(o.pick(kept, rank, base + cnt / 2u - 1u) + o.pick(kept, rank, base + cnt / 2u)) / 2.0;
             };
             out1 = med(0u, ks);
             out2 = med(ks, mcount - ks);
         } else {
-            const uint64_t g1 = ballot64(mine && rank < ks);
-            const uint64_t g2 = kept & ~g1;
+            Masks<E> g1, g2;
+#pragma unroll
+            for (int s = 0; s < E; ++s) {
+                g1.m[s] = ballot64(((kept.m[s] >> lane) & 1ull) && rank[s] < ks);
+                g2.m[s] = kept.m[s] & ~g1.m[s];
+            }
             if (ks >= 1u && ks < mcount) {
-                const int64_t va = pick(ks - 1u), vb = pick(ks);
+                const int64_t va = o.pick(kept, rank, ks - 1u), vb = o.pick(kept, rank, ks);
                 if (va == vb) {
-                    const uint64_t eq = ballot64(mine && val == va);
-                    tie = (eq & clipmask) != 0ull && (eq & ~clipmask) != 0ull;
+                    bool has_clip = false, has_span = false;
+#pragma unroll
+                    for (int s = 0; s < E; ++s) {
+                        const uint64_t eq = ballot64(((kept.m[s] >> lane) & 1ull) && val[s] == va);
+                        has_clip |= (eq & clip.m[s]) != 0ull;
+                        has_span |= (eq & ~clip.m[s]) != 0ull;
+                    }
+                    tie = has_clip && has_span;
                 }
             }
-            out1 = median_in_lanes<FIT>(g1, clipmask, o, support);
-            out2 = median_in_lanes<FIT>(g2, clipmask, o, support);
+            out1 = median_in_lanes<FIT, E>(g1, clip, o, support);
+            out2 = median_in_lanes<FIT, E>(g2, clip, o, support);
         }
     } else {
-        const uint64_t g1 = ballot64(((meta >> PM_GRP_SHIFT) & 3u) == 1u);
-        const uint64_t g2 = ballot64(((meta >> PM_GRP_SHIFT) & 3u) == 2u);
-        out1 = median_in_lanes<FIT>(g1, clipmask, o, support);  // src/call.rs:367
-        out2 = median_in_lanes<FIT>(g2, clipmask, o, support);  // src/call.rs:368
+        Masks<E> g1, g2;
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            g1.m[s] = ballot64(((meta[s] >> PM_GRP_SHIFT) & 3u) == 1u);
+            g2.m[s] = ballot64(((meta[s] >> PM_GRP_SHIFT) & 3u) == 2u);
+        }
+        out1 = median_in_lanes<FIT, E>(g1, clip, o, support);  // src/call.rs:367
+        out2 = median_in_lanes<FIT, E>(g2, clip, o, support);  // src/call.rs:368
     }
 }
+
+// One locus with up to 64*E offered reads, on one wave.
+template <bool UNPHASED, int AUX, int E>
+__device__ __forceinline__ void wave_locus(const KArgs &a, uint64_t j, uint64_t p0, int n, uint32_t start, uint32_t end,
+                                           int lane, WaveLds &L) {
+    Window W;
+    W.se = start - 10u;
+    W.ee = end + 10u;
+    W.se1 = W.se + 1u;
+    W.width = W.ee - W.se1;
+    W.minlen = a.minlen;
+    BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
+    uint32_t status = 0;
+    int64_t val[E];
+    uint32_t meta[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        val[s] = 0;
+        meta[s] = 0;
+        const int cnt = min(64, n - s * 64);
+        if (cnt > 0) {  // wave-uniform
+            bool valid;
+            const uint64_t first = p0 + (uint64_t)(s * 64);
+            const PairMeta m = load_pair_meta(b, first, cnt, lane, status, valid);
+            walk_pairs<UNPHASED, AUX>(b, m, valid, cnt, W, lane, status, L, val[s], meta[s]);
+            if (a.pair_call && lane < cnt) a.pair_call[first + lane] = val[s];
+            if (a.pair_bits && lane < cnt) a.pair_bits[first + lane] = (uint8_t)(meta[s] & 7u);
+        }
+    }
+    bool tie;
+    double out1, out2;
+    constexpr int64_t kFit = 1ll << (31 - LaneOrder<true, E>::IDX_BITS);
+    bool big_value = false;
+#pragma unroll
+    for (int s = 0; s < E; ++s) big_value |= (meta[s] & PM_KEPT) && (val[s] < -kFit || val[s] >= kFit);
+    if (ballot64(big_value) == 0ull)
+        reduce_locus_in_lanes<UNPHASED, true, E>(val, meta, lane, a.support, out1, out2, tie);
+    else
+        reduce_locus_in_lanes<UNPHASED, false, E>(val, meta, lane, a.support, out1, out2, tie);
+    if (lane == 0) {
+        a.phase1[j] = out1;
+        a.phase2[j] = out2;
+        if (tie) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
+    }
+    if (status) atomicOr(&a.status->err, status);  // per lane: index / phase errors belong to the lane's read
+}
+
+constexpr int kMediumSlots = 4;  // locus_call_medium: up to 256 reads per wave
 
 // AUX: cache policy of the CIGAR stream loads (0 = default, 2 = nt: read-once data)
 template <bool UNPHASED, int AUX>
@@ -168,6 +281,8 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
     uint32_t status = 0;
     if (p1 < p0 || p1 > a.n_pairs) status |= ST_INDEX;
     if (start < 10u || end < start) status |= ST_LOCUS;  // src/call.rs:285 (u32 underflow), repeats.rs:102
+    const uint64_t n64 = p1 - p0;
+    if (!status && n64 > 64ull && a.only_small) status |= ST_HINT;  // the caller promised <= 64 reads per locus
     if (status) {
         if (lane == 0) {
             atomicOr(&a.status->err, status);
@@ -176,62 +291,69 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
         }
         return;
     }
-    const uint64_t n64 = p1 - p0;
-    if (n64 > 64ull) {  // deep locus: hand over to locus_call_big
+    if (n64 > 64ull) {  // deeper locus: list it for locus_call_medium (<= 256 reads) or locus_call_big
         if (lane == 0) {
-            const uint32_t slot = atomicAdd(&a.status->big_count[a.parity], 1u);
-            a.worklist[slot] = (uint32_t)j;
+            const uint32_t kind = n64 > 64ull * kMediumSlots ? 1u : 0u;
+            const uint32_t shard = blockIdx.x % kListShards;
+            const uint32_t slot = atomicAdd(&a.status->list_count[a.parity][kind][shard].n, 1u);
+            a.worklist[((uint64_t)kind * kListShards + shard) * a.shard_cap + slot] = (uint32_t)j;
         }
         return;
     }
-    const int n = (int)n64;
-    Window W;
-    W.se = start - 10u;
-    W.ee = end + 10u;
-    W.se1 = W.se + 1u;
-    W.width = W.ee - W.se1;
-    W.minlen = a.minlen;
+    wave_locus<UNPHASED, AUX, 1>(a, j, p0, (int)n64, start, end, lane, lds[wave]);
+}
 
-    BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
-    bool valid;
-    const PairMeta m = load_pair_meta(b, p0, n, lane, status, valid);
-
-    int64_t val;
-    uint32_t meta;
-    walk_pairs<UNPHASED, AUX>(b, m, valid, n, W, lane, status, lds[wave], val, meta);
-    if (a.pair_call && lane < n) a.pair_call[p0 + lane] = val;
-    if (a.pair_bits && lane < n) a.pair_bits[p0 + lane] = (uint8_t)(meta & 7u);
-
-    bool tie;
-    double out1, out2;
-    const bool big_value = (meta & PM_KEPT) && (val < -(1ll << 24) || val >= (1ll << 24));
-    if (ballot64(big_value) == 0ull)
-        reduce_locus_in_lanes<UNPHASED, true>(val, meta, lane, a.support, out1, out2, tie);
-    else
-        reduce_locus_in_lanes<UNPHASED, false>(val, meta, lane, a.support, out1, out2, tie);
-    if (lane == 0) {
-        a.phase1[j] = out1;
-        a.phase2[j] = out2;
-        if (tie) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
+// Loci with 65..256 offered reads: still one wave per locus, four reads per lane.  Persistent waves
+// stride over the work list that locus_call_small filled.
+template <bool UNPHASED, int AUX>
+__global__ __launch_bounds__(256) void locus_call_medium(KArgs a) {
+    __shared__ WaveLds lds[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ uint32_t cnt[kListShards];
+    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[a.parity][0][threadIdx.x].n;
+    __syncthreads();
+    uint32_t total = 0;
+    for (int k = 0; k < kListShards; ++k) total += cnt[k];
+    for (uint32_t item = blockIdx.x * 4u + wave; item < total; item += gridDim.x * 4u) {
+        uint32_t shard = 0, idx = item;
+        while (idx >= cnt[shard]) idx -= cnt[shard++];
+        const uint64_t j = a.worklist[(uint64_t)shard * a.shard_cap + idx];
+        const uint64_t p0 = a.locus_pair_off[j];
+        const int n = (int)(a.locus_pair_off[j + 1] - p0);
+        wave_locus<UNPHASED, AUX, kMediumSlots>(a, j, p0, n, a.locus_start[j], a.locus_end[j], lane, lds[wave]);
     }
-    if (status) atomicOr(&a.status->err, status);  // per lane: index / phase errors belong to the lane's read
 }
 
 // ---------------------------------------------------------------------------------------------
 // Deep loci.  Scratch layout: sval[p] (i64) and smeta[p] (u8) indexed by global pair number.
 
 constexpr int kBigPairsPerWave = 16;
+constexpr uint32_t kBigLdsCap = 2048;  // per-read results of loci up to this depth stay in LDS
 
 struct BigShared {
     unsigned int cnt_kept, ng[3], ns[3];
     unsigned int tie_span, tie_clip;
     long long med[3][2];
     long long split_lo, split_hi;
+    long long lval[kBigLdsCap];
+    unsigned char lmeta[kBigLdsCap];
 };
 
-// rank counting over the scratch for one group; returns via sh.med[g]
-__device__ void big_group_median(const KArgs &a, uint64_t p0, uint32_t n, int g, uint32_t support, BigShared &sh,
-                                 double &out) {
+// Per-read results of one deep locus: in LDS up to kBigLdsCap reads (workgroup barriers suffice), in
+// the ctx's global scratch beyond (needs agent-scope fences between the passes: slow, but any depth).
+struct DeepStore {
+    int64_t *val;
+    unsigned char *meta;
+    bool global;
+    __device__ __forceinline__ void publish() const {
+        if (global) __threadfence();
+        __syncthreads();
+    }
+};
+
+// rank counting over the store for one group; returns via sh.med[g]
+__device__ void big_group_median(const DeepStore &S, uint32_t n, int g, uint32_t support, BigShared &sh, double &out) {
     const uint32_t ng = sh.ng[g], ns = sh.ns[g];
     if (ng < support) {  // uniform over the block
         out = qnan();
@@ -240,19 +362,19 @@ __device__ void big_group_median(const KArgs &a, uint64_t p0, uint32_t n, int g,
     const uint32_t take = (ns <= support) ? support - ns : 0u;
     // chosen = spans of the group, plus the `take` largest clips (src/call.rs:509-513)
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-        uint32_t me = a.smeta[p0 + e];
+        uint32_t me = S.meta[e];
         const bool ing = (me & PM_KEPT) && ((me >> PM_GRP_SHIFT) & 3u) == (uint32_t)g;
         bool ch = false;
         if (ing) {
             if (!(me & PM_CLIP))
                 ch = true;
             else if (take > 0u) {
-                const int64_t v = a.sval[p0 + e];
+                const int64_t v = S.val[e];
                 uint32_t drank = 0;
                 for (uint32_t jx = 0; jx < n && drank < take; ++jx) {
-                    const uint32_t mj = a.smeta[p0 + jx];
+                    const uint32_t mj = S.meta[jx];
                     if ((mj & PM_KEPT) && (mj & PM_CLIP) && ((mj >> PM_GRP_SHIFT) & 3u) == (uint32_t)g) {
-                        const int64_t vj = a.sval[p0 + jx];
+                        const int64_t vj = S.val[jx];
                         drank += (vj > v || (vj == v && jx < e)) ? 1u : 0u;
                     }
                 }
@@ -261,20 +383,19 @@ __device__ void big_group_median(const KArgs &a, uint64_t p0, uint32_t n, int g,
         }
         // the chosen bit of group 1 must not leak into group 2: it is rewritten per group
         me = ch ? (me | PM_CHOSEN) : (me & ~PM_CHOSEN);
-        a.smeta[p0 + e] = (uint8_t)me;
+        S.meta[e] = (unsigned char)me;
     }
-    __threadfence();
-    __syncthreads();
+    S.publish();
     const uint32_t M = (ns > support) ? ns : support;
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-        const uint32_t me = a.smeta[p0 + e];
+        const uint32_t me = S.meta[e];
         if (!((me & PM_CHOSEN) && ((me >> PM_GRP_SHIFT) & 3u) == (uint32_t)g)) continue;
-        const int64_t v = a.sval[p0 + e];
+        const int64_t v = S.val[e];
         uint32_t arank = 0;
         for (uint32_t jx = 0; jx < n; ++jx) {
-            const uint32_t mj = a.smeta[p0 + jx];
+            const uint32_t mj = S.meta[jx];
             if ((mj & PM_CHOSEN) && ((mj >> PM_GRP_SHIFT) & 3u) == (uint32_t)g) {
-                const int64_t vj = a.sval[p0 + jx];
+                const int64_t vj = S.val[jx];
                 arank += before(vj, (int)jx, v, (int)e) ? 1u : 0u;
             }
         }
@@ -295,13 +416,21 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
     __shared__ WaveLds lds[4];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_big = a.status->big_count[a.parity];
-    // the other parity's counter belongs to the next call on this ctx: clear it here, one kernel
-    // boundary before locus_call_small of that call increments it
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.status->big_count[a.parity ^ 1u] = 0u;
+    // the work list is sharded (blockIdx % kListShards of the producer): many counters instead of one hot word
+    __shared__ uint32_t cnt[kListShards];
+    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[a.parity][1][threadIdx.x].n;
+    __syncthreads();
+    uint32_t total = 0;
+    for (int k = 0; k < kListShards; ++k) total += cnt[k];
+    // the other parity's counters belong to the next deep-locus call on this ctx: clear them here (last
+    // kernel of the sequence), kernel boundaries before locus_call_small of that call increments them
+    if (blockIdx.x == 0 && threadIdx.x < 2 * kListShards)
+        a.status->list_count[a.parity ^ 1u][threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
 
-    for (uint32_t item = blockIdx.x; item < n_big; item += gridDim.x) {
-        const uint64_t j = a.worklist[item];
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+        uint32_t shard = 0, idx = item;
+        while (idx >= cnt[shard]) idx -= cnt[shard++];
+        const uint64_t j = a.worklist[((uint64_t)kListShards + shard) * a.shard_cap + idx];
         const uint64_t p0 = a.locus_pair_off[j];
         const uint32_t n = (uint32_t)(a.locus_pair_off[j + 1] - p0);
         const uint32_t start = a.locus_start[j], end = a.locus_end[j];
@@ -312,6 +441,10 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
         W.width = W.ee - W.se1;
         W.minlen = a.minlen;
         BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
+        DeepStore S;
+        S.global = n > kBigLdsCap;
+        S.val = S.global ? (int64_t *)(a.sval + p0) : (int64_t *)sh.lval;
+        S.meta = S.global ? (unsigned char *)(a.smeta + p0) : sh.lmeta;
         uint32_t status = 0;
         if (threadIdx.x == 0) {
             sh.cnt_kept = 0;
@@ -321,53 +454,52 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
         // ---- walk: the 4 waves take blocks of kBigPairsPerWave reads in turn ----
         const uint32_t nblk = (n + kBigPairsPerWave - 1) / kBigPairsPerWave;
         for (uint32_t blk = wave; blk < nblk; blk += 4u) {
-            const uint64_t first = p0 + (uint64_t)blk * kBigPairsPerWave;
-            const int cnt = (int)min((uint32_t)kBigPairsPerWave, n - blk * kBigPairsPerWave);
+            const uint32_t e0 = blk * kBigPairsPerWave;
+            const uint64_t first = p0 + e0;
+            const int cnt_r = (int)min((uint32_t)kBigPairsPerWave, n - e0);
             bool valid;
-            const PairMeta m = load_pair_meta(b, first, cnt, lane, status, valid);
-                    int64_t val;
+            const PairMeta m = load_pair_meta(b, first, cnt_r, lane, status, valid);
+            int64_t val;
             uint32_t meta;
-            walk_pairs<UNPHASED, AUX>(b, m, valid, cnt, W, lane, status, lds[wave], val, meta);
-            if (lane < cnt) {
-                a.sval[first + lane] = val;
-                a.smeta[first + lane] = (uint8_t)meta;
+            walk_pairs<UNPHASED, AUX>(b, m, valid, cnt_r, W, lane, status, lds[wave], val, meta);
+            if (lane < cnt_r) {
+                S.val[e0 + lane] = val;
+                S.meta[e0 + lane] = (unsigned char)meta;
                 if (a.pair_call) a.pair_call[first + lane] = val;
                 if (a.pair_bits) a.pair_bits[first + lane] = (uint8_t)(meta & 7u);
             }
         }
         if (status) atomicOr(&a.status->err, status);
-        __threadfence();
-        __syncthreads();
+        S.publish();
 
         // ---- unphased: global rank -> haplotype group (src/call.rs:311-313) ----
         if (UNPHASED) {
             uint32_t local = 0;
-            for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) local += (a.smeta[p0 + e] & PM_KEPT) ? 1u : 0u;
+            for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) local += (S.meta[e] & PM_KEPT) ? 1u : 0u;
             if (local) atomicAdd(&sh.cnt_kept, local);
             __syncthreads();
             const uint32_t mcount = sh.cnt_kept, ks = mcount / 2u;
             for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-                uint32_t me = a.smeta[p0 + e];
+                uint32_t me = S.meta[e];
                 if (!(me & PM_KEPT)) continue;
-                const int64_t v = a.sval[p0 + e];
+                const int64_t v = S.val[e];
                 uint32_t rank = 0;
                 for (uint32_t jx = 0; jx < n; ++jx)
-                    if (a.smeta[p0 + jx] & PM_KEPT) rank += before(a.sval[p0 + jx], (int)jx, v, (int)e) ? 1u : 0u;
+                    if (S.meta[jx] & PM_KEPT) rank += before(S.val[jx], (int)jx, v, (int)e) ? 1u : 0u;
                 const uint32_t grp = rank < ks ? 1u : 2u;
-                // group bits live in a second byte plane until every rank is known: other threads
-                // still read PM_KEPT of this byte, and KEPT is not modified by this write
+                // other threads still read PM_KEPT of this byte while ranks are being counted; the
+                // group bits written here leave PM_KEPT untouched
                 me = (me & ~(3u << PM_GRP_SHIFT)) | (grp << PM_GRP_SHIFT);
-                a.smeta[p0 + e] = (uint8_t)me;
+                S.meta[e] = (unsigned char)me;
                 if (ks >= 1u && rank == ks - 1u) sh.split_lo = v;
                 if (rank == ks) sh.split_hi = v;
             }
-            __threadfence();
-            __syncthreads();
+            S.publish();
             if (ks >= 1u && ks < mcount && sh.split_lo == sh.split_hi) {
                 const int64_t vs = sh.split_lo;
                 for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-                    const uint32_t me = a.smeta[p0 + e];
-                    if ((me & PM_KEPT) && a.sval[p0 + e] == vs) {
+                    const uint32_t me = S.meta[e];
+                    if ((me & PM_KEPT) && S.val[e] == vs) {
                         if (me & PM_CLIP)
                             sh.tie_clip = 1u;
                         else
@@ -381,7 +513,7 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
         {
             uint32_t c_ng[3] = {0, 0, 0}, c_ns[3] = {0, 0, 0};
             for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-                const uint32_t me = a.smeta[p0 + e];
+                const uint32_t me = S.meta[e];
                 if (!(me & PM_KEPT)) continue;
                 const uint32_t g = (me >> PM_GRP_SHIFT) & 3u;
                 if (g == 1u || g == 2u) {
@@ -396,8 +528,8 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
         }
         __syncthreads();
         double out1, out2;
-        big_group_median(a, p0, n, 1, a.support, sh, out1);
-        big_group_median(a, p0, n, 2, a.support, sh, out2);
+        big_group_median(S, n, 1, a.support, sh, out1);
+        big_group_median(S, n, 2, a.support, sh, out2);
         if (threadIdx.x == 0) {
             a.phase1[j] = out1;
             a.phase2[j] = out2;
@@ -409,24 +541,27 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
 
 // ---- launchers (called from capi.hip) ----
 template <bool UNPHASED, int AUX>
-static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid) {
+static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, uint32_t grid_big, hipStream_t s,
+                     hipEvent_t ev_mid) {
     if (grid_small) hipLaunchKernelGGL((locus_call_small<UNPHASED, AUX>), dim3(grid_small), dim3(256), 0, s, a);
     if (ev_mid) (void)hipEventRecord(ev_mid, s);
+    if (a.only_small) return;  // no locus can be on a work list
+    hipLaunchKernelGGL((locus_call_medium<UNPHASED, AUX>), dim3(grid_medium), dim3(256), 0, s, a);
     hipLaunchKernelGGL((locus_call_big<UNPHASED, AUX>), dim3(grid_big), dim3(256), 0, s, a);
 }
 
-void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_big,
-                       hipStream_t s, hipEvent_t ev_mid) {
+void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,
+                       uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid) {
     if (unphased) {
         if (nt_loads)
-            launch_t<true, 2>(a, grid_small, grid_big, s, ev_mid);
+            launch_t<true, 2>(a, grid_small, grid_medium, grid_big, s, ev_mid);
         else
-            launch_t<true, 0>(a, grid_small, grid_big, s, ev_mid);
+            launch_t<true, 0>(a, grid_small, grid_medium, grid_big, s, ev_mid);
     } else {
         if (nt_loads)
-            launch_t<false, 2>(a, grid_small, grid_big, s, ev_mid);
+            launch_t<false, 2>(a, grid_small, grid_medium, grid_big, s, ev_mid);
         else
-            launch_t<false, 0>(a, grid_small, grid_big, s, ev_mid);
+            launch_t<false, 0>(a, grid_small, grid_medium, grid_big, s, ev_mid);
     }
 }
 

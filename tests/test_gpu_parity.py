@@ -107,11 +107,12 @@ def test_random_vs_oracle(ctx, orc, seed, unphased):
 
 
 @pytest.mark.parametrize("unphased", [False, True])
-@pytest.mark.parametrize("max_reads", [64, 65, 130, 700])
+@pytest.mark.parametrize("max_reads", [64, 65, 130, 700, 2048, 2300])
 def test_deep_loci(ctx, orc, unphased, max_reads):
     """Loci with more than 64 offered reads take the work-list kernel."""
-    batch, _ = gen.random_case(1000 + max_reads, n_loci=24, unphased=unphased, max_reads=max_reads,
-                               long_every=9, support=3)
+    # up to 2048 reads the per-read results stay in LDS, beyond they go through the global scratch
+    batch, _ = gen.random_case(1000 + max_reads, n_loci=24 if max_reads < 2000 else 8, unphased=unphased,
+                               max_reads=max_reads, long_every=9, support=3)
     assert int(np.diff(batch.locus_pair_off.astype(np.int64)).max()) >= max_reads
     rc, got = ctx.call_batch(batch, debug=True)
     oc, want = orc.call_batch(batch, debug=True)
@@ -347,6 +348,29 @@ def test_superset_of_candidates_changes_nothing(ctx):
     assert ctx.status()[0] == 0
     assert gen.same_f64(b20.phase1.cpu().numpy(), s20.phase1.cpu().numpy())
     assert gen.same_f64(b20.phase2.cpu().numpy(), s20.phase2.cpu().numpy())
+
+
+def test_max_reads_hint(ctx):
+    """A promise of <= 64 reads per locus skips the deep-locus launches; breaking it is reported."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    wl = synth.Workload("p70", 500, reads_per_locus=70, seed=3)
+    d = synth.DeviceBatch(wl, dev, 0, 500)
+    ctx.call_batch_device(d.c_batch, d.c_result, st)
+    assert ctx.status()[0] == 0
+    want = d.phase1.cpu().numpy().copy()
+    try:
+        ctx.set_option("max_reads_hint", 64)
+        ctx.call_batch_device(d.c_batch, d.c_result, st)
+        assert ctx.status()[0] == B.INQ_ERR_ARG
+        ctx.set_option("max_reads_hint", 70)
+        d.phase1.fill_(7.0)
+        ctx.call_batch_device(d.c_batch, d.c_result, st)
+        assert ctx.status()[0] == 0 and gen.same_f64(d.phase1.cpu().numpy(), want)
+    finally:
+        ctx.set_option("max_reads_hint", 0)
 
 
 def test_timing_events(ctx):

@@ -13,6 +13,7 @@ ap.add_argument("--loci", type=int, default=0)
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--neighbors", type=int, default=0)
+ap.add_argument("--which", type=int, default=1, help="0 = whole launch sequence, 1 = locus_call_small only")
 ap.add_argument("--reads-per-locus", type=int, default=0)
 a = ap.parse_args()
 key, vals = a.spec.split("=")
@@ -35,7 +36,7 @@ for r in range(a.rounds + 1):
         for _ in range(a.steps):
             ctx.call_batch_device(d.c_batch, d.c_result, st)
         torch.cuda.synchronize()
-        ms, n = ctx.timing_read(1)
+        ms, n = ctx.timing_read(a.which)
         if r:  # round 0 = warm-up
             res[v].append(ms / n)
 assert ctx.status()[0] == 0
