@@ -61,6 +61,12 @@ int inq_frontend_next(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **l
 void inq_frontend_set_batch_words(inq_frontend_t *fe, uint64_t max_cigar_words);
 void inq_frontend_close(inq_frontend_t *fe);
 
+/* `inquiSTR combine` (src/combine.rs:27-59): column-wise paste of N .inq files — every line of the first
+ * file, then columns 4.. of the same line of each other file, tab-joined.  Files ending in ".gz" are
+ * read through gzip (src/combine.rs:10-25).  Returns 0, or 101 where the reference panics (missing
+ * file, a later file with fewer lines than the first). */
+int inq_combine(const char *const *files, size_t n_files, int out_fd, char *errbuf, size_t errcap);
+
 /* ---- text side (src/call.rs:27-65, 91-101) ---- */
 size_t inq_host_format_f64(double v, char *buf, size_t cap);
 size_t inq_host_format_row(const char *chrom, uint32_t start, uint32_t end, double p1, double p2, char *buf, size_t cap);

@@ -22,6 +22,7 @@ CLI_PATH = os.path.join(_PKG, "lib", "inquistr")
 
 HOST_ABI_SYMBOLS = (
     "inq_genotype_repeats",
+    "inq_combine",
     "inq_frontend_open",
     "inq_frontend_n_targets",
     "inq_frontend_target",
@@ -76,6 +77,8 @@ def load():
         vp = C.c_void_p
         L.inq_genotype_repeats.restype = C.c_int
         L.inq_genotype_repeats.argtypes = [C.POINTER(CallArgsC), C.c_int, C.c_char_p, C.c_size_t]
+        L.inq_combine.restype = C.c_int
+        L.inq_combine.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
         L.inq_frontend_open.restype = C.c_int
         L.inq_frontend_open.argtypes = [C.POINTER(CallArgsC), C.POINTER(vp), C.c_char_p, C.c_size_t]
         L.inq_frontend_n_targets.restype = C.c_uint64
@@ -132,6 +135,18 @@ def genotype_repeats(bamp: str, region: Optional[str], region_file: Optional[str
     out.flush()
     fd = out.fileno()
     rc = L.inq_genotype_repeats(C.byref(a), fd, err, len(err))
+    if rc != 0:
+        raise CallError(rc, err.value.decode(errors="replace"))
+
+
+def combine(calls, out=None) -> None:
+    """src/combine.rs:27-59: paste the H1/H2 columns of several .inq files next to the first one's rows."""
+    L = load()
+    out = sys.stdout if out is None else out
+    out.flush()
+    arr = (C.c_char_p * len(calls))(*[os.fspath(c).encode() for c in calls])
+    err = C.create_string_buffer(2048)
+    rc = L.inq_combine(arr, len(calls), out.fileno(), err, len(err))
     if rc != 0:
         raise CallError(rc, err.value.decode(errors="replace"))
 

@@ -24,12 +24,22 @@ static void usage(FILE *f) {
 }
 
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::strcmp(argv[1], "combine") == 0) {  // src/main.rs:65-71: one or more .inq files
+        if (argc < 3) {
+            std::fputs("error: the following required arguments were not provided:\n  <CALLS>...\n\nUsage: inquistr combine <CALLS>...\n", stderr);
+            return 2;
+        }
+        char err[1024] = {0};
+        int rc = inq_combine(argv + 2, (size_t)(argc - 2), 1, err, sizeof err);
+        if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
+        return rc;
+    }
     if (argc < 2 || std::strcmp(argv[1], "call") != 0) {
         if (argc >= 2 && (!std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help"))) {
             std::puts("Tool to genotype STRs from long reads (MI355X build: `call` only)\n\nUsage: inquistr call [OPTIONS] <BAM>");
             return 0;
         }
-        std::fputs("error: this build provides the `call` subcommand only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
+        std::fputs("error: this build provides the `call` and `combine` subcommands only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
         return 2;
     }
     if (argc == 2) {  // arg_required_else_help
