@@ -1,0 +1,155 @@
+"""`inquiSTR call` over several GPUs of one node: one process per GPU (torch.distributed; backend
+`nccl` = RCCL on the GPUs, `gloo` for CPU rehearsal), loci partitioned by rank, no data-path
+collective; the only exchange is the gather of the per-shard rows to rank 0, which writes the `.inq`.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m inquistr_amd.call_dist sample.bam -R loci.bed -t 8 > sample.inq
+
+Each rank sweeps the BAM only over its own contiguous slice of the (contig, start)-sorted targets
+with the C++ front end and feeds its own GPU through the C ABI; the reference's counterpart is the
+rayon loop over loci (src/call.rs:115-136), which shares nothing but the output Vec.
+"""
+from __future__ import annotations
+
+import argparse
+import functools
+import os
+import sys
+import tempfile
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import call as hostcall
+from .batch import Batch
+
+
+def _hip_compute(device: int) -> Callable[[Batch], Tuple[np.ndarray, np.ndarray]]:
+    from . import hipcall
+
+    ctx = hipcall.Context(device)
+
+    def run(b: Batch):
+        _, res = ctx.call_batch(b)
+        return res.phase1, res.phase2
+
+    return run
+
+
+def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: Optional[str], minlen: int = 5,
+                                 support: int = 3, threads: int = 1, unphased: bool = False,
+                                 sample_name: Optional[str] = None, out=None, rank: int = 0, world: int = 1,
+                                 device: int = 0, compute: Optional[Callable] = None, group=None) -> None:
+    """Same arguments as call.genotype_repeats plus (rank, world).  Rank 0 writes header + rows."""
+    import torch
+    import torch.distributed as dist
+
+    # every rank parses and validates the full target list exactly like a single-process run would
+    fe_all = hostcall.FrontEnd(bamp, region=region, region_file=region_file, minlen=minlen, support=support,
+                               threads=1, unphased=unphased, sample_name=sample_name)
+    targets = fe_all.targets()
+    sample = fe_all.sample
+    fe_all.close()
+    n = len(targets)
+    # contiguous slices of the position-sorted list (contig order of first appearance keeps slices local)
+    order = sorted(range(n), key=lambda i: (targets[i][0], targets[i][1], i))
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    mine = order[lo:hi]
+    p1 = np.full(len(mine), np.nan)
+    p2 = np.full(len(mine), np.nan)
+    if mine:
+        compute = compute or _hip_compute(device)
+        with tempfile.NamedTemporaryFile("w", suffix=".bed", delete=False) as f:
+            for i in mine:
+                f.write(f"{targets[i][0]}\t{targets[i][1]}\t{targets[i][2]}\n")
+            sub_bed = f.name
+        try:
+            fe = hostcall.FrontEnd(bamp, region_file=sub_bed, minlen=minlen, support=support, threads=threads,
+                                   unphased=unphased, sample_name=sample_name)
+            for batch, idx in fe.batches():
+                a, b = compute(batch)
+                p1[idx], p2[idx] = a, b
+            fe.close()
+        finally:
+            os.unlink(sub_bed)
+    if world > 1:
+        width = max((n * (r + 1) // world) - (n * r // world) for r in range(world))
+        gdev = torch.device("cuda", device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        buf = torch.full((2, max(width, 1)), float("nan"), dtype=torch.float64, device=gdev)
+        buf[0, : len(mine)] = torch.from_numpy(p1)
+        buf[1, : len(mine)] = torch.from_numpy(p2)
+        bufs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, bufs, dst=0, group=group)
+        if rank != 0:
+            return
+        full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
+        for r in range(world):
+            sl = order[n * r // world : n * (r + 1) // world]
+            full1[sl] = bufs[r][0, : len(sl)].cpu().numpy()
+            full2[sl] = bufs[r][1, : len(sl)].cpu().numpy()
+    else:
+        full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
+        full1[mine], full2[mine] = p1, p2
+    # output, src/call.rs:137-157: BED order for -t 1, (human chrom, start) order otherwise
+    L = hostcall.load()
+    import ctypes as C
+
+    rows = list(range(n))
+    if threads > 1:
+        def cmp(x, y):
+            c = L.inq_host_human_compare(targets[x][0].encode(), targets[y][0].encode())
+            return c or (targets[x][1] > targets[y][1]) - (targets[x][1] < targets[y][1])
+
+        rows.sort(key=functools.cmp_to_key(cmp))
+    out = sys.stdout if out is None else out
+    buf = C.create_string_buffer(4096)
+    L.inq_host_format_header(sample.encode(), buf, len(buf))
+    lines = [buf.value.decode()]
+    for i in rows:
+        L.inq_host_format_row(targets[i][0].encode(), targets[i][1], targets[i][2], float(full1[i]), float(full2[i]), buf, len(buf))
+        lines.append(buf.value.decode())
+    out.write("\n".join(lines) + "\n")
+    out.flush()
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    ap = argparse.ArgumentParser(prog="inquistr_amd.call_dist", description="inquiSTR call, one process per GPU")
+    ap.add_argument("bam")
+    ap.add_argument("-r", "--region")
+    ap.add_argument("-R", "--region-file", "--region_file", dest="region_file")
+    ap.add_argument("-m", "--minlen", type=int, default=5)
+    ap.add_argument("-s", "--support", type=int, default=3)
+    ap.add_argument("-t", "--threads", type=int, default=1)
+    ap.add_argument("-u", "--unphased", action="store_true")
+    ap.add_argument("--sample-name", "--sample_name", dest="sample_name")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--same-device", action="store_true", help="all ranks on device 0 (rehearsal on a one-GPU box)")
+    a = ap.parse_args(argv)
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
+    try:
+        genotype_repeats_distributed(a.bam, a.region, a.region_file, a.minlen, a.support, a.threads, a.unphased,
+                                     a.sample_name, rank=rank, world=world, device=device)
+    except hostcall.CallError as e:
+        if rank == 0:
+            print(e.message, file=sys.stderr)
+        return e.status
+    finally:
+        if world > 1 and dist.is_initialized():
+            dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
