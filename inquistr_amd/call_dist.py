@@ -122,6 +122,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("-t", "--threads", type=int, default=1)
     ap.add_argument("-u", "--unphased", action="store_true")
     ap.add_argument("--sample-name", "--sample_name", dest="sample_name")
+    ap.add_argument("-o", "--output", help="write the .inq here instead of stdout (gloo prints connection notes on stdout)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-device", action="store_true", help="all ranks on device 0 (rehearsal on a one-GPU box)")
     a = ap.parse_args(argv)
@@ -138,14 +139,17 @@ def main(argv: Optional[List[str]] = None) -> int:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
+    out = open(a.output, "w") if (a.output and rank == 0) else None
     try:
         genotype_repeats_distributed(a.bam, a.region, a.region_file, a.minlen, a.support, a.threads, a.unphased,
-                                     a.sample_name, rank=rank, world=world, device=device)
+                                     a.sample_name, out=out, rank=rank, world=world, device=device)
     except hostcall.CallError as e:
         if rank == 0:
             print(e.message, file=sys.stderr)
         return e.status
     finally:
+        if out is not None:
+            out.close()
         if world > 1 and dist.is_initialized():
             dist.destroy_process_group()
     return 0
