@@ -121,6 +121,11 @@ def _make_case(tmp_path, seed, n_loci=60, ultra_long=False):
             if r.sa:
                 tags.append(("SA", "Z", r.sa[1]))
             tags.append(("NM", "i", 3))
+            if k % 3 == 0:  # methylation-style tags before/after the ones the path reads: B arrays, Z strings
+                tags.insert(0, ("ML", "B", ("C", [1, 2, 250] * (k % 5))))
+                tags.append(("MM", "Z", "C+m,5,12,0;"))
+                tags.append(("qs", "f", 12.5))
+                tags.append(("ts", "A", "+"))
             r.tid = t
             w.add(f"read{k}", r.flag, t, r.pos, r.mapq, r.cigar, tags, l_seq=rng.choice([0, 0, 7]))
             k += 1
