@@ -97,6 +97,34 @@ __device__ __forceinline__ PairMeta load_pair_meta(const BatchView &b, uint64_t 
     return m;
 }
 
+// The same in two stages, so a wave can fetch the descriptors of its NEXT block of reads while it walks
+// the current one: stage A (pair index) one block ahead of stage B (descriptor), checks at use time.
+__device__ __forceinline__ uint32_t meta_stage_a(const BatchView &b, uint64_t first, int cnt, int lane) {
+    return lane < cnt ? b.pair_read[first + (uint64_t)lane] : 0xffffffffu;
+}
+__device__ __forceinline__ uint4 meta_stage_b(const BatchView &b, uint32_t ri) {
+    // ri comes from a completed stage A; out-of-range indices load nothing and are flagged in stage C
+    return (uint64_t)ri < b.n_reads ? b.reads[ri] : make_uint4(0u, 0xffffffffu, 0u, 0u);
+}
+__device__ __forceinline__ PairMeta meta_stage_c(const BatchView &b, const uint4 r, int cnt, int lane, uint32_t &status,
+                                                  bool &valid) {
+    PairMeta m{0u, 0u, 0u, 0u};
+    valid = false;
+    if (lane < cnt) {
+        const uint64_t n4 = ((uint64_t)r.y + 3u) >> 2;
+        if (r.y < 0x10000000u && (uint64_t)r.x + n4 <= b.n_cigar4) {
+            m.off4 = r.x;
+            m.nc = r.y | ((r.w & (RB_IS_2D << 8)) ? 0x80000000u : 0u);
+            m.pos = r.z;
+            m.misc = r.w;
+            valid = true;
+        } else {
+            status |= ST_INDEX;
+        }
+    }
+    return m;
+}
+
 // ops that consume the reference: M D N = X -> bits 0,2,3,7,8 (src/call.rs:384-392,404)
 constexpr uint32_t kConsume = 0x18Du;
 

@@ -328,26 +328,22 @@ __global__ __launch_bounds__(256) void locus_call_medium(KArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Deep loci.  Scratch layout: sval[p] (i64) and smeta[p] (u8) indexed by global pair number.
 
-constexpr int kBigPairsPerWave = 16;
-constexpr uint32_t kBigLdsCap = 2048;  // per-read results of loci up to this depth stay in LDS
+constexpr int kBigBlock = 64;           // reads one wave walks per block in locus_call_big_walk
 
 struct BigShared {
     unsigned int cnt_kept, ng[3], ns[3];
     unsigned int tie_span, tie_clip;
     long long med[3][2];
     long long split_lo, split_hi;
-    long long lval[kBigLdsCap];
-    unsigned char lmeta[kBigLdsCap];
 };
 
-// Per-read results of one deep locus: in LDS up to kBigLdsCap reads (workgroup barriers suffice), in
-// the ctx's global scratch beyond (needs agent-scope fences between the passes: slow, but any depth).
+// Per-read results of one very deep locus (> kSortCap reads) stay in the ctx's global scratch and are
+// ranked there by counting: O(n^2), with agent-scope fences between the passes.  Any depth, slow.
 struct DeepStore {
     int64_t *val;
     unsigned char *meta;
-    bool global;
     __device__ __forceinline__ void publish() const {
-        if (global) __threadfence();
+        __threadfence();
         __syncthreads();
     }
 };
@@ -410,23 +406,96 @@ __device__ void big_group_median(const DeepStore &S, uint32_t n, int g, uint32_t
     __syncthreads();
 }
 
+// The whole reduce of one locus over the global store (the > kSortCap fallback).
+template <bool UNPHASED>
+__device__ void reduce_deep_global(const KArgs &a, uint64_t j, uint64_t p0, uint32_t n, BigShared &sh) {
+    DeepStore S{(int64_t *)(a.sval + p0), (unsigned char *)(a.smeta + p0)};
+    if (threadIdx.x == 0) {
+        sh.cnt_kept = 0;
+        for (int g = 0; g < 3; ++g) sh.ng[g] = sh.ns[g] = 0;
+        sh.tie_span = sh.tie_clip = 0;
+    }
+    __syncthreads();
+    if (UNPHASED) {  // global rank -> haplotype group (src/call.rs:311-313)
+        uint32_t local = 0;
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) local += (S.meta[e] & PM_KEPT) ? 1u : 0u;
+        if (local) atomicAdd(&sh.cnt_kept, local);
+        __syncthreads();
+        const uint32_t mcount = sh.cnt_kept, ks = mcount / 2u;
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+            uint32_t me = S.meta[e];
+            if (!(me & PM_KEPT)) continue;
+            const int64_t v = S.val[e];
+            uint32_t rank = 0;
+            for (uint32_t jx = 0; jx < n; ++jx)
+                if (S.meta[jx] & PM_KEPT) rank += before(S.val[jx], (int)jx, v, (int)e) ? 1u : 0u;
+            const uint32_t grp = rank < ks ? 1u : 2u;
+            // other threads still read PM_KEPT of this byte while ranks are being counted; the
+            // group bits written here leave PM_KEPT untouched
+            me = (me & ~(3u << PM_GRP_SHIFT)) | (grp << PM_GRP_SHIFT);
+            S.meta[e] = (unsigned char)me;
+            if (ks >= 1u && rank == ks - 1u) sh.split_lo = v;
+            if (rank == ks) sh.split_hi = v;
+        }
+        S.publish();
+        if (ks >= 1u && ks < mcount && sh.split_lo == sh.split_hi) {
+            const int64_t vs = sh.split_lo;
+            for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+                const uint32_t me = S.meta[e];
+                if ((me & PM_KEPT) && S.val[e] == vs) {
+                    if (me & PM_CLIP)
+                        sh.tie_clip = 1u;
+                    else
+                        sh.tie_span = 1u;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        uint32_t c_ng[3] = {0, 0, 0}, c_ns[3] = {0, 0, 0};
+        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+            const uint32_t me = S.meta[e];
+            if (!(me & PM_KEPT)) continue;
+            const uint32_t g = (me >> PM_GRP_SHIFT) & 3u;
+            if (g == 1u || g == 2u) {
+                c_ng[g]++;
+                if (!(me & PM_CLIP)) c_ns[g]++;
+            }
+        }
+        for (int g = 1; g <= 2; ++g) {
+            if (c_ng[g]) atomicAdd(&sh.ng[g], c_ng[g]);
+            if (c_ns[g]) atomicAdd(&sh.ns[g], c_ns[g]);
+        }
+    }
+    __syncthreads();
+    double out1, out2;
+    big_group_median(S, n, 1, a.support, sh, out1);
+    big_group_median(S, n, 2, a.support, sh, out2);
+    if (threadIdx.x == 0) {
+        a.phase1[j] = out1;
+        a.phase2[j] = out2;
+        if (UNPHASED && sh.tie_span && sh.tie_clip) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
+    }
+    __syncthreads();
+}
+
+// ---- loci with more than 256 reads, stage 1: walk -----------------------------------------------
+// One workgroup per listed locus; its four waves take 64-read blocks in turn through the same walker
+// and leave (Call, meta) per read in the ctx's global scratch.  The kernel boundary in front of the
+// reduce kernel makes the scratch visible: no fences.  The descriptors of a wave's next block are
+// fetched while it walks the current one.
 template <bool UNPHASED, int AUX>
-__global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
-    __shared__ BigShared sh;
+__global__ __launch_bounds__(256) void locus_call_big_walk(KArgs a) {
     __shared__ WaveLds lds[4];
+    __shared__ uint32_t cnt[kListShards];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the work list is sharded (blockIdx % kListShards of the producer): many counters instead of one hot word
-    __shared__ uint32_t cnt[kListShards];
     if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[a.parity][1][threadIdx.x].n;
     __syncthreads();
     uint32_t total = 0;
     for (int k = 0; k < kListShards; ++k) total += cnt[k];
-    // the other parity's counters belong to the next deep-locus call on this ctx: clear them here (last
-    // kernel of the sequence), kernel boundaries before locus_call_small of that call increments them
-    if (blockIdx.x == 0 && threadIdx.x < 2 * kListShards)
-        a.status->list_count[a.parity ^ 1u][threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
-
+    BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
     for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
         uint32_t shard = 0, idx = item;
         while (idx >= cnt[shard]) idx -= cnt[shard++];
@@ -440,100 +509,199 @@ __global__ __launch_bounds__(256) void locus_call_big(KArgs a) {
         W.se1 = W.se + 1u;
         W.width = W.ee - W.se1;
         W.minlen = a.minlen;
-        BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
-        DeepStore S;
-        S.global = n > kBigLdsCap;
-        S.val = S.global ? (int64_t *)(a.sval + p0) : (int64_t *)sh.lval;
-        S.meta = S.global ? (unsigned char *)(a.smeta + p0) : sh.lmeta;
         uint32_t status = 0;
-        if (threadIdx.x == 0) {
-            sh.cnt_kept = 0;
-            for (int g = 0; g < 3; ++g) sh.ng[g] = sh.ns[g] = 0;
-            sh.tie_span = sh.tie_clip = 0;
-        }
-        // ---- walk: the 4 waves take blocks of kBigPairsPerWave reads in turn ----
-        const uint32_t nblk = (n + kBigPairsPerWave - 1) / kBigPairsPerWave;
-        for (uint32_t blk = wave; blk < nblk; blk += 4u) {
-            const uint32_t e0 = blk * kBigPairsPerWave;
-            const uint64_t first = p0 + e0;
-            const int cnt_r = (int)min((uint32_t)kBigPairsPerWave, n - e0);
+        const uint32_t nblk = (n + kBigBlock - 1) / kBigBlock;
+        auto blk_cnt = [&](uint32_t blk) { return blk < nblk ? (int)min((uint32_t)kBigBlock, n - blk * kBigBlock) : 0; };
+        // software pipeline over this wave's blocks: A = pair index (2 ahead), B = descriptor (1 ahead)
+        uint32_t blk = wave;
+        uint32_t ri_b = meta_stage_a(b, p0 + (uint64_t)blk * kBigBlock, blk_cnt(blk), lane);
+        uint4 rd = meta_stage_b(b, ri_b);
+        uint32_t ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + 4u) * kBigBlock, blk_cnt(blk + 4u), lane);
+        for (; blk < nblk; blk += 4u) {
+            const int c = blk_cnt(blk);
+            const uint64_t first = p0 + (uint64_t)blk * kBigBlock;
             bool valid;
-            const PairMeta m = load_pair_meta(b, first, cnt_r, lane, status, valid);
+            if (lane < c && (uint64_t)ri_b >= b.n_reads) status |= ST_INDEX;
+            const PairMeta m = meta_stage_c(b, rd, (lane < c && (uint64_t)ri_b < b.n_reads) ? c : 0, lane, status, valid);
+            // next block: descriptor load now (its index arrived during the previous walk), index load for the one after
+            ri_b = ri_next;
+            rd = meta_stage_b(b, ri_b);
+            ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + 8u) * kBigBlock, blk_cnt(blk + 8u), lane);
             int64_t val;
             uint32_t meta;
-            walk_pairs<UNPHASED, AUX>(b, m, valid, cnt_r, W, lane, status, lds[wave], val, meta);
-            if (lane < cnt_r) {
-                S.val[e0 + lane] = val;
-                S.meta[e0 + lane] = (unsigned char)meta;
+            walk_pairs<UNPHASED, AUX>(b, m, valid, c, W, lane, status, lds[wave], val, meta);
+            if (lane < c) {
+                a.sval[first + lane] = val;
+                a.smeta[first + lane] = (uint8_t)meta;
                 if (a.pair_call) a.pair_call[first + lane] = val;
                 if (a.pair_bits) a.pair_bits[first + lane] = (uint8_t)(meta & 7u);
             }
         }
         if (status) atomicOr(&a.status->err, status);
-        S.publish();
+    }
+}
 
-        // ---- unphased: global rank -> haplotype group (src/call.rs:311-313) ----
-        if (UNPHASED) {
-            uint32_t local = 0;
-            for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) local += (S.meta[e] & PM_KEPT) ? 1u : 0u;
-            if (local) atomicAdd(&sh.cnt_kept, local);
-            __syncthreads();
-            const uint32_t mcount = sh.cnt_kept, ks = mcount / 2u;
-            for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-                uint32_t me = S.meta[e];
-                if (!(me & PM_KEPT)) continue;
-                const int64_t v = S.val[e];
-                uint32_t rank = 0;
-                for (uint32_t jx = 0; jx < n; ++jx)
-                    if (S.meta[jx] & PM_KEPT) rank += before(S.val[jx], (int)jx, v, (int)e) ? 1u : 0u;
-                const uint32_t grp = rank < ks ? 1u : 2u;
-                // other threads still read PM_KEPT of this byte while ranks are being counted; the
-                // group bits written here leave PM_KEPT untouched
-                me = (me & ~(3u << PM_GRP_SHIFT)) | (grp << PM_GRP_SHIFT);
-                S.meta[e] = (unsigned char)me;
-                if (ks >= 1u && rank == ks - 1u) sh.split_lo = v;
-                if (rank == ks) sh.split_hi = v;
-            }
-            S.publish();
-            if (ks >= 1u && ks < mcount && sh.split_lo == sh.split_hi) {
-                const int64_t vs = sh.split_lo;
-                for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-                    const uint32_t me = S.meta[e];
-                    if ((me & PM_KEPT) && S.val[e] == vs) {
-                        if (me & PM_CLIP)
-                            sh.tie_clip = 1u;
-                        else
-                            sh.tie_span = 1u;
-                    }
-                }
-            }
-            __syncthreads();
+// ---- stage 2: reduce ------------------------------------------------------------------------------
+// One workgroup per listed locus: the kept Calls become 64-bit keys
+//     [63:62] haplotype group | [61:14] value + 2^47 | [13:1] file-order index | [0] clipped
+// sorted once by a bitonic network in LDS; both haplotype groups are then contiguous ascending ranges
+// and median_str_length's span/clip rule reduces to one prefix count of "spanning" flags.  Two
+// instantiations split the list by depth so that shallow-deep loci keep several workgroups per CU:
+// CAP = 2048 (16 KB of keys) and CAP = 8192 (64 KB); deeper loci, or values beyond 48 bits, take
+// the global rank-counting fallback inside the CAP = 8192 launch.
+constexpr uint64_t kKeyBias = 1ull << 47;
+constexpr uint64_t kKeySent = ~0ull;
+
+template <int CAP>
+struct SortLds {
+    unsigned long long key[CAP];
+    unsigned int seg[256];
+    unsigned int m, c1, tie_span, tie_clip, overflow;
+    long long pick[2];
+};
+
+__device__ __forceinline__ int64_t key_value(uint64_t k) { return (int64_t)((k >> 14) & ((1ull << 48) - 1ull)) - (int64_t)kKeyBias; }
+
+// median_str_length (src/call.rs:497-522) of the sorted range key[lo, hi).  Block-uniform result.
+template <int CAP>
+__device__ double median_of_sorted_range(SortLds<CAP> &L, uint32_t lo, uint32_t hi, uint32_t support) {
+    const uint32_t ng = hi - lo;
+    if (ng < support) return qnan();  // :498-500
+    const uint32_t t = threadIdx.x;
+    const uint32_t seglen = (ng + 255u) / 256u;
+    const uint32_t s0 = min(hi, lo + t * seglen), s1 = min(hi, s0 + seglen);
+    uint32_t spans = 0;
+    for (uint32_t e = s0; e < s1; ++e) spans += (uint32_t)(~L.key[e] & 1ull);
+    L.seg[t] = spans;
+    __syncthreads();
+    uint32_t before_me = 0, ns = 0;
+    for (uint32_t k = 0; k < 256u; ++k) {
+        const uint32_t c = L.seg[k];
+        before_me += k < t ? c : 0u;
+        ns += c;
+    }
+    // chosen = every spanning Call, plus (when there are no more than `support` of them) the largest
+    // support - ns clipped ones (:509-513) = the LAST `take` clips of the ascending range; which of several
+    // equal clipped values is taken does not change the multiset of values
+    const uint32_t nc = ng - ns;
+    const uint32_t take = ns <= support ? support - ns : 0u;  // <= nc because ng >= support
+    const uint32_t first_clip = nc - take;                     // clips with clip-rank >= first_clip are chosen
+    const uint32_t M = ns + take;
+    uint32_t span_before = before_me;
+    for (uint32_t e = s0; e < s1; ++e) {
+        const uint64_t k = L.key[e];
+        const bool clip = (k & 1ull) != 0ull;
+        const uint32_t clip_before = (e - lo) - span_before;
+        const bool chosen = !clip || clip_before >= first_clip;
+        if (chosen) {
+            const uint32_t r = span_before + (clip_before > first_clip ? clip_before - first_clip : 0u);
+            if (r == M / 2u) L.pick[1] = key_value(k);
+            if (!(M & 1u) && r == M / 2u - 1u) L.pick[0] = key_value(k);
         }
-        // ---- group sizes ----
-        {
-            uint32_t c_ng[3] = {0, 0, 0}, c_ns[3] = {0, 0, 0};
-            for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-                const uint32_t me = S.meta[e];
-                if (!(me & PM_KEPT)) continue;
-                const uint32_t g = (me >> PM_GRP_SHIFT) & 3u;
-                if (g == 1u || g == 2u) {
-                    c_ng[g]++;
-                    if (!(me & PM_CLIP)) c_ns[g]++;
-                }
-            }
-            for (int g = 1; g <= 2; ++g) {
-                if (c_ng[g]) atomicAdd(&sh.ng[g], c_ng[g]);
-                if (c_ns[g]) atomicAdd(&sh.ns[g], c_ns[g]);
+        span_before += clip ? 0u : 1u;
+    }
+    __syncthreads();
+    const double out = (M & 1u) ? (double)L.pick[1] : (double)(L.pick[0] + L.pick[1]) / 2.0;  // :515-520
+    __syncthreads();
+    return out;
+}
+
+template <bool UNPHASED, int CAP, bool LAST>
+__global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
+    __shared__ SortLds<CAP> L;
+    __shared__ BigShared sh;  // for the global fallback
+    __shared__ uint32_t cnt[kListShards];
+    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[a.parity][1][threadIdx.x].n;
+    __syncthreads();
+    uint32_t total = 0;
+    for (int k = 0; k < kListShards; ++k) total += cnt[k];
+    // the other parity's counters belong to the next deep-locus call on this ctx: clear them in the last
+    // kernel of the sequence, kernel boundaries before locus_call_small of that call increments them
+    if (LAST && blockIdx.x == 0 && threadIdx.x < 2 * kListShards)
+        a.status->list_count[a.parity ^ 1u][threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
+
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+        uint32_t shard = 0, idx = item;
+        while (idx >= cnt[shard]) idx -= cnt[shard++];
+        const uint64_t j = a.worklist[((uint64_t)kListShards + shard) * a.shard_cap + idx];
+        const uint64_t p0 = a.locus_pair_off[j];
+        const uint32_t n = (uint32_t)(a.locus_pair_off[j + 1] - p0);
+        // depth classes: this launch takes (CAP/4, CAP] reads (the CAP = 2048 launch everything up to 2048);
+        // the CAP = 8192 launch also takes what no sort can hold
+        if (CAP == 2048 ? n > 2048u : n <= 2048u) continue;
+        if (n > (uint32_t)CAP) {
+            reduce_deep_global<UNPHASED>(a, j, p0, n, sh);
+            continue;
+        }
+        if (threadIdx.x == 0) L.m = L.c1 = L.tie_span = L.tie_clip = L.overflow = 0u;
+        __syncthreads();
+        // keys of the elements that belong to a haplotype group (slot order is fixed by the sort that follows)
+        for (uint32_t e = threadIdx.x; e < n; e += 256u) {
+            const uint32_t me = a.smeta[p0 + e];
+            const uint32_t g = (me >> PM_GRP_SHIFT) & 3u;
+            const bool in = UNPHASED ? (me & PM_KEPT) != 0u : ((me & PM_KEPT) && (g == 1u || g == 2u));
+            if (in) {
+                const int64_t v = a.sval[p0 + e];
+                if (v < -(int64_t)kKeyBias || v >= (int64_t)kKeyBias) L.overflow = 1u;
+                const uint64_t key = ((uint64_t)(UNPHASED ? 0u : g) << 62) | (((uint64_t)(v + (int64_t)kKeyBias) & ((1ull << 48) - 1ull)) << 14) |
+                                     ((uint64_t)e << 1) | ((me & PM_CLIP) ? 1ull : 0ull);
+                L.key[atomicAdd(&L.m, 1u)] = key;
+                if (!UNPHASED && g == 1u) atomicAdd(&L.c1, 1u);
             }
         }
         __syncthreads();
-        double out1, out2;
-        big_group_median(S, n, 1, a.support, sh, out1);
-        big_group_median(S, n, 2, a.support, sh, out2);
+        if (L.overflow) {  // a Call beyond 48 bits: not representable in the key
+            reduce_deep_global<UNPHASED>(a, j, p0, n, sh);
+            continue;
+        }
+        const uint32_t m = L.m;
+        uint32_t N = 1;
+        while (N < m) N <<= 1;
+        for (uint32_t e = m + threadIdx.x; e < N; e += 256u) L.key[e] = kKeySent;
+        __syncthreads();
+        for (uint32_t k = 2; k <= N; k <<= 1) {
+            for (uint32_t s = k >> 1; s > 0; s >>= 1) {
+                for (uint32_t i = threadIdx.x; i < N; i += 256u) {
+                    const uint32_t l = i ^ s;
+                    if (l > i) {
+                        const uint64_t x = L.key[i], y = L.key[l];
+                        if ((y < x) == ((i & k) == 0u)) {
+                            L.key[i] = y;
+                            L.key[l] = x;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        uint32_t lo1, hi1, lo2, hi2;
+        if (UNPHASED) {  // src/call.rs:311-313: h1 = lower n/2 of the sorted calls, h2 = the rest
+            const uint32_t ks = m / 2u;
+            lo1 = 0, hi1 = ks, lo2 = ks, hi2 = m;
+            if (ks >= 1u && ks < m) {
+                const uint64_t va = L.key[ks - 1u] >> 14, vb = L.key[ks] >> 14;  // group bits are 0 here
+                if (va == vb) {
+                    for (uint32_t e = threadIdx.x; e < m; e += 256u) {
+                        const uint64_t k2 = L.key[e];
+                        if ((k2 >> 14) == va) {
+                            if (k2 & 1ull)
+                                L.tie_clip = 1u;
+                            else
+                                L.tie_span = 1u;
+                        }
+                    }
+                }
+            }
+        } else {
+            lo1 = 0, hi1 = L.c1, lo2 = L.c1, hi2 = m;
+        }
+        __syncthreads();
+        const double out1 = median_of_sorted_range<CAP>(L, lo1, hi1, a.support);
+        const double out2 = median_of_sorted_range<CAP>(L, lo2, hi2, a.support);
         if (threadIdx.x == 0) {
             a.phase1[j] = out1;
             a.phase2[j] = out2;
-            if (UNPHASED && sh.tie_span && sh.tie_clip) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
+            if (UNPHASED && L.tie_span && L.tie_clip) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
         }
         __syncthreads();
     }
@@ -547,7 +715,9 @@ static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, 
     if (ev_mid) (void)hipEventRecord(ev_mid, s);
     if (a.only_small) return;  // no locus can be on a work list
     hipLaunchKernelGGL((locus_call_medium<UNPHASED, AUX>), dim3(grid_medium), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((locus_call_big<UNPHASED, AUX>), dim3(grid_big), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((locus_call_big_walk<UNPHASED, AUX>), dim3(grid_big), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048, false>), dim3(grid_big), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 8192, true>), dim3(grid_big), dim3(256), 0, s, a);
 }
 
 void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,

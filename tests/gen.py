@@ -108,6 +108,8 @@ def random_case(seed: int, n_loci: int = 40, unphased: bool = False, minlen: int
         end = start + rng.randint(0, 250)
         cursor = end + rng.randint(30, 1500)
         n = rng.choice([0, 1, 2, 3, 5, 6, 7, 12, 20, max_reads])
+        if j == 1 and max_reads > 40:
+            n = max_reads  # deep-locus tests need the depth they ask for
         recs = random_locus_reads(rng, start, end, n, long_every)
         idx = []
         merged: List[py.Record] = []

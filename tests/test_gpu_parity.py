@@ -107,11 +107,11 @@ def test_random_vs_oracle(ctx, orc, seed, unphased):
 
 
 @pytest.mark.parametrize("unphased", [False, True])
-@pytest.mark.parametrize("max_reads", [64, 65, 130, 700, 2048, 2300])
+@pytest.mark.parametrize("max_reads", [64, 65, 130, 256, 257, 700, 2300, 8192, 8300])
 def test_deep_loci(ctx, orc, unphased, max_reads):
     """Loci with more than 64 offered reads take the work-list kernel."""
-    # up to 2048 reads the per-read results stay in LDS, beyond they go through the global scratch
-    batch, _ = gen.random_case(1000 + max_reads, n_loci=24 if max_reads < 2000 else 8, unphased=unphased,
+    # <= 64: wave per locus; <= 256: four reads per lane; <= 8192: walk kernel + LDS sort; beyond: global ranks
+    batch, _ = gen.random_case(1000 + max_reads, n_loci=24 if max_reads < 2000 else 6, unphased=unphased,
                                max_reads=max_reads, long_every=9, support=3)
     assert int(np.diff(batch.locus_pair_off.astype(np.int64)).max()) >= max_reads
     rc, got = ctx.call_batch(batch, debug=True)
