@@ -93,7 +93,7 @@ def test_kat_call_from_cigar(ctx, kat):
             assert bool(got.pair_bits[j] & B.INQ_PAIR_CLIP) == (kind == "Clip"), v["name"]
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(48))
 @pytest.mark.parametrize("unphased", [False, True])
 def test_random_vs_oracle(ctx, orc, seed, unphased):
     support = [3, 1, 2, 5][seed % 4]
@@ -179,6 +179,36 @@ def test_huge_values(ctx, orc, unphased):
     assert rc == oc == 0
     assert np.abs(want.pair_call).max() > (1 << 32)
     _assert_same(got, want, f"huge unphased={unphased}")
+
+
+@pytest.mark.parametrize("unphased", [False, True])
+def test_wide_windows_fill_the_lane_queue(ctx, orc, unphased):
+    """Loci tens of kb wide with reads made of thousands of short ops: nearly every lane of every chunk
+    starts inside the window, so the LDS window-lane queue drains many times per read (and in the middle
+    of multi-chunk reads), with soft clips and accidental-2D reads mixed in."""
+    import random
+
+    rng = random.Random(21)
+    bb = B.BatchBuilder(minlen=2, support=2, unphased=unphased)
+    for j in range(12):
+        start = 100_000 + 200_000 * j
+        end = start + rng.choice([300, 5_000, 40_000])
+        idx = []
+        for k in range(rng.choice([3, 8, 20, 70])):
+            ops = []
+            for _ in range(rng.choice([40, 300, 1200, 3000])):
+                ops.append(("M", rng.randint(1, 30)))
+                ops.append((rng.choice("IIDDS"), rng.choice([1, 2, 3, 4, 9])))
+            span = sum(l for o, l in ops if o in "MD")
+            pos = start - 10 - rng.randint(0, max(1, span // 3))
+            idx.append(bb.add_read(pos, B.encode_cigar(ops), phase=1 + (k & 1), is_2d=(k % 5 == 0), mapq=rng.choice([9, 60, 60])))
+        bb.add_locus(start, end, idx)
+    batch = bb.build()
+    rc, got = ctx.call_batch(batch, debug=True)
+    oc, want = orc.call_batch(batch, debug=True)
+    assert rc == oc == 0
+    assert (np.abs(want.pair_call) > 100).sum() > 10
+    _assert_same(got, want, f"wide unphased={unphased}")
 
 
 def test_empty_and_ragged(ctx, orc):
