@@ -206,10 +206,10 @@ int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, v
     a.shard_cap = shard_cap;
     const uint32_t hint = c->call_hint ? c->call_hint : c->max_reads_hint;
     c->call_hint = 0;
-    a.only_small = (hint > 0 && hint <= 64) ? 1u : 0u;
+    a.max_reads_hint = hint;
     // the last deep-locus kernel of a sequence clears the OTHER parity's counters; a sequence without the
     // deep kernels appends nothing and must leave the parity alone
-    if (!a.only_small) c->parity ^= 1u;
+    if (!(hint > 0 && hint <= 64)) c->parity ^= 1u;
 
     // CIGAR words of a read referenced by one locus only are read exactly once: stream them past the
     // caches (nt).  Reads shared by neighbouring loci keep the default policy so the second locus hits L2.

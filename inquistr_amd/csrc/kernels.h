@@ -41,7 +41,7 @@ struct KArgs {
     uint32_t parity;
     uint32_t blocks_per_xcd;  // grid_small / 8
     uint32_t shard_cap;       // loci one shard can list: every locus whose block has blockIdx % kListShards == shard
-    uint32_t only_small;      // caller's promise: no locus has more than 64 offered reads
+    uint32_t max_reads_hint;  // caller's promise (0 = none): no locus is offered more reads than this
 };
 
 void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,

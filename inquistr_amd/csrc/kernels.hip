@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
     if (p1 < p0 || p1 > a.n_pairs) status |= ST_INDEX;
     if (start < 10u || end < start) status |= ST_LOCUS;  // src/call.rs:285 (u32 underflow), repeats.rs:102
     const uint64_t n64 = p1 - p0;
-    if (!status && n64 > 64ull && a.only_small) status |= ST_HINT;  // the caller promised <= 64 reads per locus
+    if (!status && a.max_reads_hint && n64 > a.max_reads_hint) status |= ST_HINT;  // the caller's promise is broken
     if (status) {
         if (lane == 0) {
             atomicOr(&a.status->err, status);
@@ -707,17 +707,33 @@ __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
     }
 }
 
+__global__ void clear_other_parity(KArgs a) {
+    if (threadIdx.x < 2 * kListShards)
+        a.status->list_count[a.parity ^ 1u][threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
+}
+
 // ---- launchers (called from capi.hip) ----
 template <bool UNPHASED, int AUX>
 static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, uint32_t grid_big, hipStream_t s,
                      hipEvent_t ev_mid) {
     if (grid_small) hipLaunchKernelGGL((locus_call_small<UNPHASED, AUX>), dim3(grid_small), dim3(256), 0, s, a);
     if (ev_mid) (void)hipEventRecord(ev_mid, s);
-    if (a.only_small) return;  // no locus can be on a work list
+    // launches a promised depth makes pointless are skipped (a broken promise is flagged by locus_call_small)
+    const uint32_t h = a.max_reads_hint;
+    if (h && h <= 64u) return;  // no locus can be on a work list
     hipLaunchKernelGGL((locus_call_medium<UNPHASED, AUX>), dim3(grid_medium), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((locus_call_big_walk<UNPHASED, AUX>), dim3(grid_big), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048, false>), dim3(grid_big), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 8192, true>), dim3(grid_big), dim3(256), 0, s, a);
+    if (!(h && h <= 64u * kMediumSlots)) {
+        hipLaunchKernelGGL((locus_call_big_walk<UNPHASED, AUX>), dim3(grid_big), dim3(256), 0, s, a);
+        if (!(h && h <= 2048u)) {
+            hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048, false>), dim3(grid_big), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 8192, true>), dim3(grid_big), dim3(256), 0, s, a);
+            return;
+        }
+        hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048, true>), dim3(grid_big), dim3(256), 0, s, a);
+        return;
+    }
+    // medium is the last kernel of this sequence: it has to clear the other parity's list counters
+    hipLaunchKernelGGL((clear_other_parity), dim3(1), dim3(64), 0, s, a);
 }
 
 void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,

@@ -41,28 +41,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t x) {
     return x;
 }
 
-// Sum of a signed 64-bit value over the wave; result is wave-uniform (held in SGPRs).
-__device__ __forceinline__ int64_t wave_reduce_add_i64(int64_t v) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
-#define INQ_STEP64(MOVLO, MOVHI)                                     \
-    {                                                                \
-        uint64_t o = ((uint64_t)(MOVHI) << 32) | (uint64_t)(MOVLO);  \
-        uint64_t s = (((uint64_t)hi << 32) | lo) + o;                \
-        lo = (uint32_t)s;                                            \
-        hi = (uint32_t)(s >> 32);                                    \
-    }
-    INQ_STEP64(dpp_shr_zero<DPP_ROW_SHR1>(lo), dpp_shr_zero<DPP_ROW_SHR1>(hi));
-    INQ_STEP64(dpp_shr_zero<DPP_ROW_SHR2>(lo), dpp_shr_zero<DPP_ROW_SHR2>(hi));
-    INQ_STEP64(dpp_shr_zero<DPP_ROW_SHR4>(lo), dpp_shr_zero<DPP_ROW_SHR4>(hi));
-    INQ_STEP64(dpp_shr_zero<DPP_ROW_SHR8>(lo), dpp_shr_zero<DPP_ROW_SHR8>(hi));
-    INQ_STEP64((dpp_bcast<DPP_ROW_BCAST15, 0xa>(lo)), (dpp_bcast<DPP_ROW_BCAST15, 0xa>(hi)));
-    INQ_STEP64((dpp_bcast<DPP_ROW_BCAST31, 0xc>(lo)), (dpp_bcast<DPP_ROW_BCAST31, 0xc>(hi)));
-#undef INQ_STEP64
-    uint32_t tlo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
-    uint32_t thi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
-    return (int64_t)(((uint64_t)thi << 32) | tlo);
-}
-
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }

@@ -48,6 +48,9 @@ WORKLOADS: Dict[str, Workload] = {
     "unphased100k": Workload("unphased100k", 100_000, unphased=True, seed=2),
     "shard500k": Workload("shard500k", 500_000, unphased=True, seed=3),
     "expansion50k": Workload("expansion50k", 50_000, heavy_pct=10, clip_pct=5, seed=4),
+    # not a BASELINE config: every read ONT-like (~2000-2400 ops, 8-10 chunks per read) — exercises the
+    # chunk pipeline inside long reads rather than across short ones
+    "longreads20k": Workload("longreads20k", 20_000, heavy_pct=100, seed=5),
 }
 
 

@@ -395,10 +395,25 @@ def test_max_reads_hint(ctx):
         ctx.set_option("max_reads_hint", 64)
         ctx.call_batch_device(d.c_batch, d.c_result, st)
         assert ctx.status()[0] == B.INQ_ERR_ARG
-        ctx.set_option("max_reads_hint", 70)
-        d.phase1.fill_(7.0)
-        ctx.call_batch_device(d.c_batch, d.c_result, st)
-        assert ctx.status()[0] == 0 and gen.same_f64(d.phase1.cpu().numpy(), want)
+        for hint in (70, 256, 300, 2048, 5000, 70):  # every launch-skipping level, twice through the parities
+            ctx.set_option("max_reads_hint", hint)
+            d.phase1.fill_(7.0)
+            ctx.call_batch_device(d.c_batch, d.c_result, st)
+            assert ctx.status()[0] == 0 and gen.same_f64(d.phase1.cpu().numpy(), want), hint
+        deep = synth.DeviceBatch(synth.Workload("p300", 200, reads_per_locus=300, seed=4), dev, 0, 200)
+        ctx.set_option("max_reads_hint", 0)
+        ctx.call_batch_device(deep.c_batch, deep.c_result, st)
+        assert ctx.status()[0] == 0
+        want_deep = deep.phase1.cpu().numpy().copy()
+        for hint in (300, 2048, 2049, 256):
+            ctx.set_option("max_reads_hint", hint)
+            deep.phase1.fill_(7.0)
+            ctx.call_batch_device(deep.c_batch, deep.c_result, st)
+            rc = ctx.status()[0]
+            if hint < 300:
+                assert rc == B.INQ_ERR_ARG
+            else:
+                assert rc == 0 and gen.same_f64(deep.phase1.cpu().numpy(), want_deep), hint
     finally:
         ctx.set_option("max_reads_hint", 0)
 
