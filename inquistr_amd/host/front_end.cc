@@ -55,7 +55,7 @@ FrontEnd::FrontEnd(BamFile &bam, const std::vector<RepeatInterval> &targets, boo
 
 bool FrontEnd::begin_group(std::string *err) {
     Group &G = groups_[g_];
-    pairs_.assign(G.loci.size(), {});
+    edges_.clear();
     cig_.clear();
     reads_.clear();
     lo_ = 0;
@@ -74,7 +74,7 @@ bool FrontEnd::begin_group(std::string *err) {
     return bam_.seek(vo, err);
 }
 
-int FrontEnd::add_read(const BamRec &r, std::string *err, bool *panic) {
+int FrontEnd::add_read(const BamRec &r, bool has_clip, std::string *err, bool *panic) {
     // get_phase(): any aux type but U8 ('C') / I32 ('i') panics, for every record fetch() yields in
     // phased mode (src/call.rs:349, 482-491)
     uint8_t bits = 0, phase = 0;
@@ -91,8 +91,6 @@ int FrontEnd::add_read(const BamRec &r, std::string *err, bool *panic) {
         }
     }
     // is_accidental_2d is only reached from a soft-clip op (src/call.rs:394)
-    bool has_clip = false;
-    for (uint32_t i = 0; i < r.n_cigar && !has_clip; ++i) has_clip = (r.cigar[i] & 0xf) == 4;
     if (has_clip && r.sa_type) {
         std::string pm;
         int v = is_accidental_2d(r, &pm);
@@ -120,23 +118,44 @@ int FrontEnd::add_read(const BamRec &r, std::string *err, bool *panic) {
 void FrontEnd::emit(size_t from, size_t to, HostBatch &out) {
     const Group &G = groups_[g_];
     out.clear();
-    // reads referenced by loci [from, to), renumbered in first-use order
-    std::vector<uint32_t> remap(reads_.size(), 0xffffffffu);
-    out.locus_pair_off.push_back(0);
-    for (size_t j = from; j < to; ++j) {
-        for (uint32_t ri : pairs_[j]) {
-            if (remap[ri] == 0xffffffffu) {
-                remap[ri] = (uint32_t)out.reads.size();
-                inq_read_t rd = reads_[ri];
+    const size_t nl = to - from;
+    // stable counting sort of the edges of loci [from, to) by locus: file order inside a locus is kept
+    bucket_.assign(nl + 1, 0);
+    size_t n_out = 0;
+    for (const Edge &e : edges_)
+        if (e.locus >= from && e.locus < to) {
+            ++bucket_[e.locus - from + 1];
+            ++n_out;
+        }
+    for (size_t j = 0; j < nl; ++j) bucket_[j + 1] += bucket_[j];
+    out.locus_pair_off.assign(bucket_.begin(), bucket_.end());
+    out.pair_read.resize(n_out);
+    const bool whole = n_out == edges_.size();  // nothing stays behind: the store becomes the batch as it is
+    std::vector<uint32_t> remap;
+    if (whole) {
+        for (const Edge &e : edges_) out.pair_read[bucket_[e.locus - from]++] = e.read;
+        out.cigar.swap(cig_);
+        out.reads.swap(reads_);
+        cig_.clear();
+        reads_.clear();
+        edges_.clear();
+    } else {
+        remap.assign(reads_.size(), 0xffffffffu);
+        for (const Edge &e : edges_) {
+            if (e.locus < from || e.locus >= to) continue;
+            if (remap[e.read] == 0xffffffffu) {
+                remap[e.read] = (uint32_t)out.reads.size();
+                inq_read_t rd = reads_[e.read];
                 const uint32_t *src = cig_.data() + (size_t)rd.cigar_off4 * 4;
                 rd.cigar_off4 = (uint32_t)(out.cigar.size() / 4);
-                size_t n4 = ((size_t)rd.n_cigar + 3) / 4 * 4;
+                const size_t n4 = ((size_t)rd.n_cigar + 3) / 4 * 4;
                 out.cigar.insert(out.cigar.end(), src, src + n4);
                 out.reads.push_back(rd);
             }
-            out.pair_read.push_back(remap[ri]);
+            out.pair_read[bucket_[e.locus - from]++] = remap[e.read];
         }
-        out.locus_pair_off.push_back(out.pair_read.size());
+    }
+    for (size_t j = from; j < to; ++j) {
         out.locus_start.push_back(G.loci[j].start);
         out.locus_end.push_back(G.loci[j].end);
         out.locus_index.push_back(G.loci[j].index);
@@ -144,25 +163,27 @@ void FrontEnd::emit(size_t from, size_t to, HostBatch &out) {
 }
 
 void FrontEnd::compact(size_t keep_from) {
-    // drop reads no open locus references
+    // drop the edges of emitted loci and the reads no open locus references
     std::vector<uint32_t> remap(reads_.size(), 0xffffffffu);
     std::vector<uint32_t> ncig;
     std::vector<inq_read_t> nreads;
-    for (size_t j = keep_from; j < pairs_.size(); ++j) {
-        for (uint32_t &ri : pairs_[j]) {
-            if (remap[ri] == 0xffffffffu) {
-                remap[ri] = (uint32_t)nreads.size();
-                inq_read_t rd = reads_[ri];
-                const uint32_t *src = cig_.data() + (size_t)rd.cigar_off4 * 4;
-                rd.cigar_off4 = (uint32_t)(ncig.size() / 4);
-                size_t n4 = ((size_t)rd.n_cigar + 3) / 4 * 4;
-                ncig.insert(ncig.end(), src, src + n4);
-                nreads.push_back(rd);
-            }
-            ri = remap[ri];
+    size_t w = 0;
+    for (const Edge &e0 : edges_) {
+        if (e0.locus < keep_from) continue;
+        Edge e = e0;
+        if (remap[e.read] == 0xffffffffu) {
+            remap[e.read] = (uint32_t)nreads.size();
+            inq_read_t rd = reads_[e.read];
+            const uint32_t *src = cig_.data() + (size_t)rd.cigar_off4 * 4;
+            rd.cigar_off4 = (uint32_t)(ncig.size() / 4);
+            const size_t n4 = ((size_t)rd.n_cigar + 3) / 4 * 4;
+            ncig.insert(ncig.end(), src, src + n4);
+            nreads.push_back(rd);
         }
+        e.read = remap[e.read];
+        edges_[w++] = e;
     }
-    for (size_t j = 0; j < keep_from; ++j) std::vector<uint32_t>().swap(pairs_[j]);
+    edges_.resize(w);
     cig_.swap(ncig);
     reads_.swap(nreads);
 }
@@ -205,15 +226,24 @@ int FrontEnd::next(HostBatch &out, std::string *err, bool *panic) {
                     continue;
                 }
             }
-            const int64_t endpos = bam_endpos(rec);
+            // one pass over the CIGAR: reference span ([3P] bam_endpos) and "has a soft clip"
+            int64_t rlen = 0;
+            bool has_clip = false;
+            for (uint32_t i = 0; i < rec.n_cigar; ++i) {
+                const uint32_t op = rec.cigar[i] & 0xf;
+                if ((0x18Du >> op) & 1u) rlen += rec.cigar[i] >> 4;
+                has_clip |= op == 4u;
+            }
+            if ((rec.flag & 0x4) || rlen == 0) rlen = 1;
+            const int64_t endpos = pos + rlen;
             int ridx = -1;
             for (size_t j = lo_; j < m && (int64_t)G.loci[j].start_ext < endpos; ++j) {
                 if ((int64_t)G.loci[j].end_ext > pos) {  // [3P] htslib: pos < end && endpos > beg
                     if (ridx < 0) {
-                        ridx = add_read(rec, err, panic);
+                        ridx = add_read(rec, has_clip, err, panic);
                         if (ridx < 0) return -1;
                     }
-                    pairs_[j].push_back((uint32_t)ridx);
+                    edges_.push_back({(uint32_t)j, (uint32_t)ridx});
                 }
             }
             if (cig_.size() > max_words_ && lo_ > flushed_) {

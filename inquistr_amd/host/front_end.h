@@ -44,7 +44,7 @@ private:
         std::vector<Locus> loci;
     };
     bool begin_group(std::string *err);
-    int add_read(const BamRec &r, std::string *err, bool *panic);
+    int add_read(const BamRec &r, bool has_clip, std::string *err, bool *panic);
     void emit(size_t from, size_t to, HostBatch &out);
     void compact(size_t keep_from);
 
@@ -59,7 +59,12 @@ private:
     // contig-local store
     std::vector<uint32_t> cig_;
     std::vector<inq_read_t> reads_;
-    std::vector<std::vector<uint32_t>> pairs_;  // per locus of the group
+    // (locus of the group, read of the store) in file order; grouped by locus (stable) when a batch is emitted
+    struct Edge {
+        uint32_t locus, read;
+    };
+    std::vector<Edge> edges_;
+    std::vector<uint64_t> bucket_;  // scratch of emit()
 };
 
 }  // namespace inqhost
