@@ -133,6 +133,20 @@ def main():
 
     results = [result_for(b) for b in outs]
     pending = []
+    # gather-to-rank-0 is what the path needs; if this torch/RCCL build lacks NCCL gather (the error is a
+    # backend capability error, raised on every rank before any traffic) fall back to all_gather
+    use_all_gather = False
+    all_bufs = None
+    if world > 1 and args.backend == "nccl":
+        try:
+            probe = torch.zeros(4, device=dev)
+            dist.gather(probe, [torch.zeros(4, device=dev) for _ in range(world)] if rank == 0 else None, dst=0)
+        except Exception as e:  # noqa: BLE001
+            use_all_gather = True
+            if rank == 0:
+                print(f"[bench] NCCL gather unavailable ({type(e).__name__}); using all_gather_into_tensor", file=sys.stderr)
+        if use_all_gather:
+            all_bufs = [torch.empty(world, 2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]
 
     def step(i):
         k = i & 1
@@ -145,7 +159,9 @@ def main():
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
                 glist = list(gathered[k].unbind(0)) if rank == 0 else None
-                if args.backend == "nccl":
+                if args.backend == "nccl" and use_all_gather:
+                    pending.append(dist.all_gather_into_tensor(all_bufs[k], outs[k], async_op=True))
+                elif args.backend == "nccl":
                     pending.append(dist.gather(outs[k], glist, dst=0, async_op=True))
                 else:  # rehearsal: stage through pinned host memory, gather on gloo
                     stage[k].copy_(outs[k], non_blocking=True)
@@ -192,8 +208,9 @@ def main():
     if rank == 0 and world > 1:
         # the last gathered buffer must hold rank 0's own rows in slot 0
         last = (args.steps - 1) & 1
-        own = outs[last].to(gathered[last].device)
-        g0 = gathered[last][0]
+        src = all_bufs[last] if use_all_gather else gathered[last]
+        own = outs[last].to(src.device)
+        g0 = src[0]
         if not bool(((own == g0) | (own.isnan() & g0.isnan())).all()):
             raise SystemExit("gathered rows differ from the local result")
     if rank == 0:
