@@ -65,6 +65,56 @@ def cpu_baseline(wl, sample_loci: int):
     }
 
 
+def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str = ""):
+    """L2: BAM + BED -> .inq.  The product CLI (C++ sweep front end + HIP kernels) next to this bench's CPU
+    baseline leg at that level: oracle/ref_shaped_call, the reference's control flow (BASELINE.md §3 modes
+    A / B / C) around the oracle — a CPU restatement, not the Rust binary.  Outputs are compared byte for
+    byte.  Returns one JSON-able dict."""
+    import subprocess
+    import tempfile
+
+    from inquistr_amd import synth
+    from tools import make_synth_bam
+
+    wl = synth.WORKLOADS[workload]
+    tmp = keep or tempfile.mkdtemp(prefix="inq_l2_")
+    prefix = os.path.join(tmp, f"{workload}_{loci}")
+    t0 = time.time()
+    if not os.path.exists(prefix + ".bam"):
+        make_synth_bam.write(workload, loci, prefix)
+    gen_s = time.time() - t0
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
+    cli = os.path.join(ROOT, "inquistr_amd", "lib", "inquistr")
+    ref = os.path.join(ROOT, "oracle", "ref_shaped_call")
+    un = ["-u"] if wl.unphased else []
+
+    def timed(cmd, n):
+        best, out = None, None
+        for _ in range(n):
+            t = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True)
+            dt = time.perf_counter() - t
+            if r.returncode != 0:
+                raise SystemExit(f"{cmd} failed: {r.stderr.decode()[-500:]}")
+            best = dt if best is None else min(best, dt)
+            out = r.stdout
+        return best, out
+
+    res = {}
+    t_gpu, out_gpu = timed([cli, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", str(threads), "--sample-name", "S"] + un, reps + 1)
+    res["gpu_cli"] = {"seconds": t_gpu, "loci_per_s": loci / t_gpu, "threads": threads}
+    for mode, thr in (("C", 1), ("B", threads), ("A", threads)):
+        t, out = timed([ref, prefix + ".bam", prefix + ".bed", mode, str(thr), str(int(wl.unphased)), str(wl.minlen),
+                        str(wl.support), "S"], 1 if mode == "A" else reps)
+        same = sorted(out.splitlines()) == sorted(out_gpu.splitlines()) if mode == "C" else out == out_gpu
+        res[f"cpu_{mode}"] = {"seconds": t, "loci_per_s": loci / t, "threads": thr, "inq_identical": bool(same)}
+    return {"level": "L2 end-to-end BAM+BED -> .inq", "workload": workload, "loci": loci,
+            "bam_mb": os.path.getsize(prefix + ".bam") / 1e6, "bam_gen_s": gen_s, **res,
+            "speedup_vs_A": res["cpu_A"]["seconds"] / t_gpu, "speedup_vs_B": res["cpu_B"]["seconds"] / t_gpu,
+            "speedup_vs_C": res["cpu_C"]["seconds"] / t_gpu,
+            "note": "CPU modes = oracle/ref_shaped_call: CPU restatement of the reference's control flow, not the Rust binary"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,7 +128,14 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 control flow on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--l2", action="store_true", help="measure L2 (BAM+BED -> .inq, CLI vs CPU baseline modes) instead of L0")
+    ap.add_argument("--l2-loci", type=int, default=20_000)
+    ap.add_argument("--l2-threads", type=int, default=0)
+    ap.add_argument("--l2-keep", default="", help="directory to keep / reuse the generated BAM in")
     args = ap.parse_args()
+    if args.l2:
+        print(json.dumps(l2_end_to_end(args.workload, args.l2_loci, args.l2_threads or host_threads(), 2, args.l2_keep)), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
