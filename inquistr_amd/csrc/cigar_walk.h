@@ -192,7 +192,6 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
     uint32_t qcount = 0;
     uint32_t lane_range = 0, lane_bad = 0;
     uint32_t end_carry = 0;  // lane k: reference_position after the last op of read k
-    const uint32_t lane4 = (uint32_t)lane * 4u;
 
     // ---- load cursor: runs 4 chunk loads ahead of the compute cursor ----
     int hk = 0;
@@ -251,16 +250,17 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
         lane_range |= carry + incl;
         // x = position after this lane's ops, relative to start_ext + 1.  One of the lane's ops can start
         // inside the window only if 0 <= x and x - tot < width  <=>  x <u width + tot  (all < 2^31 inside
-        // the parity domain).  Lanes past the read's last op (zero fill) are left out.
+        // the parity domain).  Zero-filled lanes behind a read that ends inside the window pass the test too;
+        // they queue four `0M` that contribute nothing, which is cheaper than a second compare on every chunk.
         const uint32_t x = (carry - W.se1) + incl;
-        const uint32_t t_rem = t_nc - (tc << 8);  // ops of this read from this chunk on (scalar)
-        const bool inw = x < W.width + tot && lane4 < t_rem;
+        const bool inw = x < W.width + tot;
         const uint64_t mask = ballot64(inw);
         if (mask) {
-            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, qcount));
+            QueueEntry *const tail = &L.q[qcount];  // wave-uniform
             if (inw) {
-                L.q[slot].w = w;
-                L.q[slot].info = make_uint2(x - tot, t_info);
+                const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                tail[idx].w = w;
+                tail[idx].info = make_uint2(x - tot, t_info);
             }
             qcount += (uint32_t)__popcll(mask);
             if (qcount > 64u) drain_queue(L, qcount, W, lane);

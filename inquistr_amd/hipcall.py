@@ -52,10 +52,12 @@ class InqError(RuntimeError):
 _lib = None
 
 
-def load():
-    """Loads libinquistr_hip.so (built by `make -C inquistr_amd/csrc` / __graft_entry__.build())."""
+def load(path: Optional[str] = None):
+    """Loads libinquistr_hip.so (built by `make -C inquistr_amd/csrc` / __graft_entry__.build()).
+    `path` loads another build of the library into its own handle (A/B timing of two builds in one
+    process, tools/ab_options.py --libs); it is not cached."""
     global _lib
-    if _lib is not None:
+    if _lib is not None and path is None:
         return _lib
     # PyTorch wheels bundle their own libamdhip64.so.7; both it and /opt/rocm's carry the same SONAME, so
     # the first one loaded serves the whole process.  With ours first, torch later reports "No HIP GPUs
@@ -66,12 +68,13 @@ def load():
             import torch  # noqa: F401
         except Exception:
             pass
-    if not os.path.exists(LIB_PATH):
+    lib_path = path or LIB_PATH
+    if not os.path.exists(lib_path):
         raise ImportError(
-            f"{LIB_PATH} not found: build the HIP extension first "
+            f"{lib_path} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback."
         )
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     vp = C.c_void_p
     L.inq_ctx_create.restype = C.c_int
     L.inq_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -103,7 +106,8 @@ def load():
     L.inq_last_error.argtypes = [vp]
     L.inq_abi_version.restype = C.c_int
     L.inq_abi_version.argtypes = []
-    _lib = L
+    if path is None:
+        _lib = L
     return L
 
 
@@ -114,8 +118,8 @@ def strerror(code: int) -> str:
 class Context:
     """One HIP device context (inq_ctx_t).  Raises InqError(INQ_ERR_NO_DEVICE) without an MI355X."""
 
-    def __init__(self, device_id: int = 0):
-        self._L = load()
+    def __init__(self, device_id: int = 0, lib=None):
+        self._L = lib if lib is not None else load()
         self._h = C.c_void_p()
         rc = self._L.inq_ctx_create(device_id, C.byref(self._h))
         if rc != INQ_OK:

@@ -13,6 +13,7 @@ ap.add_argument("--loci", type=int, default=0)
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--neighbors", type=int, default=0)
+ap.add_argument("--libs", default="", help="comma-separated library files: A/B of two BUILDS (the option spec is then applied to each)")
 ap.add_argument("--which", type=int, default=1, help="0 = whole launch sequence, 1 = locus_call_small only")
 ap.add_argument("--reads-per-locus", type=int, default=0)
 a = ap.parse_args()
@@ -25,22 +26,26 @@ if a.reads_per_locus:
 dev = torch.device("cuda:0")
 d = synth.DeviceBatch(wl, dev, 0, a.loci or wl.n_loci, neighbors=a.neighbors)
 print(f"pairs {d.n_pairs} reads {d.n_reads} algorithmic GB {d.algorithmic_bytes()/1e9:.3f}")
-ctx = hipcall.Context(0)
+libs = [l for l in a.libs.split(",") if l] or [None]
+ctxs = [(os.path.basename(l) if l else "default", hipcall.Context(0, lib=hipcall.load(l) if l else None)) for l in libs]
 st = torch.cuda.current_stream().cuda_stream
-res = {v: [] for v in vals}
-ctx.timing_enable(True)
+res = {(n, v): [] for n, _ in ctxs for v in vals}
+for _, c in ctxs:
+    c.timing_enable(True)
 for r in range(a.rounds + 1):
-    for v in vals:
-        ctx.set_option(key, v)
-        ctx.timing_reset()
-        for _ in range(a.steps):
-            ctx.call_batch_device(d.c_batch, d.c_result, st)
-        torch.cuda.synchronize()
-        ms, n = ctx.timing_read(a.which)
-        if r:  # round 0 = warm-up
-            res[v].append(ms / n)
-assert ctx.status()[0] == 0
+    for name, ctx in ctxs:
+        for v in vals:
+            ctx.set_option(key, v)
+            ctx.timing_reset()
+            for _ in range(a.steps):
+                ctx.call_batch_device(d.c_batch, d.c_result, st)
+            torch.cuda.synchronize()
+            ms, n = ctx.timing_read(a.which)
+            if r:  # round 0 = warm-up
+                res[(name, v)].append(ms / n)
+for _, c in ctxs:
+    assert c.status()[0] == 0
 ab = d.algorithmic_bytes()
-for v in vals:
-    m = statistics.median(res[v]); mn = min(res[v])
-    print(f"{key}={v}: median {m*1e3:.1f} us  min {mn*1e3:.1f} us  -> {ab/m/1e6:.0f} GB/s median, {ab/mn/1e6:.0f} GB/s best")
+for (name, v), t in res.items():
+    m = statistics.median(t); mn = min(t)
+    print(f"{name} {key}={v}: median {m*1e3:.1f} us  min {mn*1e3:.1f} us  -> {ab/m/1e6:.0f} GB/s median, {ab/mn/1e6:.0f} GB/s best")
