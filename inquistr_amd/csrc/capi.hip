@@ -38,7 +38,6 @@ struct inq_ctx {
     DevBuf worklist, sval, smeta;
     // staging for the host-buffer entry
     DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
-    uint32_t parity = 0;
     uint32_t grid_big = 1024;
     uint32_t grid_medium = 8192;
     uint32_t max_reads_hint = 0;  // 0 = unknown; else the caller's bound on reads per locus
@@ -201,15 +200,11 @@ int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, v
     a.worklist = (uint32_t *)c->worklist.p;
     a.sval = (int64_t *)c->sval.p;
     a.smeta = (uint8_t *)c->smeta.p;
-    a.parity = c->parity;
     a.blocks_per_xcd = per_xcd;
     a.shard_cap = shard_cap;
     const uint32_t hint = c->call_hint ? c->call_hint : c->max_reads_hint;
     c->call_hint = 0;
     a.max_reads_hint = hint;
-    // the last deep-locus kernel of a sequence clears the OTHER parity's counters; a sequence without the
-    // deep kernels appends nothing and must leave the parity alone
-    if (!(hint > 0 && hint <= 64)) c->parity ^= 1u;
 
     // CIGAR words of a read referenced by one locus only are read exactly once: stream them past the
     // caches (nt).  Reads shared by neighbouring loci keep the default policy so the second locus hits L2.

@@ -11,11 +11,12 @@ constexpr int kListShards = 32;
 struct DevStatus {
     unsigned int err;           // ST_* bits OR-ed by the kernels
     unsigned int pad;
-    // work-list lengths [call parity][kind: 0 = medium (65..256 reads), 1 = big][shard].  Every counter
+    // work-list lengths [kind: 0 = medium (65..256 reads), 1 = big][shard], zero between launch sequences
+    // (the last kernel of a sequence that may have filled them clears them).  Every counter
     // sits on its own 128-byte line: returning atomics on one line serialise at ~11 ns each.
     struct alignas(128) Counter {
         unsigned int n;
-    } list_count[2][2][kListShards];
+    } list_count[2][kListShards];
     unsigned long long ties;    // unphased loci whose split cuts mixed Span/Clip ties
 };
 
@@ -38,7 +39,6 @@ struct KArgs {
     uint32_t *worklist;  // [kind][kListShards][shard_cap]
     int64_t *sval;       // [n_pairs]
     uint8_t *smeta;      // [n_pairs]
-    uint32_t parity;
     uint32_t blocks_per_xcd;  // grid_small / 8
     uint32_t shard_cap;       // loci one shard can list: every locus whose block has blockIdx % kListShards == shard
     uint32_t max_reads_hint;  // caller's promise (0 = none): no locus is offered more reads than this

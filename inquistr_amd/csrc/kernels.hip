@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
         if (lane == 0) {
             const uint32_t kind = n64 > 64ull * kMediumSlots ? 1u : 0u;
             const uint32_t shard = blockIdx.x % kListShards;
-            const uint32_t slot = atomicAdd(&a.status->list_count[a.parity][kind][shard].n, 1u);
+            const uint32_t slot = atomicAdd(&a.status->list_count[kind][shard].n, 1u);
             a.worklist[((uint64_t)kind * kListShards + shard) * a.shard_cap + slot] = (uint32_t)j;
         }
         return;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void locus_call_medium(KArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ uint32_t cnt[kListShards];
-    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[a.parity][0][threadIdx.x].n;
+    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[0][threadIdx.x].n;
     __syncthreads();
     uint32_t total = 0;
     for (int k = 0; k < kListShards; ++k) total += cnt[k];
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void locus_call_big_walk(KArgs a) {
     __shared__ uint32_t cnt[kListShards];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[a.parity][1][threadIdx.x].n;
+    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[1][threadIdx.x].n;
     __syncthreads();
     uint32_t total = 0;
     for (int k = 0; k < kListShards; ++k) total += cnt[k];
@@ -606,19 +606,15 @@ __device__ double median_of_sorted_range(SortLds<CAP> &L, uint32_t lo, uint32_t 
     return out;
 }
 
-template <bool UNPHASED, int CAP, bool LAST>
+template <bool UNPHASED, int CAP>
 __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
     __shared__ SortLds<CAP> L;
     __shared__ BigShared sh;  // for the global fallback
     __shared__ uint32_t cnt[kListShards];
-    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[a.parity][1][threadIdx.x].n;
+    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[1][threadIdx.x].n;
     __syncthreads();
     uint32_t total = 0;
     for (int k = 0; k < kListShards; ++k) total += cnt[k];
-    // the other parity's counters belong to the next deep-locus call on this ctx: clear them in the last
-    // kernel of the sequence, kernel boundaries before locus_call_small of that call increments them
-    if (LAST && blockIdx.x == 0 && threadIdx.x < 2 * kListShards)
-        a.status->list_count[a.parity ^ 1u][threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
 
     for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
         uint32_t shard = 0, idx = item;
@@ -707,9 +703,10 @@ __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
     }
 }
 
-__global__ void clear_other_parity(KArgs a) {
-    if (threadIdx.x < 2 * kListShards)
-        a.status->list_count[a.parity ^ 1u][threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
+// Last kernel of every sequence that launched a deep-locus kernel: the work lists are empty again for the
+// next sequence (also when the same sequence is replayed from a hipGraph).
+__global__ void clear_lists(KArgs a) {
+    if (threadIdx.x < 2 * kListShards) a.status->list_count[threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
 }
 
 // ---- launchers (called from capi.hip) ----
@@ -724,16 +721,10 @@ static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, 
     hipLaunchKernelGGL((locus_call_medium<UNPHASED, AUX>), dim3(grid_medium), dim3(256), 0, s, a);
     if (!(h && h <= 64u * kMediumSlots)) {
         hipLaunchKernelGGL((locus_call_big_walk<UNPHASED, AUX>), dim3(grid_big), dim3(256), 0, s, a);
-        if (!(h && h <= 2048u)) {
-            hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048, false>), dim3(grid_big), dim3(256), 0, s, a);
-            hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 8192, true>), dim3(grid_big), dim3(256), 0, s, a);
-            return;
-        }
-        hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048, true>), dim3(grid_big), dim3(256), 0, s, a);
-        return;
+        hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048>), dim3(grid_big), dim3(256), 0, s, a);
+        if (!(h && h <= 2048u)) hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 8192>), dim3(grid_big), dim3(256), 0, s, a);
     }
-    // medium is the last kernel of this sequence: it has to clear the other parity's list counters
-    hipLaunchKernelGGL((clear_other_parity), dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((clear_lists), dim3(1), dim3(64), 0, s, a);
 }
 
 void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,

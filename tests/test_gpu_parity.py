@@ -418,6 +418,37 @@ def test_max_reads_hint(ctx):
         ctx.set_option("max_reads_hint", 0)
 
 
+def test_hip_graph_replay(ctx):
+    """The device entry only enqueues: captured into a hipGraph (torch.cuda.CUDAGraph) and replayed, every
+    replay must reproduce the rows — shallow loci, 65..256-read loci and deeper ones in one batch, so the
+    work lists are filled and emptied on every replay."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    wl = synth.Workload("mix", 600, reads_per_locus=30, seed=8)
+    d = synth.DeviceBatch(wl, dev, 0, 600, neighbors=6)  # 210 .. 390 offered reads per locus, edges fewer
+    shallow = synth.DeviceBatch(synth.WORKLOADS["phased10k"], dev, 0, 600)
+    st = torch.cuda.current_stream().cuda_stream
+    for b in (d, shallow):  # eager reference + scratch allocation outside the capture
+        ctx.call_batch_device(b.c_batch, b.c_result, st)
+    assert ctx.status()[0] == 0
+    want_d, want_s = d.phase1.cpu().numpy().copy(), shallow.phase1.cpu().numpy().copy()
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g, stream=cap):
+            ctx.call_batch_device(d.c_batch, d.c_result, cap.cuda_stream)
+            ctx.call_batch_device(shallow.c_batch, shallow.c_result, cap.cuda_stream)
+    for _ in range(3):
+        d.phase1.fill_(1.0)
+        shallow.phase1.fill_(1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert gen.same_f64(d.phase1.cpu().numpy(), want_d) and gen.same_f64(shallow.phase1.cpu().numpy(), want_s)
+    assert ctx.status()[0] == 0
+
+
 def test_timing_events(ctx):
     import torch
 
