@@ -60,7 +60,8 @@ struct inq_ctx {
 static int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return INQ_OK;
     if (b.p) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // earlier launches (possibly on the caller's stream) may still use the old buffer
+        HIP_TRY(c, hipDeviceSynchronize());
         HIP_TRY(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -164,7 +165,7 @@ static int check_scalars(const inq_batch_t *b, const inq_result_t *r) {
     return INQ_OK;
 }
 
-int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream) {
+static int call_batch_device_impl(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream) {
     if (!c) return INQ_ERR_ARG;
     int rc = check_scalars(b, r);
     if (rc != INQ_OK) return rc;
@@ -227,6 +228,16 @@ int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, v
     return INQ_OK;
 }
 
+int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream) {
+    try {  // nothing may unwind across the C ABI
+        return call_batch_device_impl(c, b, r, hip_stream);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
 int inq_ctx_status(inq_ctx_t *c, uint64_t *n_tie_loci) {
     if (!c) return INQ_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -241,7 +252,7 @@ int inq_ctx_status(inq_ctx_t *c, uint64_t *n_tie_loci) {
     return status_to_code(h.err);
 }
 
-int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
+static int call_batch_impl(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
     if (!c) return INQ_ERR_ARG;
     int rc = check_scalars(b, r);
     if (rc != INQ_OK) return rc;
@@ -294,7 +305,7 @@ int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
     dr.pair_bits = r->pair_bits ? (uint8_t *)c->pbits.p : nullptr;
     dr.n_tie_loci = 0;
     c->call_hint = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(max_reads, 1), 0xffffffffull);  // skips the deep-locus launches when no locus needs them
-    if ((rc = inq_call_batch_device(c, &db, &dr, s)) != INQ_OK) return rc;
+    if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(r->phase1, dr.phase1, (size_t)b->n_loci * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(r->phase2, dr.phase2, (size_t)b->n_loci * 8, hipMemcpyDeviceToHost, s));
     if (r->pair_call && b->n_pairs)
@@ -309,6 +320,16 @@ int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
     HIP_TRY(c, hipStreamSynchronize(s));
     r->n_tie_loci = c->h_status->ties;
     return status_to_code(c->h_status->err);
+}
+
+int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
+    try {
+        return call_batch_impl(c, b, r);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
 }
 
 int inq_ctx_timing_enable(inq_ctx_t *c, int on) {

@@ -262,7 +262,7 @@ int BamFile::next(BamRec &rec, std::string *err) {
         return -1;
     }
     uint32_t block_size = le32(l);
-    if (block_size < 32) {
+    if (block_size < 32 || block_size > (1u << 30)) {
         if (err) *err = "corrupt BAM record";
         return -1;
     }

@@ -251,7 +251,7 @@ struct inq_frontend {
 
 extern "C" {
 
-int inq_frontend_open(const inq_call_args_t *args, inq_frontend_t **out, char *errbuf, size_t errcap) {
+static int inq_frontend_open_impl(const inq_call_args_t *args, inq_frontend_t **out, char *errbuf, size_t errcap) {
     if (!out) return INQ_EXIT_ERROR;
     *out = nullptr;
     std::unique_ptr<inq_frontend> F(new inq_frontend());
@@ -285,7 +285,7 @@ void inq_frontend_set_batch_words(inq_frontend_t *fe, uint64_t w) {
     if (fe) fe->fe->set_max_batch_words(w);
 }
 
-int inq_frontend_next(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **locus_index, char *errbuf,
+static int inq_frontend_next_impl(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **locus_index, char *errbuf,
                       size_t errcap) {
     if (!fe || !batch) return -INQ_EXIT_ERROR;
     std::string err;
@@ -303,14 +303,14 @@ int inq_frontend_next(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **l
 
 void inq_frontend_close(inq_frontend_t *fe) { delete fe; }
 
-int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
+static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
     using clk = std::chrono::steady_clock;
     const bool timing = std::getenv("INQ_TIMING") != nullptr;
     auto t_start = clk::now();
     double t_front = 0, t_dev = 0;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     inq_frontend_t *F = nullptr;
-    int rc = inq_frontend_open(args, &F, errbuf, errcap);
+    int rc = inq_frontend_open_impl(args, &F, errbuf, errcap);
     if (rc != INQ_EXIT_OK) return rc;
     std::unique_ptr<inq_frontend> guard(F);
     const size_t n = F->P.targets.size();
@@ -510,7 +510,7 @@ struct LineReader {
 };
 }  // namespace
 
-int inq_combine(const char *const *files, size_t n_files, int out_fd, char *errbuf, size_t errcap) {
+static int inq_combine_impl(const char *const *files, size_t n_files, int out_fd, char *errbuf, size_t errcap) {
     if (!files || n_files == 0) {
         set_err(errbuf, errcap, "no input files");
         return INQ_EXIT_ERROR;
@@ -565,6 +565,35 @@ int inq_combine(const char *const *files, size_t n_files, int out_fd, char *errb
     }
     if (!write_all(out_fd, out)) return INQ_EXIT_PANIC;
     return INQ_EXIT_OK;
+}
+
+// public entries: no C++ exception may unwind across the C ABI
+#define INQ_GUARD(expr, errbuf, errcap)                                   \
+    try {                                                                  \
+        return expr;                                                       \
+    } catch (const std::exception &e) {                                    \
+        set_err(errbuf, errcap, std::string("internal error: ") + e.what()); \
+        return INQ_EXIT_ERROR;                                             \
+    } catch (...) {                                                        \
+        set_err(errbuf, errcap, "internal error");                         \
+        return INQ_EXIT_ERROR;                                             \
+    }
+int inq_frontend_open(const inq_call_args_t *args, inq_frontend_t **out, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_frontend_open_impl(args, out, errbuf, errcap), errbuf, errcap)
+}
+int inq_frontend_next(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **locus_index, char *errbuf, size_t errcap) {
+    try {
+        return inq_frontend_next_impl(fe, batch, locus_index, errbuf, errcap);
+    } catch (...) {
+        set_err(errbuf, errcap, "internal error");
+        return -INQ_EXIT_ERROR;
+    }
+}
+int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_genotype_repeats_impl(args, out_fd, errbuf, errcap), errbuf, errcap)
+}
+int inq_combine(const char *const *files, size_t n_files, int out_fd, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_combine_impl(files, n_files, out_fd, errbuf, errcap), errbuf, errcap)
 }
 
 size_t inq_host_format_f64(double v, char *buf, size_t cap) { return (size_t)std::snprintf(buf, cap, "%s", format_f64(v).c_str()); }
