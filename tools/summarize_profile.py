@@ -72,10 +72,17 @@ json.dump(
 )
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary `{tag}` — bench.py --workload {workload} ({loci} loci/GPU)\n\n")
-    f.write("Command: `tools/profile_round.sh` = `rocprofv3 --kernel-trace --stats` + separate `--pmc` passes around\n`python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`.\n\n")
+    f.write("Command: `tools/profile_round.sh` = `rocprofv3 --kernel-trace --stats -- python3 bench.py` (the driver's command, defaults)\nplus separate `rocprofv3 --pmc …` passes around `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`.\n\n")
     f.write("| kernel | dispatches | avg duration (µs) | min | max |\n|---|---|---|---|---|\n")
     for k, v in trace.items():
         f.write(f"| `{k}` | {len(v)} | {statistics.mean(v)/1e3:.1f} | {min(v)/1e3:.1f} | {max(v)/1e3:.1f} |\n")
+    bl = os.path.join(src, "trace.log")
+    if os.path.exists(bl):
+        for line in open(bl):
+            if line.startswith("{") and "roofline" in line:
+                d = json.loads(line)
+                f.write(f"\nbench.py line of the traced run: value {d['value']:.4g} {d['unit']}, roofline.avg_kernel_ms {d['roofline']['avg_kernel_ms']:.4f} "
+                        f"(HIP events, {d['roofline']['launches_timed']} timed launches), achieved {d['roofline']['achieved']:.0f} GB/s.\n")
     f.write(f"\nAlgorithmic bytes per launch: {alg} ({alg/1e9:.3f} GB) -> {alg/avg_ns:.0f} GB/s at the profiled duration.\n\n")
     f.write(f"HBM traffic per launch of `{small}`: FETCH_SIZE {fetch_kib:.0f} KiB raw -> x2 (gfx950) = {2*fetch_kib*1024/1e9:.3f} GB read, "
             f"WRITE_SIZE {write_kib:.0f} KiB = {write_kib*1024/1e6:.2f} MB written; total {hbm/1e9:.3f} GB = {hbm/alg:.3f} x algorithmic.\n\n")
