@@ -72,7 +72,7 @@ int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg) {
     }
     P.sample = a->sample_name ? std::string(a->sample_name) : sample_name_from_path(bamp);  // :91-100
     // get_chrom_lengths_from_bam_header opens the BAM before the target arguments are looked at (:187)
-    P.bam.reset(new BamFile((int)std::max<uint64_t>(1, std::min<uint64_t>(a->threads, 64))));
+    P.bam.reset(new BamFile(1));  // header + index; with -t > 1 every sweep worker opens its own reader
     std::string e;
     if (!P.bam->open(bamp, &e)) {
         msg = "Error opening local BAM: " + e;  // :242-243
@@ -129,8 +129,8 @@ public:
         std::vector<uint32_t> index;  // position of each batch locus in the full target list
     };
     ParallelFrontEnd(const std::string &bam_path, BamFile &hdr, const std::vector<RepeatInterval> &targets, bool unphased,
-                     int n_workers)
-        : path_(bam_path), targets_(targets), unphased_(unphased) {
+                     int n_workers, uint64_t max_words = 0)
+        : path_(bam_path), targets_(targets), unphased_(unphased), max_words_(max_words) {
         std::vector<uint32_t> order(targets.size());
         for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
@@ -189,6 +189,7 @@ private:
             sub.reserve(slices_[k].size());
             for (uint32_t i : slices_[k]) sub.push_back(targets_[i]);
             FrontEnd fe(bam, sub, unphased_);
+            if (max_words_) fe.set_max_batch_words(max_words_);
             for (;;) {
                 Item it;
                 {
@@ -229,6 +230,7 @@ private:
     std::string path_;
     const std::vector<RepeatInterval> &targets_;
     bool unphased_;
+    uint64_t max_words_ = 0;
     std::vector<std::vector<uint32_t>> slices_;
     std::atomic<size_t> next_slice_{0};
     std::vector<std::thread> pool_;
@@ -243,9 +245,13 @@ private:
 
 struct inq_frontend {
     Prepared P;
-    std::unique_ptr<FrontEnd> fe;
+    std::unique_ptr<FrontEnd> fe;           // threads <= 1: one sweep on the caller's thread
+    std::unique_ptr<ParallelFrontEnd> pfe;  // threads  > 1: the same worker pool the CLI driver uses
+    ParallelFrontEnd::Item item;
     HostBatch batch;
+    std::string bam_path;
     uint32_t minlen = 5, support = 3;
+    uint64_t threads = 1, max_words = 0;
     bool unphased = false;
 };
 
@@ -264,7 +270,9 @@ static int inq_frontend_open_impl(const inq_call_args_t *args, inq_frontend_t **
     F->minlen = args->minlen;
     F->support = (uint32_t)std::min<uint64_t>(args->support, 0xffffffffull);
     F->unphased = args->unphased != 0;
-    F->fe.reset(new FrontEnd(*F->P.bam, F->P.targets, F->unphased));
+    F->threads = args->threads;
+    F->bam_path = args->bam;
+    if (F->threads <= 1) F->fe.reset(new FrontEnd(*F->P.bam, F->P.targets, F->unphased));
     *out = F.release();
     return INQ_EXIT_OK;
 }
@@ -282,7 +290,9 @@ int inq_frontend_target(const inq_frontend_t *fe, uint64_t i, const char **chrom
 const char *inq_frontend_sample(const inq_frontend_t *fe) { return fe ? fe->P.sample.c_str() : ""; }
 
 void inq_frontend_set_batch_words(inq_frontend_t *fe, uint64_t w) {
-    if (fe) fe->fe->set_max_batch_words(w);
+    if (!fe) return;
+    fe->max_words = w;
+    if (fe->fe) fe->fe->set_max_batch_words(w);
 }
 
 static int inq_frontend_next_impl(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **locus_index, char *errbuf,
@@ -290,10 +300,26 @@ static int inq_frontend_next_impl(inq_frontend_t *fe, inq_batch_t *batch, const 
     if (!fe || !batch) return -INQ_EXIT_ERROR;
     std::string err;
     bool panic = false;
+    if (fe->threads > 1) {  // batches arrive in completion order; locus_index says where each row belongs
+        if (!fe->pfe)
+            fe->pfe.reset(new ParallelFrontEnd(fe->bam_path, *fe->P.bam, fe->P.targets, fe->unphased,
+                                               (int)std::min<uint64_t>(fe->threads, 64), fe->max_words));
+        fe->pfe->recycle(std::move(fe->item));
+        fe->item = ParallelFrontEnd::Item();
+        int rc = fe->pfe->next(fe->item, &err, &panic);
+        if (rc < 0) {
+            set_err(errbuf, errcap, err);
+            return -INQ_EXIT_PANIC;
+        }
+        if (rc == 0) return 0;
+        fe->item.batch.view(batch, fe->minlen, fe->support, fe->unphased);
+        if (locus_index) *locus_index = fe->item.index.data();
+        return 1;
+    }
     int rc = fe->fe->next(fe->batch, &err, &panic);
     if (rc < 0) {
         set_err(errbuf, errcap, err);
-        return panic ? -INQ_EXIT_PANIC : -INQ_EXIT_PANIC;  // read errors are expect()/unwrap() panics too (:294,346)
+        return -INQ_EXIT_PANIC;  // read errors are expect()/unwrap() panics too (:294,346)
     }
     if (rc == 0) return 0;
     fe->batch.view(batch, fe->minlen, fe->support, fe->unphased);
