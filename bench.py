@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 control flow on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--gather-every", type=int, default=4, help="N>1: steps whose rows travel to rank 0 in one gather")
     ap.add_argument("--l2", action="store_true", help="measure L2 (BAM+BED -> .inq, CLI vs CPU baseline modes) instead of L0")
     ap.add_argument("--l2-loci", type=int, default=20_000)
     ap.add_argument("--l2-threads", type=int, default=0)
@@ -172,13 +173,16 @@ def main():
     ctx = hipcall.Context(local_rank)
     ctx.set_option("max_reads_hint", wl.reads_per_locus)  # the generator's fixed depth: no deep-locus launches needed
     shard = synth.DeviceBatch(wl, dev, lo, hi)
-    # results: two rotating [2, n] buffers (row 0 = H1, row 1 = H2) so the gather of step k overlaps step k+1
-    outs = [torch.empty(2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]
+    # results: two rotating groups of G steps, each [G, 2, n] (row 0 = H1, row 1 = H2).  The rows of a whole
+    # group go to rank 0 in ONE gather (fewer, larger collectives) that overlaps the next group's kernels.
+    G = max(1, args.gather_every) if world > 1 else 1
+    outs = [torch.empty(G, 2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty(world, 2, per_gpu, dtype=torch.float64, device=gdev) for _ in range(2)] if (world > 1 and rank == 0) else None
-    stage = [torch.empty(2, per_gpu, dtype=torch.float64).pin_memory() for _ in range(2)] if (world > 1 and args.backend == "gloo") else None
+    gathered = [torch.empty(world, G, 2, per_gpu, dtype=torch.float64, device=gdev) for _ in range(2)] if (world > 1 and rank == 0) else None
+    stage = [torch.empty(G, 2, per_gpu, dtype=torch.float64).pin_memory() for _ in range(2)] if (world > 1 and args.backend == "gloo") else None
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     main_stream = torch.cuda.current_stream()
+    events = [torch.cuda.Event() for _ in range(2)]
 
     from inquistr_amd.batch import InqResultC
 
@@ -188,7 +192,7 @@ def main():
         r.pair_call = r.pair_bits = None
         return r
 
-    results = [result_for(b) for b in outs]
+    results = [[result_for(outs[b][g]) for g in range(G)] for b in range(2)]
     pending = []
     # gather-to-rank-0 is what the path needs; if this torch/RCCL build lacks NCCL gather (the error is a
     # backend capability error, raised on every rank before any traffic) fall back to all_gather
@@ -203,29 +207,44 @@ def main():
             if rank == 0:
                 print(f"[bench] NCCL gather unavailable ({type(e).__name__}); using all_gather_into_tensor", file=sys.stderr)
         if use_all_gather:
-            all_bufs = [torch.empty(world, 2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]
+            all_bufs = [torch.empty(world, G, 2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]
 
-    def step(i):
-        k = i & 1
-        if world > 1 and len(pending) >= 2:
-            pending.pop(0).wait()  # buffer k is free again
-        ctx.call_batch_device(shard.c_batch, results[k], main_stream.cuda_stream)
-        if world > 1:
-            ev = torch.cuda.Event()
-            ev.record(main_stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                glist = list(gathered[k].unbind(0)) if rank == 0 else None
-                if args.backend == "nccl" and use_all_gather:
-                    pending.append(dist.all_gather_into_tensor(all_bufs[k], outs[k], async_op=True))
-                elif args.backend == "nccl":
-                    pending.append(dist.gather(outs[k], glist, dst=0, async_op=True))
-                else:  # rehearsal: stage through pinned host memory, gather on gloo
-                    stage[k].copy_(outs[k], non_blocking=True)
-                    comm_stream.synchronize()
-                    pending.append(dist.gather(stage[k], glist, dst=0, async_op=True))
+    def send_group(b):
+        ev = events[b]
+        ev.record(main_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev)
+            glist = list(gathered[b].unbind(0)) if rank == 0 else None
+            if args.backend == "nccl" and use_all_gather:
+                pending.append(dist.all_gather_into_tensor(all_bufs[b], outs[b], async_op=True))
+            elif args.backend == "nccl":
+                pending.append(dist.gather(outs[b], glist, dst=0, async_op=True))
+            else:  # rehearsal: stage through pinned host memory, gather on gloo
+                stage[b].copy_(outs[b], non_blocking=True)
+                comm_stream.synchronize()
+                pending.append(dist.gather(stage[b], glist, dst=0, async_op=True))
+
+    state = {"n": 0}  # steps issued since the last drain
+
+    def step(_i):
+        n = state["n"]
+        b, g = (n // G) & 1, n % G
+        if world > 1 and g == 0 and len(pending) >= 2:
+            pending.pop(0).wait()  # the group buffer b is free again
+        ctx.call_batch_device(shard.c_batch, results[b][g], main_stream.cuda_stream)
+        state["n"] = n + 1
+        if world > 1 and g == G - 1:
+            send_group(b)
+
+    def flush():
+        n = state["n"]
+        if world > 1 and n % G != 0:  # a partly filled group still has to reach rank 0
+            send_group((n // G) & 1)
+        state["last"] = ((n - 1) // G) & 1, (n - 1) % G
+        state["n"] = 0
 
     def drain():
+        flush()
         while pending:
             pending.pop(0).wait()
         torch.cuda.synchronize()
@@ -263,11 +282,11 @@ def main():
     dt_max = float(t.item())
 
     if rank == 0 and world > 1:
-        # the last gathered buffer must hold rank 0's own rows in slot 0
-        last = (args.steps - 1) & 1
-        src = all_bufs[last] if use_all_gather else gathered[last]
-        own = outs[last].to(src.device)
-        g0 = src[0]
+        # the last gathered group must hold rank 0's own rows in slot 0
+        lb, lg = state["last"]
+        src = all_bufs[lb] if use_all_gather else gathered[lb]
+        own = outs[lb][lg].to(src.device)
+        g0 = src[0][lg]
         if not bool(((own == g0) | (own.isnan() & g0.isnan())).all()):
             raise SystemExit("gathered rows differ from the local result")
     if rank == 0:
@@ -307,7 +326,7 @@ def main():
                 "cigar_ops_per_gpu": shard.n_ops_total,
                 "minlen": wl.minlen,
                 "support": wl.support,
-                "sharding": f"loci x {world} ranks ({args.backend}), gather of 16 B/locus to rank 0 overlapped" if world > 1 else "single GPU",
+                "sharding": f"loci x {world} ranks ({args.backend}), rows of {G} steps per gather to rank 0 (16 B/locus), overlapped" if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
