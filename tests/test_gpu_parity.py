@@ -349,6 +349,36 @@ def test_full_size_roofline_workload(ctx, orc):
     assert gen.same_f64(part.phase2.cpu().numpy(), p2[70_000:71_000])
 
 
+@pytest.mark.parametrize("name,lo,hi,samples", [
+    ("phased10k", 0, 10_000, [(0, 300), (9_700, 10_000)]),                      # BASELINE config #2, whole
+    ("expansion50k", 0, 50_000, [(0, 64), (25_000, 25_064), (49_936, 50_000)]),  # config #5, whole
+    ("shard500k", 187_500, 250_000, [(187_500, 187_800), (249_700, 250_000)]),   # config #4: the shard of rank 3 of 8
+])
+def test_full_size_other_configs(ctx, orc, name, lo, hi, samples):
+    """The other BASELINE configs at full size, device-resident: exact against the oracle on sampled locus
+    ranges (the generator is counter based, so numpy reproduces any range), idempotent, no device error."""
+    import torch
+
+    wl = synth.WORKLOADS[name]
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    d = synth.DeviceBatch(wl, dev, lo, hi)
+    ctx.call_batch_device(d.c_batch, d.c_result, st)
+    rc, ties = ctx.status()
+    assert rc == 0
+    p1, p2 = d.phase1.cpu().numpy().copy(), d.phase2.cpu().numpy().copy()
+    d.phase1.fill_(3.0)
+    ctx.call_batch_device(d.c_batch, d.c_result, st)
+    assert ctx.status() == (0, ties)
+    assert gen.same_f64(d.phase1.cpu().numpy(), p1)
+    for a, b in samples:
+        sub = synth.generate_numpy(wl, a, b)
+        oc, want = orc.call_batch(sub, threads=8)
+        assert oc == 0
+        assert gen.same_f64(p1[a - lo : b - lo], want.phase1) and gen.same_f64(p2[a - lo : b - lo], want.phase2), (name, a, b)
+    assert np.all(np.mod(p1[~np.isnan(p1)] * 2, 1) == 0)
+
+
 def test_superset_of_candidates_changes_nothing(ctx):
     """The ABI lets the host offer more reads than fetch() would yield (one sweep over the file instead
     of an index query per locus): the device applies htslib's overlap rule.  Offering every locus the
