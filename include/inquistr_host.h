@@ -77,6 +77,11 @@ int inq_host_human_compare(const char *a, const char *b);
 int inq_host_parse_region(const char *reg, const char *chrom_name, uint64_t chrom_len, char *chrom_out, size_t cap,
                           uint32_t *start, uint32_t *end);
 /* BAI facts (for fixtures): number of references, and mapped/unmapped counts of one */
+/* File offset (compressed bytes) from which a forward scan sees every record of `tid` overlapping positions
+ * >= pos, from the .bai linear index; 0 if the contig has nothing there.  Lets a multi-process run split the
+ * targets by the amount of BAM each rank has to read rather than by locus count. */
+uint64_t inq_host_bai_file_offset(const char *bai_path, int32_t tid, int64_t pos);
+int inq_host_bam_tid(const char *bam_path, const char *contig);
 int inq_host_bai_stats(const char *bai_path, uint32_t *n_ref, int32_t tid, uint64_t *n_mapped, uint64_t *n_unmapped,
                        uint64_t *n_bins, uint64_t *n_intv);
 

@@ -37,6 +37,8 @@ HOST_ABI_SYMBOLS = (
     "inq_host_human_compare",
     "inq_host_parse_region",
     "inq_host_bai_stats",
+    "inq_host_bai_file_offset",
+    "inq_host_bam_tid",
 )
 
 
@@ -105,6 +107,10 @@ def load():
         L.inq_host_human_compare.argtypes = [C.c_char_p, C.c_char_p]
         L.inq_host_parse_region.restype = C.c_int
         L.inq_host_parse_region.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.inq_host_bai_file_offset.restype = C.c_uint64
+        L.inq_host_bai_file_offset.argtypes = [C.c_char_p, C.c_int32, C.c_int64]
+        L.inq_host_bam_tid.restype = C.c_int
+        L.inq_host_bam_tid.argtypes = [C.c_char_p, C.c_char_p]
         L.inq_host_bai_stats.restype = C.c_int
         L.inq_host_bai_stats.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L

@@ -36,6 +36,35 @@ def _hip_compute(device: int) -> Callable[[Batch], Tuple[np.ndarray, np.ndarray]
     return run
 
 
+def _cuts_by_file_bytes(bamp: str, sorted_targets, world: int) -> List[int]:
+    """world + 1 cut points into the sorted target list.  Cost of a target = compressed bytes between its
+    scan start and the next target's (same contig), capped so that one far-away locus does not own a whole
+    chromosome; falls back to equal counts when the index gives nothing."""
+    n = len(sorted_targets)
+    L = hostcall.load()
+    bai = bamp + ".bai" if os.path.exists(bamp + ".bai") else os.path.splitext(bamp)[0] + ".bai"
+    tid_of = {}
+    offs = np.zeros(n, dtype=np.float64)
+    for k, (chrom, start, _end) in enumerate(sorted_targets):
+        if chrom not in tid_of:
+            tid_of[chrom] = L.inq_host_bam_tid(os.fspath(bamp).encode(), chrom.encode())
+        offs[k] = L.inq_host_bai_file_offset(bai.encode(), tid_of[chrom], max(0, start - 10))
+    cost = np.ones(n, dtype=np.float64)
+    if n > 1 and offs.max() > 0:
+        d = np.diff(offs)
+        ok = d > 0
+        if ok.any():
+            cap = np.percentile(d[ok], 99) * 4 + 1
+            cost[:-1] += np.clip(np.where(ok, d, 0), 0, cap)
+            cost[-1] += np.median(d[ok])
+    csum = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(min(max(np.searchsorted(csum, csum[-1] * r / world, side="left"), cuts[-1]), n)))
+    cuts.append(n)
+    return cuts
+
+
 def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: Optional[str], minlen: int = 5,
                                  support: int = 3, threads: int = 1, unphased: bool = False,
                                  sample_name: Optional[str] = None, out=None, rank: int = 0, world: int = 1,
@@ -51,9 +80,12 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
     sample = fe_all.sample
     fe_all.close()
     n = len(targets)
-    # contiguous slices of the position-sorted list (contig order of first appearance keeps slices local)
+    # contiguous slices of the position-sorted list, cut so that every rank has about the same amount of
+    # BAM to read (the .bai linear index gives the file offset of every target; SURVEY.md §8e asks for shards
+    # balanced by work, not by locus count).  Every rank computes the same cuts.
     order = sorted(range(n), key=lambda i: (targets[i][0], targets[i][1], i))
-    lo, hi = n * rank // world, n * (rank + 1) // world
+    cuts = _cuts_by_file_bytes(bamp, [targets[i] for i in order], world)
+    lo, hi = cuts[rank], cuts[rank + 1]
     mine = order[lo:hi]
     p1 = np.full(len(mine), np.nan)
     p2 = np.full(len(mine), np.nan)
@@ -73,7 +105,7 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
         finally:
             os.unlink(sub_bed)
     if world > 1:
-        width = max((n * (r + 1) // world) - (n * r // world) for r in range(world))
+        width = max(cuts[r + 1] - cuts[r] for r in range(world))
         gdev = torch.device("cuda", device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
         buf = torch.full((2, max(width, 1)), float("nan"), dtype=torch.float64, device=gdev)
         buf[0, : len(mine)] = torch.from_numpy(p1)
@@ -84,7 +116,7 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
             return
         full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
         for r in range(world):
-            sl = order[n * r // world : n * (r + 1) // world]
+            sl = order[cuts[r] : cuts[r + 1]]
             full1[sl] = bufs[r][0, : len(sl)].cpu().numpy()
             full2[sl] = bufs[r][1, : len(sl)].cpu().numpy()
     else:

@@ -649,6 +649,36 @@ int inq_host_parse_region(const char *reg, const char *chrom_name, uint64_t chro
     return INQ_EXIT_OK;
 }
 
+uint64_t inq_host_bai_file_offset(const char *bai_path, int32_t tid, int64_t pos) {
+    try {
+        static std::mutex mu;
+        static std::string cached_path;
+        static BaiIndex cached;
+        std::lock_guard<std::mutex> g(mu);
+        if (cached_path != bai_path) {
+            std::string e;
+            BaiIndex idx;
+            if (!idx.load(bai_path, &e)) return 0;
+            cached = std::move(idx);
+            cached_path = bai_path;
+        }
+        return cached.scan_start(tid, pos) >> 16;
+    } catch (...) {
+        return 0;
+    }
+}
+
+int inq_host_bam_tid(const char *bam_path, const char *contig) {
+    try {
+        BamFile b(1);
+        std::string e;
+        if (!b.open(bam_path, &e)) return -2;
+        return b.tid(contig);
+    } catch (...) {
+        return -2;
+    }
+}
+
 int inq_host_bai_stats(const char *bai_path, uint32_t *n_ref, int32_t tid, uint64_t *n_mapped, uint64_t *n_unmapped,
                        uint64_t *n_bins, uint64_t *n_intv) {
     BaiIndex idx;
