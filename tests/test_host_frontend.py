@@ -242,6 +242,22 @@ def test_reference_error_behaviour(tmp_path):
     assert e.value.status == 1 and "CRAM" in e.value.message
 
 
+def test_chrom_lengths_from_bam_header(tmp_path):
+    """src/call.rs:600-605 asserts chr7 LN == 159345973 on its (undistributed) BAM; here the same number sits in a
+    generated header and is observed through RepeatInterval's `end < LN` rule (src/repeats.rs:108-114)."""
+    bam = str(tmp_path / "plumbing.bam")
+    w = bamio.BamWriter(bam, [("chr7", 159345973)])
+    w.add("r", 0, 0, 154778000, 60, [("M", 2000)], [("HP", "C", 1)])
+    w.close()
+    assert call.FrontEnd(bam, region="chr7:154778571-154779363").targets() == [("chr7", 154778571, 154779363)]
+    assert call.FrontEnd(bam, region="chr7:10-159345972").targets() == [("chr7", 10, 159345972)]
+    with pytest.raises(call.CallError) as e:
+        call.FrontEnd(bam, region="chr7:10-159345973")
+    assert e.value.status == 101
+    bed = os.path.join(GOLDEN, "reference_test.bed")  # the reference's test-data/test.bed
+    assert call.FrontEnd(bam, region_file=bed).targets() == [("chr7", 154778571, 154779363)]
+
+
 def test_bed_reader_rules(tmp_path):
     bam, _, _, _ = _make_case(tmp_path, 6, n_loci=3)
 
