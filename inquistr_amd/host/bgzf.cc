@@ -217,21 +217,16 @@ bool BgzfReader::seek(uint64_t voffset, std::string *err) {
     next_coffset_ = voffset >> 16;
     cur_.reset();
     cur_pos_ = 0;
-    uint32_t uoff = (uint32_t)(voffset & 0xffff);
-    if (uoff || true) {
-        auto b = fetch_next(err);
-        if (!b) return false;
-        if (b->eof_marker) {
-            cur_ = b;
-            return uoff == 0;
-        }
-        if (uoff > b->data.size()) {
-            if (err) *err = "virtual offset beyond block";
-            return false;
-        }
-        cur_ = b;
-        cur_pos_ = uoff;
+    const uint32_t uoff = (uint32_t)(voffset & 0xffff);
+    auto b = fetch_next(err);
+    if (!b) return false;
+    cur_ = b;
+    if (b->eof_marker) return uoff == 0;
+    if (uoff > b->data.size()) {
+        if (err) *err = "virtual offset beyond block";
+        return false;
     }
+    cur_pos_ = uoff;
     return true;
 }
 
