@@ -62,6 +62,7 @@ bool FrontEnd::begin_group(std::string *err) {
     flushed_ = 0;
     group_eof_ = false;
     in_group_ = true;
+    last_pos_ = -1;
     if (G.tid < 0 || G.loci.empty()) {
         group_eof_ = true;
         return true;
@@ -205,6 +206,11 @@ int FrontEnd::next(HostBatch &out, std::string *err, bool *panic) {
                 break;
             }
             const int64_t pos = rec.pos;
+            if (pos < last_pos_) {  // an index exists only for coordinate-sorted files; a sweep needs the order too
+                *err = "BAM records are not coordinate-sorted (contig " + bam_.refs()[G.tid].name + ")";
+                return -1;
+            }
+            last_pos_ = pos;
             bool closed_some = false;
             while (lo_ < m && (int64_t)G.loci[lo_].end_ext <= pos) {
                 ++lo_;
@@ -223,6 +229,7 @@ int FrontEnd::next(HostBatch &out, std::string *err, bool *panic) {
                 }
                 if (vo > rec.voffset) {
                     if (!bam_.seek(vo, err)) return -1;
+                    last_pos_ = -1;  // the first record behind a jump only has to overlap the target window
                     continue;
                 }
             }

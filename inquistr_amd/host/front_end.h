@@ -56,6 +56,7 @@ private:
     bool in_group_ = false, group_eof_ = false;
     size_t lo_ = 0;      // first locus of the group not yet closed
     size_t flushed_ = 0; // loci [0, flushed_) already emitted
+    int64_t last_pos_ = -1;  // position of the previous record of the sweep (sortedness check)
     // contig-local store
     std::vector<uint32_t> cig_;
     std::vector<inq_read_t> reads_;

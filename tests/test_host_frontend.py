@@ -295,6 +295,18 @@ def test_hp_of_other_type_panics_only_when_phased(tmp_path):
     assert len(list(fe.batches())) == 1
 
 
+def test_unsorted_bam_is_refused(tmp_path):
+    bam = str(tmp_path / "unsorted.bam")
+    w = bamio.BamWriter(bam, [("chr1", 100_000)])
+    w.add("a", 0, 0, 5_000, 60, [("M", 300)], [("HP", "C", 1)])
+    w.add("b", 0, 0, 900, 60, [("M", 300)], [("HP", "C", 1)])  # goes backwards
+    w.close()
+    fe = call.FrontEnd(bam, region="chr1:1010-6000")
+    with pytest.raises(call.CallError) as e:
+        list(fe.batches())
+    assert "not coordinate-sorted" in e.value.message
+
+
 def test_cli_exit_codes(tmp_path):
     exe = call.CLI_PATH
     r = subprocess.run([exe, "call", str(tmp_path / "nope.bam"), "-r", "chr1:100-200"], capture_output=True, text=True)
