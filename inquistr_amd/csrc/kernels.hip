@@ -543,13 +543,13 @@ __global__ __launch_bounds__(256) void locus_call_big_walk(KArgs a) {
 
 // ---- stage 2: reduce ------------------------------------------------------------------------------
 // One workgroup per listed locus: the kept Calls become 64-bit keys
-//     [63:62] haplotype group | [61:14] value + 2^47 | [13:1] file-order index | [0] clipped
+//     [63:62] haplotype group | [61:15] value + 2^46 | [14:1] file-order index | [0] clipped
 // sorted once by a bitonic network in LDS; both haplotype groups are then contiguous ascending ranges
 // and median_str_length's span/clip rule reduces to one prefix count of "spanning" flags.  Two
 // instantiations split the list by depth so that shallow-deep loci keep several workgroups per CU:
-// CAP = 2048 (16 KB of keys) and CAP = 8192 (64 KB); deeper loci, or values beyond 48 bits, take
-// the global rank-counting fallback inside the CAP = 8192 launch.
-constexpr uint64_t kKeyBias = 1ull << 47;
+// CAP = 2048 (16 KB of keys), 8192 (64 KB) and 16384 (128 KB, one workgroup per CU); deeper loci take the
+// global rank-counting fallback inside the last launch.  The file index has 14 bits in the key.
+constexpr uint64_t kKeyBias = 1ull << 46;
 constexpr uint64_t kKeySent = ~0ull;
 
 template <int CAP>
@@ -560,7 +560,7 @@ struct SortLds {
     long long pick[2];
 };
 
-__device__ __forceinline__ int64_t key_value(uint64_t k) { return (int64_t)((k >> 14) & ((1ull << 48) - 1ull)) - (int64_t)kKeyBias; }
+__device__ __forceinline__ int64_t key_value(uint64_t k) { return (int64_t)((k >> 15) & ((1ull << 47) - 1ull)) - (int64_t)kKeyBias; }
 
 // median_str_length (src/call.rs:497-522) of the sorted range key[lo, hi).  Block-uniform result.
 template <int CAP>
@@ -624,8 +624,9 @@ __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
         const uint32_t n = (uint32_t)(a.locus_pair_off[j + 1] - p0);
         // depth classes: this launch takes (CAP/4, CAP] reads (the CAP = 2048 launch everything up to 2048);
         // the CAP = 8192 launch also takes what no sort can hold
-        if (CAP == 2048 ? n > 2048u : n <= 2048u) continue;
-        if (n > (uint32_t)CAP) {
+        constexpr uint32_t kLow = CAP == 2048 ? 0u : CAP == 8192 ? 2048u : 8192u;  // this launch takes (kLow, CAP]
+        if (n <= kLow || (CAP != 16384 && n > (uint32_t)CAP)) continue;
+        if (n > (uint32_t)CAP) {  // only the last class: deeper than any sort can hold
             reduce_deep_global<UNPHASED>(a, j, p0, n, sh);
             continue;
         }
@@ -639,14 +640,14 @@ __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
             if (in) {
                 const int64_t v = a.sval[p0 + e];
                 if (v < -(int64_t)kKeyBias || v >= (int64_t)kKeyBias) L.overflow = 1u;
-                const uint64_t key = ((uint64_t)(UNPHASED ? 0u : g) << 62) | (((uint64_t)(v + (int64_t)kKeyBias) & ((1ull << 48) - 1ull)) << 14) |
+                const uint64_t key = ((uint64_t)(UNPHASED ? 0u : g) << 62) | (((uint64_t)(v + (int64_t)kKeyBias) & ((1ull << 47) - 1ull)) << 15) |
                                      ((uint64_t)e << 1) | ((me & PM_CLIP) ? 1ull : 0ull);
                 L.key[atomicAdd(&L.m, 1u)] = key;
                 if (!UNPHASED && g == 1u) atomicAdd(&L.c1, 1u);
             }
         }
         __syncthreads();
-        if (L.overflow) {  // a Call beyond 48 bits: not representable in the key
+        if (L.overflow) {  // a Call beyond 47 bits: not representable in the key
             reduce_deep_global<UNPHASED>(a, j, p0, n, sh);
             continue;
         }
@@ -675,11 +676,11 @@ __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
             const uint32_t ks = m / 2u;
             lo1 = 0, hi1 = ks, lo2 = ks, hi2 = m;
             if (ks >= 1u && ks < m) {
-                const uint64_t va = L.key[ks - 1u] >> 14, vb = L.key[ks] >> 14;  // group bits are 0 here
+                const uint64_t va = L.key[ks - 1u] >> 15, vb = L.key[ks] >> 15;  // group bits are 0 here
                 if (va == vb) {
                     for (uint32_t e = threadIdx.x; e < m; e += 256u) {
                         const uint64_t k2 = L.key[e];
-                        if ((k2 >> 14) == va) {
+                        if ((k2 >> 15) == va) {
                             if (k2 & 1ull)
                                 L.tie_clip = 1u;
                             else
@@ -723,6 +724,7 @@ static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, 
         hipLaunchKernelGGL((locus_call_big_walk<UNPHASED, AUX>), dim3(grid_big), dim3(256), 0, s, a);
         hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048>), dim3(grid_big), dim3(256), 0, s, a);
         if (!(h && h <= 2048u)) hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 8192>), dim3(grid_big), dim3(256), 0, s, a);
+        if (!(h && h <= 8192u)) hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 16384>), dim3(256), dim3(256), 0, s, a);
     }
     hipLaunchKernelGGL((clear_lists), dim3(1), dim3(64), 0, s, a);
 }

@@ -107,10 +107,10 @@ def test_random_vs_oracle(ctx, orc, seed, unphased):
 
 
 @pytest.mark.parametrize("unphased", [False, True])
-@pytest.mark.parametrize("max_reads", [64, 65, 130, 256, 257, 700, 2300, 8192, 8300])
+@pytest.mark.parametrize("max_reads", [64, 65, 130, 256, 257, 700, 2300, 8192, 8300, 16384, 16500])
 def test_deep_loci(ctx, orc, unphased, max_reads):
     """Loci with more than 64 offered reads take the work-list kernel."""
-    # <= 64: wave per locus; <= 256: four reads per lane; <= 8192: walk kernel + LDS sort; beyond: global ranks
+    # <= 64: wave per locus; <= 256: four reads per lane; <= 16384: walk kernel + LDS sort (3 size classes); beyond: global ranks
     batch, _ = gen.random_case(1000 + max_reads, n_loci=24 if max_reads < 2000 else 6, unphased=unphased,
                                max_reads=max_reads, long_every=9, support=3)
     assert int(np.diff(batch.locus_pair_off.astype(np.int64)).max()) >= max_reads
@@ -425,7 +425,7 @@ def test_max_reads_hint(ctx):
         ctx.set_option("max_reads_hint", 64)
         ctx.call_batch_device(d.c_batch, d.c_result, st)
         assert ctx.status()[0] == B.INQ_ERR_ARG
-        for hint in (70, 256, 300, 2048, 5000, 70):  # every launch-skipping level, twice through the parities
+        for hint in (70, 256, 300, 2048, 5000, 9000, 70):  # every launch-skipping level, twice through the parities
             ctx.set_option("max_reads_hint", hint)
             d.phase1.fill_(7.0)
             ctx.call_batch_device(d.c_batch, d.c_result, st)
@@ -435,7 +435,7 @@ def test_max_reads_hint(ctx):
         ctx.call_batch_device(deep.c_batch, deep.c_result, st)
         assert ctx.status()[0] == 0
         want_deep = deep.phase1.cpu().numpy().copy()
-        for hint in (300, 2048, 2049, 256):
+        for hint in (300, 2048, 2049, 8193, 256):
             ctx.set_option("max_reads_hint", hint)
             deep.phase1.fill_(7.0)
             ctx.call_batch_device(deep.c_batch, deep.c_result, st)
