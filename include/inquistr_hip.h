@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define INQ_ABI_VERSION 1
+#define INQ_ABI_VERSION 2
 
 /* ---- error codes (0 = ok, negative = failure; never throws / aborts) ---- */
 enum {
@@ -42,7 +42,14 @@ enum {
     INQ_ERR_INDEX = -7,        /* pair_read[] or a read's CIGAR extent points outside the buffers    */
     INQ_ERR_HIP = -8,          /* HIP runtime failure; see inq_last_error()                         */
     INQ_ERR_NOMEM = -9,
-    INQ_ERR_NO_DEVICE = -10    /* no gfx950 device visible: the library has NO CPU fallback          */
+    INQ_ERR_NO_DEVICE = -10,   /* no gfx950 device visible: the library has NO CPU fallback          */
+    INQ_ERR_INFLATE = -11,     /* device front end: a BGZF block does not inflate to its ISIZE (htslib: read error,
+                                  `r.expect("Error reading BAM file")` src/call.rs:295,346 panics)     */
+    INQ_ERR_BAM = -12,         /* device front end: record chain / field lengths corrupt, or records of the
+                                  contig not coordinate-sorted                                          */
+    INQ_ERR_AUX = -13          /* device front end: HP aux of a fetched read is neither `C` nor `i`
+                                  (src/call.rs:482-491), SA is not `Z` or cannot be parsed (:429-451):
+                                  the reference panics                                                  */
 };
 
 /* ---- read descriptor: one 16-byte record per decoded BAM record ---------
@@ -163,6 +170,78 @@ int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);
 /* Pinned host allocations for batch buffers. */
 int inq_alloc_pinned(size_t bytes, void **out);
 void inq_free_pinned(void *p);
+
+
+/* ==== device front end: BGZF inflate + BAM record scan + overlap join on the GPU =====================
+ * Replaces, for one span of the file, what `bam.fetch((tid, start_ext, end_ext))` + `rc_records()` and the
+ * record accessors do per locus in the reference (src/call.rs:288,294,297-299,338,345,351-352; [3P]
+ * htslib bgzf.c / sam.c / hts.c): the host only reads the compressed bytes and walks the 18-byte BGZF
+ * headers and the .bai; inflating, finding the records, decoding their fixed fields and HP / SA / CG
+ * tags, and matching reads to loci with htslib's overlap rule all happen on the device, and the batch
+ * the locus kernels consume never exists in host memory.
+ */
+typedef struct inq_bgzf_block {
+    uint64_t comp_off; /* offset of the block's DEFLATE payload (behind its gzip header) in `comp`    */
+    uint32_t comp_len; /* payload bytes, without the 8-byte CRC32 / ISIZE trailer                      */
+    uint32_t isize;    /* inflated size from the trailer (<= 65536)                                    */
+    uint64_t out_off;  /* where the block's data goes in the inflated byte string                      */
+} inq_bgzf_block_t;
+
+/* per-block inflate status bits (0 = the block inflated to exactly isize bytes) */
+#define INQ_INFLATE_BAD_HEADER 0x01u    /* reserved block type, bad code-length set, extents outside the buffers */
+#define INQ_INFLATE_BAD_CODE 0x02u      /* a bit pattern that is no code of the current Huffman set            */
+#define INQ_INFLATE_INPUT_OVERRUN 0x04u /* the stream needs more bits than the payload holds                   */
+#define INQ_INFLATE_OUTPUT_SIZE 0x08u   /* more or fewer bytes than isize                                      */
+#define INQ_INFLATE_BAD_DISTANCE 0x10u  /* a match reaches in front of the block                               */
+#define INQ_INFLATE_BAD_STORED 0x20u    /* stored block LEN / NLEN mismatch                                    */
+
+/* Inflates n_blocks BGZF payloads; every pointer is HOST memory (the call uploads, runs one lane per
+ * block, downloads, synchronises).  block_status may be NULL.  Returns INQ_ERR_INFLATE if any block
+ * failed.  CRC32 is not verified. */
+int inq_bgzf_inflate(inq_ctx_t *ctx, const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks,
+                     uint64_t n_blocks, uint8_t *out, uint64_t out_bytes, uint32_t *block_status);
+
+/* One span: consecutive whole BGZF blocks of a coordinate-sorted BAM plus the loci (one contig) whose
+ * overlapping records all start inside it. */
+typedef struct inq_span {
+    const uint8_t *comp;             /* HOST (ideally pinned): the compressed bytes of the blocks        */
+    uint64_t comp_bytes;
+    const inq_bgzf_block_t *blocks;  /* file order; out_off dense and ascending from 0                   */
+    uint64_t n_blocks;
+    const uint64_t *anchors;         /* ascending offsets into the inflated bytes at which a BAM record
+                                        is known to start (virtual offsets of the .bai: chunk begins and
+                                        linear-index entries); anchors[0] = the first record to look at.
+                                        Records are found by following block_size from every anchor to
+                                        the next one, one lane per anchor.                                */
+    uint64_t n_anchors;
+    int32_t tid;                     /* header().tid(chrom), src/call.rs:287,337                          */
+    uint32_t reserved;               /* must be 0                                                         */
+    const uint32_t *locus_start;     /* [n_loci] un-extended BED coordinates, any order                   */
+    const uint32_t *locus_end;
+    uint64_t n_loci;
+    uint32_t minlen, support, unphased, reserved2;
+} inq_span_t;
+
+typedef struct inq_span_stats {
+    uint64_t n_records;      /* records found in the span                                   */
+    uint64_t n_reads;        /* of which on the span's contig (the rest lies behind it)      */
+    uint64_t n_pairs;        /* (locus, read) pairs = records fetch() would yield, summed    */
+    uint64_t n_cigar_words;  /* gathered CIGAR words incl. padding                           */
+    uint64_t inflated_bytes;
+    uint32_t max_reads;      /* deepest locus                                                */
+    uint32_t front_status;   /* raw status bits of the scan kernels (diagnostics)            */
+    uint64_t first_bad_record;
+    double ms_upload, ms_inflate, ms_scan, ms_join, ms_call; /* HIP-event times of the stages */
+} inq_span_stats_t;
+
+/* Runs the whole path for one span; result->phase1/phase2 (HOST, [n_loci]) receive the rows in the order
+ * of locus_start/locus_end; pair_call / pair_bits are not produced (pass NULL).  stats may be NULL. */
+int inq_call_span(inq_ctx_t *ctx, const inq_span_t *span, inq_result_t *result, inq_span_stats_t *stats);
+
+/* Test / debug: copies the batch the last inq_call_span built on the device into caller-allocated HOST
+ * arrays sized from that call's stats: cigar[n_cigar_words], reads[n_reads], pair_read[n_pairs],
+ * locus_pair_off[n_loci + 1].  Any pointer may be NULL. */
+int inq_span_fetch_batch(inq_ctx_t *ctx, uint32_t *cigar, inq_read_t *reads, uint32_t *pair_read, uint64_t *locus_pair_off);
 
 const char *inq_strerror(int code);
 const char *inq_backend_name(const inq_ctx_t *ctx); /* "hip:gfx950:<device name>" */

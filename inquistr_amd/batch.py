@@ -28,6 +28,9 @@ INQ_ERR_INDEX = -7
 INQ_ERR_HIP = -8
 INQ_ERR_NOMEM = -9
 INQ_ERR_NO_DEVICE = -10
+INQ_ERR_INFLATE = -11
+INQ_ERR_BAM = -12
+INQ_ERR_AUX = -13
 
 INQ_READ_UNMAPPED = 0x01
 INQ_READ_REVERSE = 0x02

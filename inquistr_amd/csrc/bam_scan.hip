@@ -1,0 +1,514 @@
+// bam_scan.hip — from inflated BGZF bytes to the batch the locus kernels consume, all on the device.
+//
+// Replaces the record side of bam.fetch()/rc_records() and the Record accessors of the reference
+// (src/call.rs:288,294,297-299,338,345,351-352,423,483; [3P] htslib sam.c bam_read1 / bam_aux_get /
+// bam_tag2cigar, hts.c region iterator):
+//   chain_count / chain_fill : find the records.  A record's start is only known from the previous
+//       record's block_size, so the .bai's virtual offsets (all of them record starts) serve as anchors
+//       and one lane follows the chain from each anchor to the next.
+//   record_parse : one lane per record: fixed fields, aux walk for HP / SA / CG.
+//   cigar_gather : one wave per read: CIGAR words to the 16-byte aligned, zero-padded layout of
+//       inq_batch_t, reference span ([3P] bam_endpos), soft-clip presence; is_accidental_2d
+//       (src/call.rs:415-477) for the reads that have both a soft clip and an SA tag.
+//   join_count / join_fill : one lane per locus: the records fetch((tid, start-10, end+10)) yields are
+//       those with pos < end_ext && endpos > start_ext; positions ascend, so they lie between two binary
+//       searches (on pos, and on the running maximum of endpos) and keep file order.
+// HBM-bound byte/integer work; no LDS tiling to speak of, the inflated bytes are read once by the parse
+// (36 bytes + aux per record) and once by the gather (CIGAR only) - SEQ and QUAL are never touched.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/inquistr_hip.h"
+#include "front_kernels.h"
+
+namespace inq {
+
+namespace {
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
+    uint32_t w;
+    __builtin_memcpy(&w, p, 4);
+    return w;
+}
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+__device__ __forceinline__ void raise(FrontStatus *st, uint32_t bit, uint64_t rec) {
+    atomicOr(&st->err, bit);
+    atomicMin(&st->first_bad, (unsigned long long)rec);
+}
+
+// ---------------------------------------------------------------- record chains
+template <bool FILL>
+__global__ __launch_bounds__(64) void chain_kernel(ScanArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (i >= a.n_anchors) return;
+    uint64_t x = a.anchors[i];
+    if (FILL) {  // the count pass validated the chain: replay it
+        const uint32_t quota = a.anchor_cnt[i];
+        uint64_t w = a.anchor_base[i];
+        for (uint32_t n = 0; n < quota; ++n) {
+            a.rec_off[w++] = x;
+            x += 4 + (uint64_t)ld32(a.u + x);
+        }
+        return;
+    }
+    const bool last = i + 1 == a.n_anchors;
+    const uint64_t stop = last ? a.u_bytes : a.anchors[i + 1];
+    uint64_t n = 0;
+    bool bad = x > a.u_bytes || stop > a.u_bytes || stop < x;
+    while (!bad && x < stop) {
+        if (x + 4 > a.u_bytes) break;  // a record cut by the end of the span: behind everything the loci need
+        const uint64_t bs = ld32(a.u + x);
+        if (bs < 32 || n == 0xffffffffull) {
+            bad = true;
+            break;
+        }
+        if (x + 4 + bs > a.u_bytes) break;
+        ++n;
+        x += 4 + bs;
+    }
+    // a chain inside the span must land exactly on the next anchor
+    if (!bad && !last && x != stop) bad = true;
+    if (bad) raise(a.st, FS_CHAIN, 0);
+    a.anchor_cnt[i] = bad ? 0u : (uint32_t)n;
+}
+
+// ---------------------------------------------------------------- record fields + aux
+// size of an aux value of BAM type `t` at v; 0 = malformed / runs past the record
+__device__ __forceinline__ uint64_t aux_size(uint32_t t, const uint8_t *v, const uint8_t *end) {
+    switch (t) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'd': return 8;
+    case 'Z': case 'H': {
+        const uint8_t *q = v;
+        while (q < end && *q) ++q;
+        return q < end ? (uint64_t)(q - v) + 1 : 0;
+    }
+    case 'B': {
+        if (v + 5 > end) return 0;
+        const uint32_t st = v[0], n = ld32(v + 1);
+        const uint64_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+        return 5 + (uint64_t)n * es;
+    }
+    default: return 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void record_parse_kernel(ScanArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_records) return;
+    const uint64_t x = a.rec_off[i];
+    const uint8_t *b = a.u + x + 4;
+    const uint32_t bs = ld32(a.u + x);
+    const int32_t tid = (int32_t)ld32(b), pos = (int32_t)ld32(b + 4);
+    const uint32_t l_read_name = b[8], mapq = b[9];
+    uint32_t n_cigar = ld16(b + 12);
+    const uint32_t flag = ld16(b + 14), l_seq = ld32(b + 16);
+    const uint64_t off_cigar = 32 + (uint64_t)l_read_name;
+    const uint64_t off_seq = off_cigar + (uint64_t)n_cigar * 4;
+    const uint64_t off_aux = off_seq + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+    inq_read_t rd;
+    rd.cigar_off4 = 0;
+    rd.n_cigar = 0;
+    rd.pos = pos;
+    rd.mapq = (uint8_t)mapq;
+    rd.bits = 0;
+    rd.phase = 0;
+    rd.reserved = 0;
+    RecInfo ri;
+    ri.cigar_src = x + 4 + off_cigar;
+    ri.sa_off = 0;
+    ri.sa_type = 0;
+    ri.err = 0;
+    if (tid != a.tid) {  // behind the contig (the file is sorted by contig, then position)
+        atomicMin(&a.st->n_valid, (unsigned long long)i);
+        a.reads[i] = rd;
+        a.info[i] = ri;
+        return;
+    }
+    if (off_aux > bs) {
+        raise(a.st, FS_RECORD, i);
+        a.reads[i] = rd;
+        a.info[i] = ri;
+        return;
+    }
+    if (i > 0) {  // coordinate order inside the contig: the join's binary searches rely on it
+        const uint8_t *pb = a.u + a.rec_off[i - 1] + 4;
+        if ((int32_t)ld32(pb) == a.tid && (int32_t)ld32(pb + 4) > pos) raise(a.st, FS_UNSORTED, i);
+    }
+    if (flag & 0x4u) rd.bits |= INQ_READ_UNMAPPED;
+    if (flag & 0x10u) rd.bits |= INQ_READ_REVERSE;
+    // aux walk; the first HP / SA / CG wins, a malformed field ends the walk ([3P] bam_aux_get)
+    const uint8_t *p = b + off_aux, *end = b + bs;
+    bool have_hp = false, have_sa = false, have_cg = false, cg_ok = false;
+    uint64_t cg_payload = 0;
+    uint32_t cg_len = 0;
+    while (p + 3 <= end) {
+        const uint32_t t0 = p[0], t1 = p[1], type = p[2];
+        const uint8_t *v = p + 3;
+        const uint64_t sz = aux_size(type, v, end);
+        if (sz == 0 || v + sz > end) break;
+        if (t0 == 'H' && t1 == 'P' && !have_hp) {
+            have_hp = true;
+            // get_phase, src/call.rs:482-491: U8 -> v, I32 -> v as u8, anything else panics
+            if (type == 'C') rd.bits |= INQ_READ_HAS_HP, rd.phase = v[0];
+            else if (type == 'i') rd.bits |= INQ_READ_HAS_HP, rd.phase = (uint8_t)ld32(v);
+            else if (!a.unphased) ri.err |= FS_HP_TYPE;
+        } else if (t0 == 'S' && t1 == 'A' && !have_sa) {
+            have_sa = true;
+            ri.sa_type = type;
+            ri.sa_off = (uint64_t)(v - a.u);
+        } else if (t0 == 'C' && t1 == 'G' && !have_cg) {
+            have_cg = true;
+            if (type == 'B' && (v[0] == 'I' || v[0] == 'i')) {
+                cg_ok = true;
+                cg_len = ld32(v + 1);
+                cg_payload = (uint64_t)(v + 5 - a.u);
+            }
+        }
+        p = v + sz;
+    }
+    // [3P] bam_tag2cigar: the real CIGAR is in CG:B,I when the stored one is <l_seq>S<ref_len>N
+    if (cg_ok && n_cigar > 0 && pos >= 0) {
+        const uint32_t c0 = ld32(b + off_cigar);
+        if ((c0 & 0xfu) == 4u && (c0 >> 4) == l_seq && cg_len >= n_cigar && cg_len < (1u << 29)) {
+            ri.cigar_src = cg_payload;
+            n_cigar = cg_len;
+        }
+    }
+    rd.n_cigar = n_cigar;
+    a.reads[i] = rd;
+    a.info[i] = ri;
+}
+
+// ---------------------------------------------------------------- is_accidental_2d on the device
+// Rust `str::parse::<i64>`: optional sign, at least one digit, digits only, no overflow
+__device__ bool parse_i64(const uint8_t *s, uint64_t n, int64_t *out) {
+    uint64_t i = 0;
+    bool neg = false;
+    if (n == 0) return false;
+    if (s[0] == '+' || s[0] == '-') neg = s[0] == '-', i = 1;
+    if (i == n) return false;
+    uint64_t v = 0;
+    const uint64_t lim = neg ? (1ull << 63) : (1ull << 63) - 1ull;
+    for (; i < n; ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        const uint64_t d = (uint64_t)(s[i] - '0');
+        if (v > (lim - d) / 10ull) return false;
+        v = v * 10ull + d;
+    }
+    *out = neg ? (int64_t)(0ull - v) : (int64_t)v;
+    return true;
+}
+
+// returns 0 / 1, or an FS_* bit (shifted left by 8) where the reference panics
+__device__ uint32_t is_accidental_2d(const uint8_t *u, const RecInfo &ri, bool reverse, int64_t rs, int64_t re) {
+    if (ri.sa_off == 0) return 0;                      // src/call.rs:425-427
+    if (ri.sa_type != 'Z') return FS_SA_TYPE << 8;     // :429-432
+    const uint8_t *s = u + ri.sa_off;                  // NUL-terminated inside the record (aux_size checked it)
+    // :434 entries separated by ';', empty ones dropped; more than one -> false (:436-438)
+    const uint8_t *first = nullptr;
+    uint64_t first_len = 0;
+    int n_entries = 0;
+    for (const uint8_t *q = s;;) {
+        const uint8_t *e = q;
+        while (*e && *e != ';') ++e;
+        if (e != q) {
+            if (!n_entries) first = q, first_len = (uint64_t)(e - q);
+            ++n_entries;
+        }
+        if (!*e) break;
+        q = e + 1;
+    }
+    if (n_entries > 1) return 0;
+    if (n_entries == 0) return FS_SA_FORMAT << 8;  // sa_entries[0] out of bounds
+    // :439 rname,POS,strand,CIGAR,mapQ,NM
+    const uint8_t *fld[4];
+    uint64_t flen[4];
+    int nf = 0;
+    const uint8_t *end = first + first_len, *start = first;
+    for (const uint8_t *q = first;; ++q) {
+        if (q == end || *q == ',') {
+            if (nf < 4) fld[nf] = start, flen[nf] = (uint64_t)(q - start);
+            ++nf;
+            start = q + 1;
+            if (q == end) break;
+        }
+    }
+    if (nf < 3 || flen[2] == 0) return FS_SA_FORMAT << 8;  // :441
+    const uint8_t strand = reverse ? '-' : '+';            // :422
+    if (strand == fld[2][0]) return 0;                     // :441-443
+    int64_t sa_start;
+    if (!parse_i64(fld[1], flen[1], &sa_start)) return FS_SA_FORMAT << 8;  // :450
+    if (nf < 4) return FS_SA_FORMAT << 8;
+    // cigar_to_rlen, :461-477
+    int64_t rlen = 0;
+    uint64_t num_start = 0, num_len = 0;
+    for (uint64_t k = 0; k < flen[3]; ++k) {
+        const uint8_t c = fld[3][k];
+        if (c >= '0' && c <= '9') {
+            if (num_len == 0) num_start = k;
+            ++num_len;
+        } else {
+            int64_t v;
+            if (!parse_i64(fld[3] + num_start, num_len, &v)) return FS_SA_FORMAT << 8;  // :469
+            if (c == 'M' || c == '=' || c == 'X' || c == 'D' || c == 'N') rlen += v;
+            num_len = 0;
+        }
+    }
+    const int64_t sa_end = sa_start + rlen;  // :451
+    const int64_t lo = rs > sa_start ? rs : sa_start, hi = re < sa_end ? re : sa_end;
+    return lo < hi ? 1u : 0u;  // :454-458
+}
+
+// ---------------------------------------------------------------- CIGAR gather
+__global__ __launch_bounds__(256) void cigar_gather_kernel(ScanArgs a, uint64_t n_valid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t i = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (i >= n_valid) return;
+    inq_read_t rd = a.reads[i];
+    const RecInfo ri = a.info[i];
+    const uint64_t unit0 = a.cig_off[i];
+    const uint32_t n = rd.n_cigar, n4 = (n + 3u) & ~3u;
+    const uint8_t *src = a.u + ri.cigar_src;
+    uint32_t *dst = a.cigar + unit0 * 4u;
+    // the extent was checked against the record for the in-record CIGAR; the CG payload by aux_size()
+    int64_t rlen = 0;
+    uint32_t clip = 0;
+    for (uint32_t k = lane; k < n4; k += 64u) {
+        const uint32_t w = k < n ? ld32(src + (uint64_t)k * 4u) : 0u;
+        dst[k] = w;
+        const uint32_t op = w & 0xfu;
+        if ((0x18Du >> op) & 1u) rlen += (int64_t)(w >> 4);  // M D N = X consume the reference
+        clip |= op == 4u;
+    }
+    for (int off = 32; off; off >>= 1) {
+        rlen += __shfl_xor(rlen, off);
+        clip |= __shfl_xor(clip, off);
+    }
+    if (lane == 0) {
+        if ((rd.bits & INQ_READ_UNMAPPED) || rlen == 0) rlen = 1;  // [3P] bam_endpos
+        const int64_t endpos = (int64_t)rd.pos + rlen;
+        a.endpos[i] = endpos;
+        rd.cigar_off4 = (uint32_t)unit0;
+        // is_accidental_2d is only reached from a soft-clip op (src/call.rs:394)
+        if (clip && ri.sa_off) {
+            const uint32_t v = is_accidental_2d(a.u, ri, (rd.bits & INQ_READ_REVERSE) != 0, (int64_t)rd.pos, endpos);
+            if (v == 1u) rd.bits |= INQ_READ_IS_2D;
+            else if (v > 1u) a.info[i].err = ri.err | (v >> 8);
+        }
+        a.reads[i] = rd;
+    }
+}
+
+// ---------------------------------------------------------------- overlap join
+template <bool FILL>
+__global__ __launch_bounds__(256) void join_kernel(ScanArgs a, uint64_t n_valid) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= a.n_loci) return;
+    const uint32_t s0 = a.locus_start[j], e0 = a.locus_end[j];
+    uint32_t n = 0;
+    if (s0 >= 10u && e0 >= s0 && e0 <= 0xffffffffu - 10u) {  // out-of-domain loci are reported by the locus kernel
+        const int64_t start_ext = (int64_t)s0 - 10, end_ext = (int64_t)e0 + 10;  // src/call.rs:285-286,335-336
+        // hi = first read with pos >= end_ext
+        uint64_t lo = 0, hi = n_valid;
+        while (lo < hi) {
+            const uint64_t m = (lo + hi) >> 1;
+            if ((int64_t)a.reads[m].pos < end_ext) lo = m + 1;
+            else hi = m;
+        }
+        const uint64_t last = lo;
+        // first = first read whose running maximum of endpos exceeds start_ext
+        lo = 0, hi = last;
+        while (lo < hi) {
+            const uint64_t m = (lo + hi) >> 1;
+            if (a.pmax[m] > start_ext) hi = m;
+            else lo = m + 1;
+        }
+        uint64_t w = FILL ? a.locus_pair_off[j] : 0;
+        for (uint64_t r = lo; r < last; ++r) {
+            if (a.endpos[r] > start_ext) {  // [3P] htslib: pos < end && endpos > beg
+                if (FILL) {
+                    a.pair_read[w++] = (uint32_t)r;
+                    const uint32_t e = a.info[r].err;
+                    if (e) raise(a.st, e, r);
+                }
+                ++n;
+            }
+        }
+    }
+    if (!FILL) {
+        a.locus_cnt[j] = n;
+        if (n) atomicMax(&a.st->max_reads, n);
+    }
+}
+
+// ---------------------------------------------------------------- scans
+// Tiles of 4096 elements: per-tile totals, one block scans the totals, then every tile scans itself with
+// its carry.  Op = sum (u64) or max (i64).
+constexpr int kTile = 4096, kScanThreads = 256, kPer = kTile / kScanThreads;
+
+struct SumOp {
+    using T = uint64_t;
+    __device__ static T id() { return 0; }
+    __device__ static T op(T x, T y) { return x + y; }
+};
+struct MaxOp {
+    using T = int64_t;
+    __device__ static T id() { return INT64_MIN; }
+    __device__ static T op(T x, T y) { return x > y ? x : y; }
+};
+
+struct LoadU32 {
+    const uint32_t *in;
+    __device__ uint64_t operator()(uint64_t i) const { return in[i]; }
+};
+struct LoadUnits {
+    const inq_read_t *reads;
+    const unsigned long long *n_valid;
+    __device__ uint64_t operator()(uint64_t i) const { return i < *n_valid ? ((uint64_t)reads[i].n_cigar + 3u) / 4u : 0u; }
+};
+struct LoadI64 {
+    const int64_t *in;
+    __device__ int64_t operator()(uint64_t i) const { return in[i]; }
+};
+
+template <class Op>
+__device__ typename Op::T block_reduce(typename Op::T v, typename Op::T *lds) {
+    for (int off = 32; off; off >>= 1) v = Op::op(v, __shfl_xor(v, off));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    typename Op::T r = lds[0];
+    for (int w = 1; w < kScanThreads / 64; ++w) r = Op::op(r, lds[w]);
+    __syncthreads();
+    return r;
+}
+
+template <class Op, class Load>
+__global__ __launch_bounds__(kScanThreads) void scan_tile_totals(Load load, uint64_t n, typename Op::T *totals) {
+    __shared__ typename Op::T lds[kScanThreads / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * kTile;
+    typename Op::T v = Op::id();
+    for (int k = 0; k < kPer; ++k) {
+        const uint64_t i = base + (uint64_t)k * kScanThreads + threadIdx.x;
+        if (i < n) v = Op::op(v, load(i));
+    }
+    v = block_reduce<Op>(v, lds);
+    if (threadIdx.x == 0) totals[blockIdx.x] = v;
+}
+
+// exclusive scan of the tile totals in place, by one block; totals[n_tiles] = grand total
+template <class Op>
+__global__ __launch_bounds__(kScanThreads) void scan_totals(typename Op::T *totals, uint64_t n_tiles) {
+    __shared__ typename Op::T lds[kScanThreads];
+    typename Op::T carry = Op::id();
+    for (uint64_t base = 0; base < n_tiles; base += kScanThreads) {
+        const uint64_t i = base + threadIdx.x;
+        const typename Op::T v = i < n_tiles ? totals[i] : Op::id();
+        lds[threadIdx.x] = v;
+        __syncthreads();
+        // Hillis-Steele inclusive scan over the 256 slots
+        for (int off = 1; off < kScanThreads; off <<= 1) {
+            typename Op::T t = Op::id();
+            if ((int)threadIdx.x >= off) t = lds[threadIdx.x - off];
+            __syncthreads();
+            lds[threadIdx.x] = Op::op(lds[threadIdx.x], t);
+            __syncthreads();
+        }
+        const typename Op::T incl = lds[threadIdx.x];
+        const typename Op::T excl = threadIdx.x ? lds[threadIdx.x - 1] : Op::id();
+        const typename Op::T all = lds[kScanThreads - 1];
+        __syncthreads();
+        if (i < n_tiles) totals[i] = Op::op(carry, excl);
+        (void)incl;
+        carry = Op::op(carry, all);
+    }
+    if (threadIdx.x == 0) totals[n_tiles] = carry;
+}
+
+// EXCLUSIVE: out[i] = carry + sum of earlier elements (and out[n] = total); else inclusive
+template <class Op, class Load, bool EXCLUSIVE>
+__global__ __launch_bounds__(kScanThreads) void scan_apply(Load load, uint64_t n, const typename Op::T *totals, typename Op::T *out) {
+    using T = typename Op::T;
+    __shared__ T lds[kScanThreads];
+    // thread t owns kPer consecutive elements of the tile
+    const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kPer;
+    T v[kPer];
+    T sum = Op::id();
+    for (int k = 0; k < kPer; ++k) {
+        v[k] = base + k < n ? (T)load(base + k) : Op::id();
+        sum = Op::op(sum, v[k]);
+    }
+    lds[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kScanThreads; off <<= 1) {
+        T t = Op::id();
+        if ((int)threadIdx.x >= off) t = lds[threadIdx.x - off];
+        __syncthreads();
+        lds[threadIdx.x] = Op::op(lds[threadIdx.x], t);
+        __syncthreads();
+    }
+    T run = Op::op(totals[blockIdx.x], threadIdx.x ? lds[threadIdx.x - 1] : Op::id());
+    for (int k = 0; k < kPer; ++k) {
+        if (base + k < n) {
+            if (EXCLUSIVE) out[base + k] = run;
+            run = Op::op(run, v[k]);
+            if (!EXCLUSIVE) out[base + k] = run;
+        }
+    }
+    if (EXCLUSIVE && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = totals[gridDim.x];
+}
+
+template <class Op, class Load, bool EXCLUSIVE>
+void run_scan(Load load, typename Op::T *out, uint64_t n, typename Op::T *tmp, hipStream_t s) {
+    if (n == 0) {
+        if (EXCLUSIVE) (void)hipMemsetAsync(out, 0, sizeof(typename Op::T), s);
+        return;
+    }
+    const uint64_t tiles = (n + kTile - 1) / kTile;
+    hipLaunchKernelGGL((scan_tile_totals<Op, Load>), dim3((uint32_t)tiles), dim3(kScanThreads), 0, s, load, n, tmp);
+    hipLaunchKernelGGL((scan_totals<Op>), dim3(1), dim3(kScanThreads), 0, s, tmp, tiles);
+    hipLaunchKernelGGL((scan_apply<Op, Load, EXCLUSIVE>), dim3((uint32_t)tiles), dim3(kScanThreads), 0, s, load, n, tmp, out);
+}
+
+}  // namespace
+
+void launch_chain_count(const ScanArgs &a, hipStream_t s) {
+    if (!a.n_anchors) return;
+    hipLaunchKernelGGL((chain_kernel<false>), dim3((uint32_t)((a.n_anchors + 63) / 64)), dim3(64), 0, s, a);
+}
+void launch_chain_fill(const ScanArgs &a, hipStream_t s) {
+    if (!a.n_anchors) return;
+    hipLaunchKernelGGL((chain_kernel<true>), dim3((uint32_t)((a.n_anchors + 63) / 64)), dim3(64), 0, s, a);
+}
+void launch_record_parse(const ScanArgs &a, hipStream_t s) {
+    if (!a.n_records) return;
+    hipLaunchKernelGGL(record_parse_kernel, dim3((uint32_t)((a.n_records + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_cigar_gather(const ScanArgs &a, uint64_t n_valid, hipStream_t s) {
+    if (!n_valid) return;
+    hipLaunchKernelGGL(cigar_gather_kernel, dim3((uint32_t)((n_valid + 3) / 4)), dim3(256), 0, s, a, n_valid);
+}
+void launch_join_count(const ScanArgs &a, uint64_t n_valid, hipStream_t s) {
+    if (!a.n_loci) return;
+    hipLaunchKernelGGL((join_kernel<false>), dim3((uint32_t)((a.n_loci + 255) / 256)), dim3(256), 0, s, a, n_valid);
+}
+void launch_join_fill(const ScanArgs &a, uint64_t n_valid, hipStream_t s) {
+    if (!a.n_loci) return;
+    hipLaunchKernelGGL((join_kernel<true>), dim3((uint32_t)((a.n_loci + 255) / 256)), dim3(256), 0, s, a, n_valid);
+}
+
+void launch_scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *tmp, hipStream_t s) {
+    run_scan<SumOp, LoadU32, true>(LoadU32{in}, out, n, tmp, s);
+}
+void launch_scan_cigar_units(const inq_read_t *reads, const unsigned long long *n_valid, uint64_t *out, uint64_t n, uint64_t *tmp,
+                             hipStream_t s) {
+    run_scan<SumOp, LoadUnits, true>(LoadUnits{reads, n_valid}, out, n, tmp, s);
+}
+void launch_scan_max_i64(const int64_t *in, int64_t *out, uint64_t n, uint64_t *tmp, hipStream_t s) {
+    run_scan<MaxOp, LoadI64, false>(LoadI64{in}, out, n, (int64_t *)tmp, s);
+}
+
+}  // namespace inq

@@ -12,52 +12,14 @@
 
 #include "../../include/inquistr_hip.h"
 #include "cigar_walk.h"
+#include "ctx.h"
 #include "kernels.h"
 
 using namespace inq;
 
-namespace {
+namespace inq {
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-struct EvTriple {
-    hipEvent_t e0, e1, e2;
-};
-
-}  // namespace
-
-struct inq_ctx {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    std::string backend, last_err;
-    DevStatus *d_status = nullptr;
-    DevStatus *h_status = nullptr;  // pinned mirror for the host-buffer entry
-    DevBuf worklist, sval, smeta;
-    // staging for the host-buffer entry
-    DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
-    uint32_t grid_big = 1024;
-    uint32_t grid_medium = 8192;
-    uint32_t max_reads_hint = 0;  // 0 = unknown; else the caller's bound on reads per locus
-    uint32_t call_hint = 0;       // set by the host-buffer entry, which sees the offsets, for its own launch
-    int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
-    bool timing = false;
-    std::vector<EvTriple> ev_pool;
-    size_t ev_used = 0;
-};
-
-#define HIP_TRY(ctx, expr)                                                                     \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess) {                                                                \
-            (ctx)->last_err = std::string(#expr) + ": " + hipGetErrorString(_e);               \
-            return _e == hipErrorOutOfMemory ? INQ_ERR_NOMEM : INQ_ERR_HIP;                    \
-        }                                                                                      \
-    } while (0)
-
-static int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
+int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return INQ_OK;
     if (b.p) {
         // earlier launches (possibly on the caller's stream) may still use the old buffer
@@ -74,7 +36,7 @@ static int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
     return INQ_OK;
 }
 
-static int status_to_code(uint32_t st) {
+int status_to_code(uint32_t st) {
     if (st & ST_HINT) return INQ_ERR_ARG;
     if (st & ST_LOCUS) return INQ_ERR_LOCUS;
     if (st & ST_INDEX) return INQ_ERR_INDEX;
@@ -83,6 +45,8 @@ static int status_to_code(uint32_t st) {
     if (st & ST_PHASE) return INQ_ERR_PHASE;
     return INQ_OK;
 }
+
+}  // namespace inq
 
 extern "C" {
 
@@ -100,6 +64,9 @@ const char *inq_strerror(int code) {
     case INQ_ERR_INDEX: return "pair or CIGAR index outside the batch buffers";
     case INQ_ERR_HIP: return "HIP runtime error";
     case INQ_ERR_NOMEM: return "out of device memory";
+    case INQ_ERR_INFLATE: return "a BGZF block does not inflate to its recorded size (corrupt or truncated BAM)";
+    case INQ_ERR_BAM: return "corrupt BAM record chain, or records not coordinate-sorted";
+    case INQ_ERR_AUX: return "HP aux of a fetched read is neither C nor i, or its SA aux cannot be parsed (the reference panics)";
     case INQ_ERR_NO_DEVICE: return "no gfx950 (MI355X) device available; this library has no CPU fallback";
     default: return "unknown error";
     }
@@ -135,6 +102,7 @@ void inq_ctx_destroy(inq_ctx_t *c) {
     if (!c) return;
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->span) span_state_destroy(c->span);
     for (DevBuf *b : {&c->worklist, &c->sval, &c->smeta, &c->cigar, &c->reads, &c->pair_read, &c->off, &c->lstart,
                       &c->lend, &c->p1, &c->p2, &c->pcall, &c->pbits})
         if (b->p) (void)hipFree(b->p);
@@ -165,7 +133,7 @@ static int check_scalars(const inq_batch_t *b, const inq_result_t *r) {
     return INQ_OK;
 }
 
-static int call_batch_device_impl(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream) {
+static int enqueue_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream) {
     if (!c) return INQ_ERR_ARG;
     int rc = check_scalars(b, r);
     if (rc != INQ_OK) return rc;
@@ -230,7 +198,7 @@ static int call_batch_device_impl(inq_ctx_t *c, const inq_batch_t *b, inq_result
 
 int inq_call_batch_device(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream) {
     try {  // nothing may unwind across the C ABI
-        return call_batch_device_impl(c, b, r, hip_stream);
+        return enqueue_batch(c, b, r, hip_stream);
     } catch (const std::bad_alloc &) {
         return INQ_ERR_NOMEM;
     } catch (...) {
@@ -305,7 +273,7 @@ static int call_batch_impl(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) 
     dr.pair_bits = r->pair_bits ? (uint8_t *)c->pbits.p : nullptr;
     dr.n_tie_loci = 0;
     c->call_hint = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(max_reads, 1), 0xffffffffull);  // skips the deep-locus launches when no locus needs them
-    if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
+    if ((rc = enqueue_batch(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(r->phase1, dr.phase1, (size_t)b->n_loci * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(r->phase2, dr.phase2, (size_t)b->n_loci * 8, hipMemcpyDeviceToHost, s));
     if (r->pair_call && b->n_pairs)
@@ -400,3 +368,8 @@ void inq_free_pinned(void *p) {
 }
 
 }  // extern "C"
+
+int inq::call_batch_device_impl(inq_ctx *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream) {
+    return enqueue_batch(c, b, r, hip_stream);
+}
+

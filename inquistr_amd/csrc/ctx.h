@@ -1,0 +1,62 @@
+// ctx.h — the library context behind inq_ctx_t, shared by the translation units that implement the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/inquistr_hip.h"
+#include "kernels.h"
+
+namespace inq {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct EvTriple {
+    hipEvent_t e0, e1, e2;
+};
+
+struct SpanState;  // device front end (span.hip)
+
+}  // namespace inq
+
+struct inq_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string backend, last_err;
+    inq::DevStatus *d_status = nullptr;
+    inq::DevStatus *h_status = nullptr;  // pinned mirror for the host-buffer entry
+    inq::DevBuf worklist, sval, smeta;
+    // staging for the host-buffer entry
+    inq::DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
+    uint32_t grid_big = 1024;
+    uint32_t grid_medium = 8192;
+    uint32_t max_reads_hint = 0;  // 0 = unknown; else the caller's bound on reads per locus
+    uint32_t call_hint = 0;       // set by the host-buffer entry, which sees the offsets, for its own launch
+    int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
+    bool timing = false;
+    std::vector<inq::EvTriple> ev_pool;
+    size_t ev_used = 0;
+    inq::SpanState *span = nullptr;  // created on first use by the device front end
+};
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (ctx)->last_err = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+            return _e == hipErrorOutOfMemory ? INQ_ERR_NOMEM : INQ_ERR_HIP;                    \
+        }                                                                                      \
+    } while (0)
+
+namespace inq {
+// grows b to at least `bytes` (with headroom); synchronises the device before freeing the old buffer
+int ensure(inq_ctx *c, DevBuf &b, size_t bytes);
+// enqueue-only launch sequence of the locus kernels over a device-resident batch
+int call_batch_device_impl(inq_ctx *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream);
+int status_to_code(uint32_t st);
+void span_state_destroy(SpanState *s);
+}  // namespace inq

@@ -1,0 +1,363 @@
+// span.hip — the device front end behind inq_bgzf_inflate() / inq_call_span() (include/inquistr_hip.h):
+// sequences bgzf_inflate.hip and bam_scan.hip, then hands the device-resident batch to the locus kernels.
+// Three small readbacks per span (record count, CIGAR size, pair count) size the buffers of the next stage.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "ctx.h"
+#include "front_kernels.h"
+
+namespace inq {
+
+struct SpanState {
+    DevBuf comp, blocks, u, block_status, anchors, anchor_cnt, anchor_base, rec_off, reads, info, endpos, pmax, cig_off, cigar,
+        lstart, lend, locus_cnt, locus_off, pair_read, p1, p2, tmp;
+    FrontStatus *d_st = nullptr;
+    struct Host {  // pinned readback area
+        FrontStatus st;
+        DevStatus ks;
+        uint64_t val[4];
+        unsigned long long init_n_valid;
+    } *h = nullptr;
+    hipEvent_t ev[6] = {};
+    bool have_ev = false;
+    // the batch the last inq_call_span built
+    uint64_t n_reads = 0, n_cigar_words = 0, n_pairs = 0, n_loci = 0;
+};
+
+void span_state_destroy(SpanState *S) {
+    if (!S) return;
+    for (DevBuf *b : {&S->comp, &S->blocks, &S->u, &S->block_status, &S->anchors, &S->anchor_cnt, &S->anchor_base, &S->rec_off,
+                      &S->reads, &S->info, &S->endpos, &S->pmax, &S->cig_off, &S->cigar, &S->lstart, &S->lend, &S->locus_cnt,
+                      &S->locus_off, &S->pair_read, &S->p1, &S->p2, &S->tmp})
+        if (b->p) (void)hipFree(b->p);
+    if (S->d_st) (void)hipFree(S->d_st);
+    if (S->h) (void)hipHostFree(S->h);
+    if (S->have_ev)
+        for (auto &e : S->ev) (void)hipEventDestroy(e);
+    delete S;
+}
+
+}  // namespace inq
+
+using namespace inq;
+
+namespace {
+
+int span_state(inq_ctx *c, SpanState **out) {
+    if (!c->span) {
+        SpanState *S = new (std::nothrow) SpanState();
+        if (!S) return INQ_ERR_NOMEM;
+        c->span = S;
+        HIP_TRY(c, hipMalloc((void **)&S->d_st, sizeof(FrontStatus)));
+        HIP_TRY(c, hipHostMalloc((void **)&S->h, sizeof(SpanState::Host), hipHostMallocDefault));
+        for (auto &e : S->ev) HIP_TRY(c, hipEventCreate(&e));
+        S->have_ev = true;
+    }
+    *out = c->span;
+    return INQ_OK;
+}
+
+// host-side shape checks of the block table: everything the inflate grid assumes
+int check_blocks(const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks, uint64_t n_blocks, uint64_t out_bytes,
+                 bool dense) {
+    if (n_blocks && (!blocks || !comp)) return INQ_ERR_ARG;
+    uint64_t next = 0;
+    for (uint64_t i = 0; i < n_blocks; ++i) {
+        const inq_bgzf_block_t &b = blocks[i];
+        if (b.comp_off > comp_bytes || b.comp_len > comp_bytes - b.comp_off) return INQ_ERR_ARG;
+        if (b.isize > 65536u || b.out_off > out_bytes || b.isize > out_bytes - b.out_off) return INQ_ERR_ARG;
+        if (dense && b.out_off != next) return INQ_ERR_ARG;
+        next = b.out_off + b.isize;
+    }
+    return INQ_OK;
+}
+
+// uploads the compressed bytes and the block table, clears the front status, inflates into S->u
+int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks,
+                       uint64_t n_blocks, uint64_t out_bytes, bool want_block_status, hipStream_t s) {
+    int rc;
+    constexpr size_t kPad = 64;
+    if ((rc = ensure(c, S->comp, comp_bytes + kPad)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->blocks, n_blocks * sizeof(inq_bgzf_block_t))) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->u, out_bytes + kPad)) != INQ_OK) return rc;
+    if (want_block_status && (rc = ensure(c, S->block_status, n_blocks * 4)) != INQ_OK) return rc;
+    if (comp_bytes) HIP_TRY(c, hipMemcpyAsync(S->comp.p, comp, comp_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)S->comp.p + comp_bytes, 0, kPad, s));
+    if (n_blocks) HIP_TRY(c, hipMemcpyAsync(S->blocks.p, blocks, n_blocks * sizeof(inq_bgzf_block_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)S->u.p + out_bytes, 0, kPad, s));
+    HIP_TRY(c, hipMemsetAsync(S->d_st, 0, sizeof(FrontStatus), s));
+    HIP_TRY(c, hipMemsetAsync(&S->d_st->first_bad, 0xff, sizeof(unsigned long long), s));
+    HIP_TRY(c, hipEventRecord(S->ev[1], s));
+    InflateArgs ia;
+    ia.comp = (const uint8_t *)S->comp.p;
+    ia.comp_bytes = comp_bytes;
+    ia.blocks = (const inq_bgzf_block_t *)S->blocks.p;
+    ia.n_blocks = n_blocks;
+    ia.out = (uint8_t *)S->u.p;
+    ia.out_bytes = out_bytes;
+    ia.block_status = want_block_status ? (uint32_t *)S->block_status.p : nullptr;
+    ia.err = &S->d_st->inflate;
+    launch_bgzf_inflate(ia, s);
+    HIP_TRY(c, hipGetLastError());
+    return INQ_OK;
+}
+
+int bgzf_inflate_impl(inq_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks, uint64_t n_blocks,
+                      uint8_t *out, uint64_t out_bytes, uint32_t *block_status) {
+    if (!c || (out_bytes && !out)) return INQ_ERR_ARG;
+    int rc = check_blocks(comp, comp_bytes, blocks, n_blocks, out_bytes, false);
+    if (rc != INQ_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    SpanState *S;
+    if ((rc = span_state(c, &S)) != INQ_OK) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = upload_and_inflate(c, S, comp, comp_bytes, blocks, n_blocks, out_bytes, true, s)) != INQ_OK) return rc;
+    if (out_bytes) HIP_TRY(c, hipMemcpyAsync(out, S->u.p, out_bytes, hipMemcpyDeviceToHost, s));
+    if (block_status && n_blocks) HIP_TRY(c, hipMemcpyAsync(block_status, S->block_status.p, n_blocks * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return S->h->st.inflate ? INQ_ERR_INFLATE : INQ_OK;
+}
+
+int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_stats_t *stats) {
+    if (!c || !sp || !r) return INQ_ERR_ARG;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (sp->reserved || sp->reserved2 || sp->unphased > 1 || sp->tid < 0) return INQ_ERR_ARG;
+    if (sp->n_loci && (!sp->locus_start || !sp->locus_end || !r->phase1 || !r->phase2)) return INQ_ERR_ARG;
+    if (sp->n_anchors && !sp->anchors) return INQ_ERR_ARG;
+    if (sp->n_loci >= 0xfffffff0ull) return INQ_ERR_ARG;
+    if (sp->support == 0) return INQ_ERR_SUPPORT_ZERO;
+    const uint64_t nb = sp->n_blocks;
+    const uint64_t u_bytes = nb ? sp->blocks[nb - 1].out_off + sp->blocks[nb - 1].isize : 0;
+    int rc = check_blocks(sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, true);
+    if (rc != INQ_OK) return rc;
+    for (uint64_t i = 0; i < sp->n_anchors; ++i) {
+        if (sp->anchors[i] > u_bytes || (i && sp->anchors[i] <= sp->anchors[i - 1])) return INQ_ERR_ARG;
+    }
+    for (uint64_t j = 0; j < sp->n_loci; ++j)
+        if (sp->locus_start[j] < 10 || sp->locus_end[j] < sp->locus_start[j]) return INQ_ERR_LOCUS;
+    r->n_tie_loci = 0;
+    if (sp->n_loci == 0) return INQ_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    SpanState *S;
+    if ((rc = span_state(c, &S)) != INQ_OK) return rc;
+    hipStream_t s = c->stream;
+    const uint64_t nl = sp->n_loci, na = sp->n_anchors;
+
+    // ---- stage 1: upload, inflate, count the records
+    HIP_TRY(c, hipEventRecord(S->ev[0], s));
+    if ((rc = ensure(c, S->anchors, na * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->anchor_cnt, na * 4)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->anchor_base, (na + 1) * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->lstart, nl * 4)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->lend, nl * 4)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->locus_cnt, nl * 4)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->locus_off, (nl + 1) * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->p1, nl * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->p2, nl * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->tmp, scan_tmp_words(std::max<uint64_t>(std::max(na, nl), 1)) * 8)) != INQ_OK) return rc;
+    if (na) HIP_TRY(c, hipMemcpyAsync(S->anchors.p, sp->anchors, na * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(S->lstart.p, sp->locus_start, nl * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(S->lend.p, sp->locus_end, nl * 4, hipMemcpyHostToDevice, s));
+    if ((rc = upload_and_inflate(c, S, sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, false, s)) != INQ_OK) return rc;
+    HIP_TRY(c, hipEventRecord(S->ev[2], s));
+
+    ScanArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.u = (const uint8_t *)S->u.p;
+    a.u_bytes = u_bytes;
+    a.anchors = (const uint64_t *)S->anchors.p;
+    a.n_anchors = na;
+    a.anchor_cnt = (uint32_t *)S->anchor_cnt.p;
+    a.anchor_base = (uint64_t *)S->anchor_base.p;
+    a.tid = sp->tid;
+    a.unphased = sp->unphased;
+    a.locus_start = (const uint32_t *)S->lstart.p;
+    a.locus_end = (const uint32_t *)S->lend.p;
+    a.n_loci = nl;
+    a.locus_cnt = (uint32_t *)S->locus_cnt.p;
+    a.locus_pair_off = (uint64_t *)S->locus_off.p;
+    a.st = S->d_st;
+    launch_chain_count(a, s);
+    launch_scan_u32_to_u64(a.anchor_cnt, a.anchor_base, na, (uint64_t *)S->tmp.p, s);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&S->h->val[0], a.anchor_base + na, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    auto front_fail = [&](const FrontStatus &st) -> int {
+        if (stats) {
+            stats->front_status = st.err | (st.inflate << 16);
+            stats->first_bad_record = st.first_bad;
+        }
+        if (st.inflate) return INQ_ERR_INFLATE;
+        if (st.err & (FS_CHAIN | FS_RECORD | FS_UNSORTED | FS_TOO_BIG)) return INQ_ERR_BAM;
+        if (st.err & (FS_HP_TYPE | FS_SA_TYPE | FS_SA_FORMAT)) return INQ_ERR_AUX;
+        return INQ_OK;
+    };
+    if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
+    const uint64_t n_rec = S->h->val[0];
+
+    // ---- stage 2: record offsets, fields, CIGAR sizes
+    if ((rc = ensure(c, S->rec_off, n_rec * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->reads, n_rec * sizeof(inq_read_t))) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->info, n_rec * sizeof(RecInfo))) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->endpos, n_rec * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->pmax, n_rec * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->cig_off, (n_rec + 1) * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->tmp, scan_tmp_words(std::max<uint64_t>(std::max(std::max(na, nl), n_rec), 1)) * 8)) != INQ_OK) return rc;
+    a.rec_off = (uint64_t *)S->rec_off.p;
+    a.n_records = n_rec;
+    a.reads = (inq_read_t *)S->reads.p;
+    a.info = (RecInfo *)S->info.p;
+    a.endpos = (int64_t *)S->endpos.p;
+    a.pmax = (int64_t *)S->pmax.p;
+    a.cig_off = (uint64_t *)S->cig_off.p;
+    S->h->init_n_valid = n_rec;
+    HIP_TRY(c, hipMemcpyAsync(&S->d_st->n_valid, &S->h->init_n_valid, 8, hipMemcpyHostToDevice, s));
+    launch_chain_fill(a, s);
+    launch_record_parse(a, s);
+    launch_scan_cigar_units(a.reads, &S->d_st->n_valid, a.cig_off, n_rec, (uint64_t *)S->tmp.p, s);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&S->h->val[1], a.cig_off + n_rec, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
+    const uint64_t n_valid = S->h->st.n_valid, n_units = S->h->val[1];
+    if (n_valid > n_rec || n_valid >= 0xfffffff0ull || n_units >= 0xffffffffull) {
+        if (stats) stats->front_status = FS_TOO_BIG;
+        return INQ_ERR_BAM;
+    }
+
+    // ---- stage 3: CIGAR gather, reference spans, overlap join (count)
+    if ((rc = ensure(c, S->cigar, n_units * 16)) != INQ_OK) return rc;
+    a.cigar = (uint32_t *)S->cigar.p;
+    a.n_cigar_units = n_units;
+    launch_cigar_gather(a, n_valid, s);
+    launch_scan_max_i64(a.endpos, a.pmax, n_valid, (uint64_t *)S->tmp.p, s);
+    HIP_TRY(c, hipEventRecord(S->ev[3], s));
+    launch_join_count(a, n_valid, s);
+    launch_scan_u32_to_u64(a.locus_cnt, a.locus_pair_off, nl, (uint64_t *)S->tmp.p, s);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&S->h->val[2], a.locus_pair_off + nl, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
+    const uint64_t n_pairs = S->h->val[2];
+    if (n_pairs >= (1ull << 40)) return INQ_ERR_ARG;
+
+    // ---- stage 4: pairs, then the locus kernels on the device-resident batch
+    if ((rc = ensure(c, S->pair_read, n_pairs * 4)) != INQ_OK) return rc;
+    a.pair_read = (uint32_t *)S->pair_read.p;
+    launch_join_fill(a, n_valid, s);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(S->ev[4], s));
+    inq_batch_t db;
+    std::memset(&db, 0, sizeof db);
+    db.n_reads = n_valid;
+    db.n_cigar_words = n_units * 4;
+    db.n_pairs = n_pairs;
+    db.n_loci = nl;
+    db.cigar = a.cigar;
+    db.reads = a.reads;
+    db.pair_read = a.pair_read;
+    db.locus_pair_off = a.locus_pair_off;
+    db.locus_start = a.locus_start;
+    db.locus_end = a.locus_end;
+    db.minlen = sp->minlen;
+    db.support = sp->support;
+    db.unphased = sp->unphased;
+    inq_result_t dr;
+    dr.phase1 = (double *)S->p1.p;
+    dr.phase2 = (double *)S->p2.p;
+    dr.pair_call = nullptr;
+    dr.pair_bits = nullptr;
+    dr.n_tie_loci = 0;
+    c->call_hint = std::max<uint32_t>(S->h->st.max_reads, 1u);
+    if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
+    HIP_TRY(c, hipEventRecord(S->ev[5], s));
+    HIP_TRY(c, hipMemcpyAsync(r->phase1, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(r->phase2, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&S->h->ks, c->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemsetAsync(&c->d_status->err, 0, sizeof(unsigned int), s));
+    HIP_TRY(c, hipMemsetAsync(&c->d_status->ties, 0, sizeof(unsigned long long), s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    S->n_reads = n_valid;
+    S->n_cigar_words = n_units * 4;
+    S->n_pairs = n_pairs;
+    S->n_loci = nl;
+    if (stats) {
+        stats->n_records = n_rec;
+        stats->n_reads = n_valid;
+        stats->n_pairs = n_pairs;
+        stats->n_cigar_words = n_units * 4;
+        stats->inflated_bytes = u_bytes;
+        stats->max_reads = S->h->st.max_reads;
+        float ms = 0.f;
+        auto el = [&](int i, int j) {
+            ms = 0.f;
+            (void)hipEventElapsedTime(&ms, S->ev[i], S->ev[j]);
+            return (double)ms;
+        };
+        stats->ms_upload = el(0, 1);
+        stats->ms_inflate = el(1, 2);
+        stats->ms_scan = el(2, 3);
+        stats->ms_join = el(3, 4);
+        stats->ms_call = el(4, 5);
+    }
+    r->n_tie_loci = S->h->ks.ties;
+    if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
+    return status_to_code(S->h->ks.err);
+}
+
+int fetch_batch_impl(inq_ctx *c, uint32_t *cigar, inq_read_t *reads, uint32_t *pair_read, uint64_t *locus_pair_off) {
+    if (!c || !c->span) return INQ_ERR_ARG;
+    SpanState *S = c->span;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (cigar && S->n_cigar_words) HIP_TRY(c, hipMemcpy(cigar, S->cigar.p, S->n_cigar_words * 4, hipMemcpyDeviceToHost));
+    if (reads && S->n_reads) HIP_TRY(c, hipMemcpy(reads, S->reads.p, S->n_reads * sizeof(inq_read_t), hipMemcpyDeviceToHost));
+    if (pair_read && S->n_pairs) HIP_TRY(c, hipMemcpy(pair_read, S->pair_read.p, S->n_pairs * 4, hipMemcpyDeviceToHost));
+    if (locus_pair_off && S->n_loci) HIP_TRY(c, hipMemcpy(locus_pair_off, S->locus_off.p, (S->n_loci + 1) * 8, hipMemcpyDeviceToHost));
+    return INQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int inq_bgzf_inflate(inq_ctx_t *c, const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks, uint64_t n_blocks,
+                     uint8_t *out, uint64_t out_bytes, uint32_t *block_status) {
+    try {  // nothing may unwind across the C ABI
+        return bgzf_inflate_impl(c, comp, comp_bytes, blocks, n_blocks, out, out_bytes, block_status);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
+int inq_call_span(inq_ctx_t *c, const inq_span_t *span, inq_result_t *result, inq_span_stats_t *stats) {
+    try {
+        return call_span_impl(c, span, result, stats);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
+int inq_span_fetch_batch(inq_ctx_t *c, uint32_t *cigar, inq_read_t *reads, uint32_t *pair_read, uint64_t *locus_pair_off) {
+    try {
+        return fetch_batch_impl(c, cigar, reads, pair_read, locus_pair_off);
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
+}  // extern "C"

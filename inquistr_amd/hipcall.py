@@ -12,6 +12,9 @@ from typing import Optional, Tuple
 import numpy as np
 
 from .batch import (
+    INQ_ERR_AUX,
+    INQ_ERR_BAM,
+    INQ_ERR_INFLATE,
     INQ_ERR_NO_DEVICE,
     INQ_OK,
     Batch,
@@ -40,7 +43,88 @@ ABI_SYMBOLS = (
     "inq_backend_name",
     "inq_last_error",
     "inq_abi_version",
+    "inq_bgzf_inflate",
+    "inq_call_span",
+    "inq_span_fetch_batch",
 )
+
+
+class BgzfBlockC(C.Structure):
+    """inq_bgzf_block_t"""
+
+    _fields_ = [("comp_off", C.c_uint64), ("comp_len", C.c_uint32), ("isize", C.c_uint32), ("out_off", C.c_uint64)]
+
+
+BGZF_BLOCK_DTYPE = np.dtype([("comp_off", "<u8"), ("comp_len", "<u4"), ("isize", "<u4"), ("out_off", "<u8")])
+
+
+class SpanC(C.Structure):
+    """inq_span_t"""
+
+    _fields_ = [
+        ("comp", C.c_void_p),
+        ("comp_bytes", C.c_uint64),
+        ("blocks", C.c_void_p),
+        ("n_blocks", C.c_uint64),
+        ("anchors", C.c_void_p),
+        ("n_anchors", C.c_uint64),
+        ("tid", C.c_int32),
+        ("reserved", C.c_uint32),
+        ("locus_start", C.c_void_p),
+        ("locus_end", C.c_void_p),
+        ("n_loci", C.c_uint64),
+        ("minlen", C.c_uint32),
+        ("support", C.c_uint32),
+        ("unphased", C.c_uint32),
+        ("reserved2", C.c_uint32),
+    ]
+
+
+class SpanStatsC(C.Structure):
+    """inq_span_stats_t"""
+
+    _fields_ = [
+        ("n_records", C.c_uint64),
+        ("n_reads", C.c_uint64),
+        ("n_pairs", C.c_uint64),
+        ("n_cigar_words", C.c_uint64),
+        ("inflated_bytes", C.c_uint64),
+        ("max_reads", C.c_uint32),
+        ("front_status", C.c_uint32),
+        ("first_bad_record", C.c_uint64),
+        ("ms_upload", C.c_double),
+        ("ms_inflate", C.c_double),
+        ("ms_scan", C.c_double),
+        ("ms_join", C.c_double),
+        ("ms_call", C.c_double),
+    ]
+
+
+def scan_bgzf(data) -> np.ndarray:
+    """Walks the BGZF headers of `data` (whole blocks): the block table inq_bgzf_inflate / inq_call_span take
+    (payload offset and length, ISIZE, dense output offsets)."""
+    mv = memoryview(data)
+    out = []
+    p, uo = 0, 0
+    while p < len(mv):
+        if p + 18 > len(mv) or mv[p] != 0x1F or mv[p + 1] != 0x8B or mv[p + 2] != 8 or not (mv[p + 3] & 4):
+            raise ValueError(f"not a BGZF block at {p}")
+        xlen = mv[p + 10] | (mv[p + 11] << 8)
+        bsize = None
+        q = p + 12
+        while q + 4 <= p + 12 + xlen:
+            slen = mv[q + 2] | (mv[q + 3] << 8)
+            if mv[q] == 66 and mv[q + 1] == 67 and slen == 2:
+                bsize = (mv[q + 4] | (mv[q + 5] << 8)) + 1
+            q += 4 + slen
+        if bsize is None or p + bsize > len(mv):
+            raise ValueError(f"bad BGZF block at {p}")
+        head = 12 + xlen
+        isize = int.from_bytes(mv[p + bsize - 4 : p + bsize], "little")
+        out.append((p + head, bsize - head - 8, isize, uo))
+        uo += isize
+        p += bsize
+    return np.array(out, dtype=BGZF_BLOCK_DTYPE)
 
 
 class InqError(RuntimeError):
@@ -106,6 +190,12 @@ def load(path: Optional[str] = None):
     L.inq_last_error.argtypes = [vp]
     L.inq_abi_version.restype = C.c_int
     L.inq_abi_version.argtypes = []
+    L.inq_bgzf_inflate.restype = C.c_int
+    L.inq_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp]
+    L.inq_call_span.restype = C.c_int
+    L.inq_call_span.argtypes = [vp, C.POINTER(SpanC), C.POINTER(InqResultC), C.POINTER(SpanStatsC)]
+    L.inq_span_fetch_batch.restype = C.c_int
+    L.inq_span_fetch_batch.argtypes = [vp, vp, vp, vp, vp]
     if path is None:
         _lib = L
     return L
@@ -166,6 +256,52 @@ class Context:
         rc = self._L.inq_call_batch_device(self._h, C.byref(bc), C.byref(rc_), C.c_void_p(stream or 0))
         if rc != INQ_OK:
             self._raise(rc)
+
+    def bgzf_inflate(self, comp, blocks: np.ndarray, check: bool = True):
+        """inq_bgzf_inflate on host buffers: returns (code, inflated bytes as uint8 array, per-block status)."""
+        comp = np.frombuffer(comp, dtype=np.uint8)
+        blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK_DTYPE)
+        n = len(blocks)
+        total = int((blocks["out_off"] + blocks["isize"]).max()) if n else 0
+        out = np.zeros(total, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.uint32)
+        rc = self._L.inq_bgzf_inflate(self._h, comp.ctypes.data, comp.size, blocks.ctypes.data, n, out.ctypes.data, total,
+                                      status.ctypes.data)
+        if rc != INQ_OK and check:
+            self._raise(rc)
+        return rc, out, status
+
+    def call_span(self, comp, blocks: np.ndarray, anchors: np.ndarray, tid: int, locus_start: np.ndarray,
+                  locus_end: np.ndarray, minlen: int = 5, support: int = 3, unphased: bool = False, check: bool = True):
+        """inq_call_span: returns (code, phase1, phase2, n_tie_loci, stats)."""
+        comp = np.frombuffer(comp, dtype=np.uint8)
+        blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK_DTYPE)
+        anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
+        ls = np.ascontiguousarray(locus_start, dtype=np.uint32)
+        le = np.ascontiguousarray(locus_end, dtype=np.uint32)
+        sp = SpanC(comp.ctypes.data, comp.size, blocks.ctypes.data, len(blocks), anchors.ctypes.data, len(anchors), tid, 0,
+                   ls.ctypes.data, le.ctypes.data, len(ls), minlen, support, 1 if unphased else 0, 0)
+        p1 = np.full(len(ls), np.nan)
+        p2 = np.full(len(ls), np.nan)
+        res = InqResultC(p1.ctypes.data, p2.ctypes.data, None, None, 0)
+        stats = SpanStatsC()
+        rc = self._L.inq_call_span(self._h, C.byref(sp), C.byref(res), C.byref(stats))
+        if rc != INQ_OK and check:
+            self._raise(rc)
+        return rc, p1, p2, int(res.n_tie_loci), stats
+
+    def span_fetch_batch(self, stats: "SpanStatsC", n_loci: int):
+        """The batch the last call_span built on the device, as host arrays (cigar, reads, pair_read, locus_pair_off)."""
+        from .batch import READ_DTYPE
+
+        cigar = np.zeros(int(stats.n_cigar_words), dtype=np.uint32)
+        reads = np.zeros(int(stats.n_reads), dtype=READ_DTYPE)
+        pair_read = np.zeros(int(stats.n_pairs), dtype=np.uint32)
+        off = np.zeros(n_loci + 1, dtype=np.uint64)
+        rc = self._L.inq_span_fetch_batch(self._h, cigar.ctypes.data, reads.ctypes.data, pair_read.ctypes.data, off.ctypes.data)
+        if rc != INQ_OK:
+            self._raise(rc)
+        return cigar, reads, pair_read, off
 
     def status(self) -> Tuple[int, int]:
         ties = C.c_uint64(0)
