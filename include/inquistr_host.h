@@ -37,7 +37,7 @@ typedef struct inq_call_args {
     const char *sample_name; /* --sample-name, NULL if absent */
     const char *reference;   /* --reference (CRAM only; CRAM is not supported here) */
     int32_t device;          /* HIP device ordinal (not a reference argument) */
-    int32_t reserved;
+    int32_t reserved;        /* front end: 0 = default (env INQ_FRONTEND=host|device), 1 = host sweep, 2 = device spans */
 } inq_call_args_t;
 
 #define INQ_EXIT_OK 0
@@ -60,6 +60,20 @@ int inq_frontend_next(inq_frontend_t *fe, inq_batch_t *batch, const uint32_t **l
                       size_t errcap);
 void inq_frontend_set_batch_words(inq_frontend_t *fe, uint64_t max_cigar_words);
 void inq_frontend_close(inq_frontend_t *fe);
+
+/* ---- spans: host half of the DEVICE front end (inq_call_span in inquistr_hip.h), no GPU involved ----
+ * Cuts the targets into spans (loci of one contig + the whole BGZF blocks holding every record that
+ * overlaps them, found through the .bai), reads the compressed bytes and builds the block table and the
+ * record-start anchors.  max_comp_bytes = 0 takes the default (256 MiB, env INQ_SPAN_MB). */
+typedef struct inq_spans inq_spans_t;
+int inq_spans_open(const inq_call_args_t *args, uint64_t max_comp_bytes, inq_spans_t **out, char *errbuf, size_t errcap);
+uint64_t inq_spans_n_targets(const inq_spans_t *s);
+/* Next span: 1 = *span filled (host pointers, valid until the next call), 0 = no more, <0 = exit status
+ * negated.  locus_index[j] = position of span locus j in the target list; targets that appear in no span
+ * have no record anywhere near (rows NaN NaN).  file_begin = file offset of span->comp[0]. */
+int inq_spans_next(inq_spans_t *s, inq_span_t *span, const uint32_t **locus_index, uint64_t *file_begin, char *errbuf,
+                   size_t errcap);
+void inq_spans_close(inq_spans_t *s);
 
 /* `inquiSTR combine` (src/combine.rs:27-59): column-wise paste of N .inq files — every line of the first
  * file, then columns 4.. of the same line of each other file, tab-joined.  Files ending in ".gz" are

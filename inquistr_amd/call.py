@@ -39,6 +39,10 @@ HOST_ABI_SYMBOLS = (
     "inq_host_bai_stats",
     "inq_host_bai_file_offset",
     "inq_host_bam_tid",
+    "inq_spans_open",
+    "inq_spans_n_targets",
+    "inq_spans_next",
+    "inq_spans_close",
 )
 
 
@@ -113,11 +117,25 @@ def load():
         L.inq_host_bam_tid.argtypes = [C.c_char_p, C.c_char_p]
         L.inq_host_bai_stats.restype = C.c_int
         L.inq_host_bai_stats.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        from .hipcall import SpanC
+
+        L.inq_spans_open.restype = C.c_int
+        L.inq_spans_open.argtypes = [C.POINTER(CallArgsC), C.c_uint64, C.POINTER(vp), C.c_char_p, C.c_size_t]
+        L.inq_spans_n_targets.restype = C.c_uint64
+        L.inq_spans_n_targets.argtypes = [vp]
+        L.inq_spans_next.restype = C.c_int
+        L.inq_spans_next.argtypes = [vp, C.POINTER(SpanC), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+        L.inq_spans_close.restype = None
+        L.inq_spans_close.argtypes = [vp]
         _lib = L
     return _lib
 
 
-def _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, reference, device=0) -> CallArgsC:
+FRONTENDS = {None: 0, "host": 1, "device": 2}
+
+
+def _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, reference, device=0,
+          frontend=None) -> CallArgsC:
     a = CallArgsC()
     a.bam = os.fspath(bamp).encode()
     a.region = region.encode() if region is not None else None
@@ -127,15 +145,18 @@ def _args(bamp, region, region_file, minlen, support, threads, unphased, sample_
     a.sample_name = sample_name.encode() if sample_name is not None else None
     a.reference = reference.encode() if reference is not None else None
     a.device = device
+    a.reserved = FRONTENDS[frontend]
     return a
 
 
 def genotype_repeats(bamp: str, region: Optional[str], region_file: Optional[str], minlen: int = 5, support: int = 3,
                      threads: int = 1, unphased: bool = False, sample_name: Optional[str] = None,
-                     reference: Optional[str] = None, out=None, device: int = 0) -> None:
-    """src/call.rs:76-86: same parameters, same output; raises CallError instead of exiting."""
+                     reference: Optional[str] = None, out=None, device: int = 0, frontend: Optional[str] = None) -> None:
+    """src/call.rs:76-86: same parameters, same output; raises CallError instead of exiting.
+    frontend: "host" (BGZF inflate + record decode on CPU threads), "device" (inq_call_span: both on the GPU)
+    or None (env INQ_FRONTEND, else the library default)."""
     L = load()
-    a = _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, reference, device)
+    a = _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, reference, device, frontend)
     err = C.create_string_buffer(2048)
     out = sys.stdout if out is None else out
     out.flush()
@@ -216,6 +237,66 @@ class FrontEnd:
     def close(self):
         if self._h and self._h.value:
             self._L.inq_frontend_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Spans:
+    """Host half of the device front end (inq_spans_*): yields, per span, everything inq_call_span takes.
+    No GPU involved."""
+
+    def __init__(self, bamp, region=None, region_file=None, minlen=5, support=3, threads=1, unphased=False,
+                 max_comp_bytes: int = 0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self._args = _args(bamp, region, region_file, minlen, support, threads, unphased, None, None)
+        err = C.create_string_buffer(2048)
+        rc = self._L.inq_spans_open(C.byref(self._args), max_comp_bytes, C.byref(self._h), err, len(err))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise CallError(rc, err.value.decode(errors="replace"))
+
+    @property
+    def n_targets(self) -> int:
+        return int(self._L.inq_spans_n_targets(self._h))
+
+    def spans(self):
+        """Yields dicts of numpy copies: comp (u8), blocks, anchors (u64), tid, locus_start/end, locus_index, file_begin."""
+        from .hipcall import BGZF_BLOCK_DTYPE, SpanC
+
+        while True:
+            sp = SpanC()
+            idx = C.POINTER(C.c_uint32)()
+            fb = C.c_uint64(0)
+            err = C.create_string_buffer(2048)
+            rc = self._L.inq_spans_next(self._h, C.byref(sp), C.byref(idx), C.byref(fb), err, len(err))
+            if rc < 0:
+                raise CallError(-rc, err.value.decode(errors="replace"))
+            if rc == 0:
+                return
+
+            def arr(ptr, n, dt):
+                if not n:
+                    return np.zeros(0, dtype=dt)
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
+
+            n = int(sp.n_loci)
+            yield dict(
+                comp=arr(sp.comp, sp.comp_bytes, np.uint8), blocks=arr(sp.blocks, sp.n_blocks, BGZF_BLOCK_DTYPE),
+                anchors=arr(sp.anchors, sp.n_anchors, np.uint64), tid=int(sp.tid),
+                locus_start=arr(sp.locus_start, n, np.uint32), locus_end=arr(sp.locus_end, n, np.uint32),
+                locus_index=np.ctypeslib.as_array(idx, shape=(max(n, 1),))[:n].copy(), file_begin=int(fb.value),
+                minlen=int(sp.minlen), support=int(sp.support), unphased=bool(sp.unphased),
+            )
+
+    def close(self):
+        if self._h and self._h.value:
+            self._L.inq_spans_close(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

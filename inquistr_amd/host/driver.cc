@@ -23,9 +23,14 @@
 #include "front_end.h"
 #include "inq_text.h"
 #include "sa2d.h"
+#include "span_planner.h"
 #include "targets.h"
 
 using namespace inqhost;
+
+#ifndef INQ_DEFAULT_DEVICE_FRONT
+#define INQ_DEFAULT_DEVICE_FRONT false
+#endif
 
 namespace {
 
@@ -243,6 +248,139 @@ private:
     std::string err_;
 };
 
+// Device front end, host half: a loader thread plans the spans, reads their compressed bytes (parallel pread
+// into page-locked buffers when a HIP device is there) and builds block tables and anchors, two spans ahead
+// of the caller, who feeds inq_call_span().
+class SpanPipeline {
+public:
+    struct Item {
+        SpanPlan plan;
+        SpanData data;
+        uint8_t *buf = nullptr;
+        size_t cap = 0;
+        bool pinned = false;
+    };
+    SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
+                 uint64_t max_comp_bytes, int n_threads, bool pinned)
+        : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned) {
+        for (auto &it : slots_) free_.push_back(&it);
+        th_ = std::thread([this] { run(); });
+    }
+    ~SpanPipeline() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_free_.notify_all();
+        th_.join();
+        for (auto &it : slots_) release_buf(it);
+    }
+    // 1 = item, 0 = done, -1 = error
+    int next(Item *&out, std::string *err) {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_item_.wait(g, [&] { return !ready_.empty() || done_ || failed_; });
+        if (!ready_.empty()) {
+            out = ready_.front();
+            ready_.pop_front();
+            return 1;
+        }
+        if (failed_) {
+            *err = err_;
+            return -1;
+        }
+        return 0;
+    }
+    void release(Item *it) {
+        std::lock_guard<std::mutex> g(mu_);
+        free_.push_back(it);
+        cv_free_.notify_one();
+    }
+
+private:
+    void release_buf(Item &it) {
+        if (it.buf) {
+            if (it.pinned) inq_free_pinned(it.buf);
+            else std::free(it.buf);
+        }
+        it.buf = nullptr;
+        it.cap = 0;
+    }
+    bool fit(Item &it, size_t bytes) {
+        if (bytes <= it.cap && it.buf) return true;
+        release_buf(it);
+        const size_t want = bytes + bytes / 4 + (1u << 20);
+        void *p = nullptr;
+        if (pinned_ && inq_alloc_pinned(want, &p) == INQ_OK) it.pinned = true;
+        else {
+            p = std::malloc(want);
+            it.pinned = false;
+        }
+        it.buf = (uint8_t *)p;
+        it.cap = p ? want : 0;
+        return p != nullptr;
+    }
+    void fail(const std::string &m) {
+        std::lock_guard<std::mutex> g(mu_);
+        failed_ = true;
+        err_ = m;
+        cv_item_.notify_all();
+    }
+    void run() {
+        SpanLoader loader;
+        std::string e;
+        if (!loader.open(path_, &e)) return fail(e);
+        for (;;) {
+            Item *it = nullptr;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_free_.wait(g, [&] { return !free_.empty() || stop_; });
+                if (stop_) return;
+                it = free_.back();
+                free_.pop_back();
+            }
+            if (!planner_.next(it->plan)) break;
+            uint64_t b = 0, en = 0;
+            if (!loader.extent(it->plan, &b, &en, &e)) return fail(e);
+            if (en - b > (64ull << 30)) return fail("a span of the BAM exceeds 64 GiB (index without usable bins)");
+            if (!fit(*it, (size_t)(en - b) + 64)) return fail("cannot allocate the span buffer");
+            if (!loader.load(it->plan, planner_.anchors(), b, en, it->buf, n_threads_, it->data, &e)) return fail(e);
+            std::lock_guard<std::mutex> g(mu_);
+            ready_.push_back(it);
+            cv_item_.notify_one();
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        done_ = true;
+        cv_item_.notify_all();
+    }
+
+    std::string path_;
+    SpanPlanner planner_;
+    int n_threads_;
+    bool pinned_;
+    Item slots_[3];
+    std::vector<Item *> free_;
+    std::deque<Item *> ready_;
+    std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_item_, cv_free_;
+    bool stop_ = false, done_ = false, failed_ = false;
+    std::string err_;
+};
+
+static uint64_t span_bytes_from_env() {
+    const char *e = std::getenv("INQ_SPAN_MB");
+    const long v = e ? std::atol(e) : 0;
+    return v > 0 ? (uint64_t)v << 20 : (256ull << 20);
+}
+
+struct inq_spans {
+    Prepared P;
+    std::unique_ptr<SpanPipeline> pipe;
+    SpanPipeline::Item *cur = nullptr;
+    uint32_t minlen = 5, support = 3;
+    bool unphased = false;
+};
+
 struct inq_frontend {
     Prepared P;
     std::unique_ptr<FrontEnd> fe;           // threads <= 1: one sweep on the caller's thread
@@ -329,6 +467,117 @@ static int inq_frontend_next_impl(inq_frontend_t *fe, inq_batch_t *batch, const 
 
 void inq_frontend_close(inq_frontend_t *fe) { delete fe; }
 
+// front end selection: args->reserved 1 = host sweep (BGZF inflate + record decode on CPU threads),
+// 2 = device (inq_call_span); 0 = INQ_FRONTEND=host|device, else the default
+static bool use_device_front(const inq_call_args_t *args) {
+    if (args->reserved == 1) return false;
+    if (args->reserved == 2) return true;
+    const char *e = std::getenv("INQ_FRONTEND");
+    if (e && std::strcmp(e, "host") == 0) return false;
+    if (e && std::strcmp(e, "device") == 0) return true;
+    return INQ_DEFAULT_DEVICE_FRONT;
+}
+
+// fills p1 / p2 through the device front end; returns an exit status
+static int run_device_front(const inq_call_args_t *args, inq_frontend *F, std::vector<double> &p1, std::vector<double> &p2,
+                            char *errbuf, size_t errcap, double *t_front, double *t_dev) {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const int timing = std::getenv("INQ_TIMING") ? (std::getenv("INQ_TIMING")[0] == '2' ? 2 : 1) : 0;
+    inq_ctx_t *ctx = nullptr;
+    int hrc = INQ_OK;
+    std::thread ctx_thread([&] { hrc = inq_ctx_create(args->device, &ctx); });
+    struct CtxGuard {
+        inq_ctx_t *&c;
+        std::thread &t;
+        ~CtxGuard() {
+            if (t.joinable()) t.join();
+            inq_ctx_destroy(c);
+        }
+    } cg{ctx, ctx_thread};
+    const int n_io = (int)std::max<uint64_t>(1, std::min<uint64_t>(args->threads, 32));
+    std::vector<double> b1, b2;
+    {
+        SpanPipeline pipe(args->bam, *F->P.bam, F->P.targets, span_bytes_from_env(), n_io, true);
+        bool joined = false;
+        for (;;) {
+            SpanPipeline::Item *it = nullptr;
+            std::string ferr;
+            auto ta = clk::now();
+            int nb = pipe.next(it, &ferr);
+            auto tb = clk::now();
+            *t_front += secs(ta, tb);
+            if (nb < 0) {
+                set_err(errbuf, errcap, ferr);
+                return INQ_EXIT_PANIC;  // read errors are expect()/unwrap() panics in the reference (:294,346)
+            }
+            if (nb == 0) break;
+            if (!joined) {
+                ctx_thread.join();
+                joined = true;
+            }
+            if (hrc != INQ_OK) {
+                set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
+                return INQ_EXIT_ERROR;
+            }
+            inq_span_t sp;
+            std::memset(&sp, 0, sizeof sp);
+            sp.comp = it->buf;
+            sp.comp_bytes = it->data.comp_bytes;
+            sp.blocks = it->data.blocks.data();
+            sp.n_blocks = it->data.blocks.size();
+            sp.anchors = it->data.anchors.data();
+            sp.n_anchors = it->data.anchors.size();
+            sp.tid = it->plan.tid;
+            sp.locus_start = it->plan.locus_start.data();
+            sp.locus_end = it->plan.locus_end.data();
+            sp.n_loci = it->plan.locus_start.size();
+            sp.minlen = F->minlen;
+            sp.support = F->support;
+            sp.unphased = F->unphased ? 1u : 0u;
+            b1.assign(sp.n_loci, NAN);
+            b2.assign(sp.n_loci, NAN);
+            inq_result_t res;
+            std::memset(&res, 0, sizeof res);
+            res.phase1 = b1.data();
+            res.phase2 = b2.data();
+            inq_span_stats_t stt;
+            int rc2 = inq_call_span(ctx, &sp, &res, &stt);
+            *t_dev += secs(tb, clk::now());
+            if (timing == 2)
+                std::fprintf(stderr,
+                             "[inq span] loci %llu comp %.1f MB -> %.1f MB, %llu records, %llu pairs | upload %.2f inflate %.2f scan %.2f "
+                             "join %.2f call %.2f ms | wall %.2f ms\n",
+                             (unsigned long long)sp.n_loci, sp.comp_bytes / 1e6, stt.inflated_bytes / 1e6,
+                             (unsigned long long)stt.n_records, (unsigned long long)stt.n_pairs, stt.ms_upload, stt.ms_inflate,
+                             stt.ms_scan, stt.ms_join, stt.ms_call, secs(tb, clk::now()) * 1e3);
+            if (rc2 != INQ_OK) {
+                std::string m = std::string("device call failed: ") + inq_strerror(rc2);
+                if (rc2 == INQ_ERR_HIP) m += std::string(" [") + inq_last_error(ctx) + "]";
+                if (rc2 == INQ_ERR_BAM || rc2 == INQ_ERR_AUX || rc2 == INQ_ERR_INFLATE)
+                    m += " (status " + std::to_string(stt.front_status) + ", record " + std::to_string(stt.first_bad_record) +
+                         " of the span at file offset " + std::to_string(it->data.file_begin) + ")";
+                set_err(errbuf, errcap, m);
+                return (rc2 == INQ_ERR_HIP || rc2 == INQ_ERR_NOMEM || rc2 == INQ_ERR_NO_DEVICE) ? INQ_EXIT_ERROR : INQ_EXIT_PANIC;
+            }
+            for (uint64_t j = 0; j < sp.n_loci; ++j) {
+                p1[it->plan.locus_index[j]] = b1[j];
+                p2[it->plan.locus_index[j]] = b2[j];
+            }
+            pipe.release(it);
+        }
+        if (!joined) ctx_thread.join();
+    }
+    if (hrc != INQ_OK) {  // no GPU is an error even for an empty target list
+        set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
+        return INQ_EXIT_ERROR;
+    }
+    return INQ_EXIT_OK;
+}
+
+static int write_rows(const inq_call_args_t *args, inq_frontend *F, const std::vector<double> &p1, const std::vector<double> &p2,
+                      int out_fd, char *errbuf, size_t errcap);
+
 static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
     using clk = std::chrono::steady_clock;
     const bool timing = std::getenv("INQ_TIMING") != nullptr;
@@ -341,6 +590,16 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     std::unique_ptr<inq_frontend> guard(F);
     const size_t n = F->P.targets.size();
     std::vector<double> p1(n, NAN), p2(n, NAN);
+
+    if (use_device_front(args)) {
+        int drc = run_device_front(args, F, p1, p2, errbuf, errcap, &t_front, &t_dev);
+        if (drc != INQ_EXIT_OK) return drc;
+        drc = write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
+        if (timing)
+            std::fprintf(stderr, "[inq timing] device front end: waiting for spans %.3fs  device calls %.3fs  total %.3fs\n", t_front,
+                         t_dev, secs(t_start, clk::now()));
+        return drc;
+    }
 
     auto t_prep = clk::now();
     // HIP runtime start-up (~0.2 s) overlaps the first BAM sweeps
@@ -456,6 +715,19 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     }
     if (!need_ctx()) return INQ_EXIT_ERROR;  // no GPU is an error even for an empty target list
 
+    {
+        int wrc = write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
+        if (wrc != INQ_EXIT_OK) return wrc;
+    }
+    if (timing)
+        std::fprintf(stderr, "[inq timing] open+targets %.3fs  hip ctx %.3fs  front end %.3fs  device calls %.3fs  total %.3fs\n",
+                     secs(t_start, t_prep), secs(t_prep, t_ctx), t_front, t_dev, secs(t_start, clk::now()));
+    return INQ_EXIT_OK;
+}
+
+static int write_rows(const inq_call_args_t *args, inq_frontend *F, const std::vector<double> &p1, const std::vector<double> &p2,
+                      int out_fd, char *errbuf, size_t errcap) {
+    const size_t n = F->P.targets.size();
     // output, src/call.rs:137-157
     std::vector<uint32_t> order(n);
     for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
@@ -486,9 +758,6 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
         set_err(errbuf, errcap, "Failed writing the result.");
         return INQ_EXIT_PANIC;
     }
-    if (timing)
-        std::fprintf(stderr, "[inq timing] open+targets %.3fs  hip ctx %.3fs  front end %.3fs  device calls %.3fs  total %.3fs\n",
-                     secs(t_start, t_prep), secs(t_prep, t_ctx), t_front, t_dev, secs(t_start, clk::now()));
     return INQ_EXIT_OK;
 }
 
@@ -620,6 +889,75 @@ int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, 
 }
 int inq_combine(const char *const *files, size_t n_files, int out_fd, char *errbuf, size_t errcap) {
     INQ_GUARD(inq_combine_impl(files, n_files, out_fd, errbuf, errcap), errbuf, errcap)
+}
+
+// ---- spans: the host half of the device front end, on its own (no GPU involved) ----
+static int inq_spans_open_impl(const inq_call_args_t *args, uint64_t max_comp_bytes, inq_spans_t **out, char *errbuf, size_t errcap) {
+    if (!out) return INQ_EXIT_ERROR;
+    *out = nullptr;
+    std::unique_ptr<inq_spans> S(new inq_spans());
+    std::string msg;
+    int rc = prepare(args, S->P, msg);
+    if (rc != INQ_EXIT_OK) {
+        set_err(errbuf, errcap, msg);
+        return rc;
+    }
+    S->minlen = args->minlen;
+    S->support = (uint32_t)std::min<uint64_t>(args->support, 0xffffffffull);
+    S->unphased = args->unphased != 0;
+    S->pipe.reset(new SpanPipeline(args->bam, *S->P.bam, S->P.targets, max_comp_bytes ? max_comp_bytes : span_bytes_from_env(),
+                                   (int)std::max<uint64_t>(1, std::min<uint64_t>(args->threads, 32)), false));
+    *out = S.release();
+    return INQ_EXIT_OK;
+}
+
+static int inq_spans_next_impl(inq_spans_t *S, inq_span_t *sp, const uint32_t **locus_index, uint64_t *file_begin, char *errbuf,
+                               size_t errcap) {
+    if (!S || !sp) return -INQ_EXIT_ERROR;
+    if (S->cur) S->pipe->release(S->cur);
+    S->cur = nullptr;
+    std::string err;
+    int rc = S->pipe->next(S->cur, &err);
+    if (rc < 0) {
+        set_err(errbuf, errcap, err);
+        return -INQ_EXIT_PANIC;
+    }
+    if (rc == 0) return 0;
+    SpanPipeline::Item *it = S->cur;
+    std::memset(sp, 0, sizeof *sp);
+    sp->comp = it->buf;
+    sp->comp_bytes = it->data.comp_bytes;
+    sp->blocks = it->data.blocks.data();
+    sp->n_blocks = it->data.blocks.size();
+    sp->anchors = it->data.anchors.data();
+    sp->n_anchors = it->data.anchors.size();
+    sp->tid = it->plan.tid;
+    sp->locus_start = it->plan.locus_start.data();
+    sp->locus_end = it->plan.locus_end.data();
+    sp->n_loci = it->plan.locus_start.size();
+    sp->minlen = S->minlen;
+    sp->support = S->support;
+    sp->unphased = S->unphased ? 1u : 0u;
+    if (locus_index) *locus_index = it->plan.locus_index.data();
+    if (file_begin) *file_begin = it->data.file_begin;
+    return 1;
+}
+
+int inq_spans_open(const inq_call_args_t *args, uint64_t max_comp_bytes, inq_spans_t **out, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_spans_open_impl(args, max_comp_bytes, out, errbuf, errcap), errbuf, errcap)
+}
+int inq_spans_next(inq_spans_t *S, inq_span_t *span, const uint32_t **locus_index, uint64_t *file_begin, char *errbuf, size_t errcap) {
+    try {
+        return inq_spans_next_impl(S, span, locus_index, file_begin, errbuf, errcap);
+    } catch (...) {
+        set_err(errbuf, errcap, "internal error");
+        return -INQ_EXIT_ERROR;
+    }
+}
+uint64_t inq_spans_n_targets(const inq_spans_t *S) { return S ? S->P.targets.size() : 0; }
+void inq_spans_close(inq_spans_t *S) {
+    if (S && S->cur) S->pipe->release(S->cur);
+    delete S;
 }
 
 size_t inq_host_format_f64(double v, char *buf, size_t cap) { return (size_t)std::snprintf(buf, cap, "%s", format_f64(v).c_str()); }

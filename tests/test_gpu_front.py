@@ -130,3 +130,106 @@ def test_inflate_reports_corruption(ctx):
     blocks3["comp_len"][0] -= 200
     rc, out, status = ctx.bgzf_inflate(good + good + good, blocks3, check=False)
     assert rc == hipcall.INQ_ERR_INFLATE and status[0] != 0 and status[1] == 0
+
+
+# ---------------------------------------------------------------- spans: scan + join + call on the device
+def _locus_view(batch_or_arrays, j):
+    """Per-locus candidate list as comparable tuples (pos, mapq, bits, phase, cigar words)."""
+    cigar, reads, pair_read, off = batch_or_arrays
+    out = []
+    for k in range(int(off[j]), int(off[j + 1])):
+        r = reads[int(pair_read[k])]
+        o = int(r["cigar_off4"]) * 4
+        n = int(r["n_cigar"])
+        assert not cigar[o + n : o + (n + 3) // 4 * 4].any()  # zero padding to 16 bytes
+        out.append((int(r["pos"]), int(r["mapq"]), int(r["bits"]), int(r["phase"]) if r["bits"] & 4 else 0, cigar[o : o + n].tobytes()))
+    return out
+
+
+@pytest.mark.parametrize("seed,unphased,span_bytes", [(1, False, 0), (2, True, 20_000), (3, False, 3_000), (4, True, 1), (5, False, 0)])
+def test_call_span_matches_oracle_and_host_emulation(ctx, tmp_path, seed, unphased, span_bytes):
+    from inquistr_amd import call
+    from tests import gen
+    from tests.test_host_frontend import _expected, _make_case
+    from tests.test_host_spans import emulate_span
+
+    minlen, support = 5, [3, 1, 2, 3][seed % 4]
+    bam, bed, loci, recs = _make_case(tmp_path, seed, ultra_long=(seed == 3))
+    sp = call.Spans(bam, region_file=bed, minlen=minlen, support=support, threads=2, unphased=unphased, max_comp_bytes=span_bytes)
+    got1 = np.full(len(loci), np.nan)
+    got2 = np.full(len(loci), np.nan)
+    for span in sp.spans():
+        rc, p1, p2, ties, stats = ctx.call_span(span["comp"], span["blocks"], span["anchors"], span["tid"], span["locus_start"],
+                                                span["locus_end"], minlen, support, unphased)
+        assert rc == 0
+        idx = span["locus_index"]
+        got1[idx], got2[idx] = p1, p2
+        # the batch built on the device = the batch a plain-Python replay of the same span builds
+        want = emulate_span(span)
+        dev = ctx.span_fetch_batch(stats, len(idx))
+        assert int(stats.n_pairs) == want.n_pairs and int(stats.n_reads) == want.n_reads
+        ref = (want.cigar, want.reads, want.pair_read, want.locus_pair_off)
+        for j in range(len(idx)):
+            assert _locus_view(dev, j) == _locus_view(ref, j), (seed, j)
+    want1, want2 = _expected(loci, recs, unphased, minlen, support)
+    assert gen.same_f64(got1, want1) and gen.same_f64(got2, want2)
+    sp.close()
+
+
+@pytest.mark.parametrize("seed,unphased,threads", [(11, False, 1), (12, True, 4)])
+def test_device_front_end_text_equals_host_front_end(tmp_path, seed, unphased, threads):
+    from inquistr_amd import call
+    from tests.test_host_frontend import _make_case
+
+    bam, bed, loci, recs = _make_case(tmp_path, seed, n_loci=120)
+    texts = {}
+    for fe in ("host", "device"):
+        path = tmp_path / f"{fe}.inq"
+        with open(path, "w") as f:
+            call.genotype_repeats(bam, None, bed, 5, 3, threads, unphased, None, None, out=f, frontend=fe)
+        texts[fe] = path.read_text()
+    assert texts["host"] == texts["device"] and texts["host"].count("\n") == len(loci) + 1
+
+
+def test_device_front_end_error_classes(tmp_path):
+    """The reference's panics that live in the record accessors keep their exit status through the device path."""
+    from inquistr_amd import call
+    from oracle import pyoracle as py
+    from tools import bamio
+
+    def run(recs, unphased=False, sort=True, tags=None):
+        bam = str(tmp_path / "e.bam")
+        w = bamio.BamWriter(bam, [("chr1", 100000)])
+        for i, r in enumerate(sorted(recs, key=lambda r: r.pos) if sort else recs):
+            w.add(f"r{i}", r.flag, 0, r.pos, 60, r.cigar, (tags or (lambda r: [("HP", r.hp[0], r.hp[1])] + ([("SA", r.sa[0], r.sa[1])] if r.sa else [])))(r))
+        w.close()
+        with open(tmp_path / "e.inq", "w") as f:
+            call.genotype_repeats(bam, "chr1:5000-5050", None, 5, 3, 1, unphased, None, None, out=f, frontend="device")
+        return (tmp_path / "e.inq").read_text()
+
+    ok = [py.Record(pos=4800, cigar=[("M", 210), ("I", 12), ("M", 300)], hp=("C", 1 + k % 2)) for k in range(8)]
+    text = run(ok)
+    assert text.splitlines()[1] == "chr1\t5000\t5050\t12\t12"
+    # HP typed 's': get_phase panics, but only in phased mode
+    bad_hp = ok + [py.Record(pos=4900, cigar=[("M", 400)], hp=("s", 1))]
+    with pytest.raises(call.CallError) as e:
+        run(bad_hp)
+    assert e.value.status == 101
+    assert run(bad_hp, unphased=True).count("\n") == 2
+    # SA that is not a string on a read with a soft clip
+    bad_sa = ok + [py.Record(pos=4990, cigar=[("S", 20), ("M", 400)], hp=("C", 1), sa=("i", 7))]
+    with pytest.raises(call.CallError) as e:
+        run(bad_sa)
+    assert e.value.status == 101
+    # ... and a malformed SA string
+    bad_sa2 = ok + [py.Record(pos=4990, cigar=[("S", 20), ("M", 400)], hp=("C", 1), sa=("Z", "chr1,notanumber,-,50M,60,0;"))]
+    with pytest.raises(call.CallError) as e:
+        run(bad_sa2)
+    assert e.value.status == 101
+    # the same reads without a soft clip never reach is_accidental_2d
+    fine = ok + [py.Record(pos=4990, cigar=[("M", 400)], hp=("C", 1), sa=("Z", "chr1,notanumber,-,50M,60,0;"))]
+    assert run(fine).count("\n") == 2
+    # records out of coordinate order
+    with pytest.raises(call.CallError) as e:
+        run([ok[0], py.Record(pos=4700, cigar=[("M", 500)], hp=("C", 1))] + ok[1:], sort=False)
+    assert e.value.status == 101

@@ -171,3 +171,70 @@ class BamWriter:
         out += struct.pack("<Q", n_no_coor)
         with open(self.path + ".bai", "wb") as f:
             f.write(out)
+
+
+def inflate_span(comp, blocks) -> bytes:
+    """zlib-inflates the blocks of a span (block table as inq_bgzf_block_t records) into one byte string."""
+    mv = memoryview(comp)
+    out = []
+    for b in blocks:
+        o, n = int(b["comp_off"]), int(b["comp_len"])
+        d = zlib.decompressobj(-15).decompress(bytes(mv[o : o + n]))
+        assert len(d) == int(b["isize"])
+        out.append(d)
+    return b"".join(out)
+
+
+_AUX_FIXED = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4, "d": 8}
+_AUX_FMT = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}
+
+
+def read_records(u: bytes, off: int):
+    """Walks BAM records in inflated bytes from `off` until one is cut by the end.  Yields dicts with the
+    fields the path reads: off, tid, pos, mapq, flag, cigar (words, CG-swapped), hp (type, value) / None,
+    sa (type, value) / None."""
+    n = len(u)
+    while off + 4 <= n:
+        (bs,) = struct.unpack_from("<I", u, off)
+        if bs < 32 or off + 4 + bs > n:
+            return
+        b = off + 4
+        tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq = struct.unpack_from("<iiBBHHHI", u, b)
+        p = b + 32 + l_rn
+        words = list(struct.unpack_from("<%dI" % n_cig, u, p))
+        p += 4 * n_cig + (l_seq + 1) // 2 + l_seq
+        end = b + bs
+        hp = sa = cg = None
+        while p + 3 <= end:
+            tag, typ = u[p : p + 2].decode("latin1"), chr(u[p + 2])
+            v = p + 3
+            if typ in _AUX_FIXED:
+                sz = _AUX_FIXED[typ]
+                val = u[v : v + 1].decode("latin1") if typ == "A" else (struct.unpack_from("<" + _AUX_FMT[typ], u, v)[0] if typ != "d" else None)
+            elif typ in "ZH":
+                z = u.index(b"\0", v, end) if b"\0" in u[v:end] else -1
+                if z < 0:
+                    break
+                sz, val = z - v + 1, u[v:z].decode("latin1")
+            elif typ == "B":
+                sub = chr(u[v])
+                (cnt,) = struct.unpack_from("<I", u, v + 1)
+                es = 1 if sub in "cC" else 2 if sub in "sS" else 4
+                sz = 5 + cnt * es
+                val = (sub, list(struct.unpack_from("<%d%s" % (cnt, _AUX_FMT[sub]), u, v + 5))) if v + sz <= end else None
+            else:
+                break
+            if v + sz > end:
+                break
+            if tag == "HP" and hp is None:
+                hp = (typ, val)
+            elif tag == "SA" and sa is None:
+                sa = (typ, val)
+            elif tag == "CG" and cg is None:
+                cg = (typ, val)
+            p = v + sz
+        if cg and cg[0] == "B" and cg[1][0] in "Ii" and words and pos >= 0 and (words[0] & 15) == 4 and (words[0] >> 4) == l_seq \
+                and len(cg[1][1]) >= len(words):
+            words = [w & 0xFFFFFFFF for w in cg[1][1]]
+        yield dict(off=off, tid=tid, pos=pos, mapq=mapq, flag=flag, cigar=words, hp=hp, sa=sa)
+        off = b + bs
