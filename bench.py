@@ -88,11 +88,11 @@ def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str =
     ref = os.path.join(ROOT, "oracle", "ref_shaped_call")
     un = ["-u"] if wl.unphased else []
 
-    def timed(cmd, n):
+    def timed(cmd, n, env=None):
         best, out = None, None
         for _ in range(n):
             t = time.perf_counter()
-            r = subprocess.run(cmd, capture_output=True)
+            r = subprocess.run(cmd, capture_output=True, env=env)
             dt = time.perf_counter() - t
             if r.returncode != 0:
                 raise SystemExit(f"{cmd} failed: {r.stderr.decode()[-500:]}")
@@ -101,8 +101,17 @@ def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str =
         return best, out
 
     res = {}
-    t_gpu, out_gpu = timed([cli, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", str(threads), "--sample-name", "S"] + un, reps + 1)
-    res["gpu_cli"] = {"seconds": t_gpu, "loci_per_s": loci / t_gpu, "threads": threads}
+    cmd = [cli, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", str(threads), "--sample-name", "S"] + un
+    t_host, out_host = timed(cmd, reps + 1, dict(os.environ, INQ_FRONTEND="host"))
+    t_dev, out_dev = timed(cmd, reps + 1, dict(os.environ, INQ_FRONTEND="device"))
+    res["gpu_cli_host_front"] = {"seconds": t_host, "loci_per_s": loci / t_host, "threads": threads}
+    res["gpu_cli_device_front"] = {"seconds": t_dev, "loci_per_s": loci / t_dev, "threads": threads,
+                                   "inq_identical_to_host_front": out_dev == out_host}
+    r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="2"))
+    res["device_front_stages"] = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("[inq")]
+    t_gpu, out_gpu = min((t_host, out_host), (t_dev, out_dev), key=lambda x: x[0])
+    res["gpu_cli"] = {"seconds": t_gpu, "loci_per_s": loci / t_gpu, "threads": threads,
+                      "front_end": "device" if t_dev <= t_host else "host"}
     for mode, thr in (("C", 1), ("B", threads), ("A", threads)):
         t, out = timed([ref, prefix + ".bam", prefix + ".bed", mode, str(thr), str(int(wl.unphased)), str(wl.minlen),
                         str(wl.support), "S"], 1 if mode == "A" else reps)

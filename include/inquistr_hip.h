@@ -153,7 +153,8 @@ int inq_call_batch_device(inq_ctx_t *ctx, const inq_batch_t *batch, inq_result_t
 int inq_ctx_status(inq_ctx_t *ctx, uint64_t *n_tie_loci);
 
 /* Kernel timing with HIP events on the launch stream (for bench.py's roofline block).
- * which: 0 = whole inq_call_batch_device launch sequence, 1 = the CIGAR-walk kernel.
+ * which: 0 = whole inq_call_batch_device launch sequence, 1 = the CIGAR-walk kernel,
+ * 2 = the BGZF inflate kernel of the last inq_bgzf_inflate / inq_call_span (launches = 1).
  * Returns accumulated milliseconds and launch count since the last reset. */
 int inq_ctx_timing_enable(inq_ctx_t *ctx, int on);
 int inq_ctx_timing_read(inq_ctx_t *ctx, int which, double *total_ms, uint64_t *launches);

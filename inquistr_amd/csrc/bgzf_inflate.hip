@@ -7,16 +7,16 @@
 // inside a block whatever one does, so the chip is filled across blocks, not inside one.
 //
 // Per lane:
-//   * a 64-bit bit buffer refilled with (unaligned) dword loads from the compressed stream;
-//   * canonical Huffman decoding by first-code / count per length (the textbook method of RFC 1951
-//     3.2.2): the 15 per-length counts of each code live in REGISTERS (static indexing in an unrolled
-//     loop), only the symbol permutation lives in LDS, lane-interleaved ([entry][lane], u16), so
-//     that lanes reading different entries still hit different banks pairwise;
+//   * a 64-bit bit buffer; the compressed stream is fetched 16 bytes at a time, one fetch ahead of its use;
+//   * canonical Huffman decoding (RFC 1951 3.2.2) without a per-length loop: the code length at the cursor
+//     comes from 15 independent compares of the left-aligned next bits against per-length limits held
+//     in REGISTERS (see Code); only the symbol permutation and 16 per-length bases live in LDS,
+//     lane-interleaved ([entry][lane], 16-bit), so lanes reading different entries hit different banks;
 //   * dynamic headers are decoded TWICE (pass 1 counts lengths, pass 2 places symbols), which
 //     removes the 320-entry per-lane length array: the header is <1 % of a block's symbols;
 //   * length/distance bases are computed arithmetically, no constant tables;
-//   * output goes straight to global memory (the history window is the output itself); matches with
-//     distance >= 4 are copied a dword at a time.
+//   * output goes straight to global memory (the history window is the output itself); a match issues all
+//     its loads before its first store (one memory round trip per <= 64 bytes, see copy_group).
 // Every access is bounded (input by the block's extent, output by ISIZE, distances by the bytes
 // produced), so a corrupt stream ends in a per-block status, never in a fault.
 #include <hip/hip_runtime.h>
@@ -35,6 +35,7 @@ constexpr int kLitSyms = 288, kDistSyms = 32;
 struct InflateLds {
     uint16_t sym[kLitSyms + kDistSyms][kLanes];  // sorted symbols: [0,288) literal/length, [288,320) distance
     uint16_t cnt[32][kLanes];                    // construction scratch: [0,16) literal/length, [16,32) distance
+    int16_t base[32][kLanes];                    // base[len] of the two codes (see Code)
 };
 
 __device__ __forceinline__ uint32_t load_u32(const uint8_t *p) {
@@ -44,14 +45,45 @@ __device__ __forceinline__ uint32_t load_u32(const uint8_t *p) {
 }
 __device__ __forceinline__ void store_u32(uint8_t *p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
 
+// Bit cursor over the payload.  The compressed bytes are fetched 16 at a time, one fetch AHEAD of their
+// use (cur = being consumed, nxt = in flight), so the decoder waits for a load issued ~10 symbols ago.
 struct BitReader {
-    const uint8_t *p;    // next byte to load
+    const uint8_t *p;    // first byte NOT yet handed to the bit buffer (drives overrun / stored-block math)
     const uint8_t *end;  // end of this block's deflate payload
     uint64_t bb;
     uint32_t bc;
-    __device__ __forceinline__ void refill() {  // afterwards bc > 32 (zeros behind the end of the payload)
+    const uint8_t *fetch;  // address of nxt
+    uint64_t cur_lo, cur_hi, nxt_lo, nxt_hi;
+    uint32_t cur_n;        // dwords left in cur
+    __device__ __forceinline__ void load16(const uint8_t *q, uint64_t &lo, uint64_t &hi) const {
+        if (q < end) {  // the buffer carries >= 16 bytes of padding behind the last payload
+            lo = (uint64_t)load_u32(q) | ((uint64_t)load_u32(q + 4) << 32);
+            hi = (uint64_t)load_u32(q + 8) | ((uint64_t)load_u32(q + 12) << 32);
+        } else
+            lo = hi = 0ull;  // zeros behind the payload; overrun() reports their use
+    }
+    __device__ __forceinline__ void start(const uint8_t *from) {  // (re)position at a byte
+        p = from;
+        bb = 0ull;
+        bc = 0u;
+        load16(from, cur_lo, cur_hi);
+        load16(from + 16, nxt_lo, nxt_hi);
+        fetch = from + 16;
+        cur_n = 4u;
+    }
+    __device__ __forceinline__ void refill() {  // afterwards bc > 32
         if (bc <= 32u) {
-            const uint32_t w = p < end ? load_u32(p) : 0u;  // the buffer carries >= 4 bytes of padding
+            if (cur_n == 0u) {
+                cur_lo = nxt_lo;
+                cur_hi = nxt_hi;
+                fetch += 16;
+                load16(fetch, nxt_lo, nxt_hi);
+                cur_n = 4u;
+            }
+            const uint32_t w = (uint32_t)cur_lo;
+            cur_lo = (cur_lo >> 32) | (cur_hi << 32);
+            cur_hi >>= 32;
+            --cur_n;
             bb |= (uint64_t)w << bc;
             p += 4;
             bc += 32u;
@@ -68,38 +100,82 @@ struct BitReader {
         return v;
     }
     // bits consumed beyond the payload?
-    __device__ __forceinline__ bool overrun(const uint8_t *start) const {
-        const int64_t used = (int64_t)(p - start) * 8 - (int64_t)bc;
-        return used > (int64_t)(end - start) * 8;
+    __device__ __forceinline__ bool overrun(const uint8_t *start_) const {
+        const int64_t used = (int64_t)(p - start_) * 8 - (int64_t)bc;
+        return used > (int64_t)(end - start_) * 8;
     }
 };
 
-// counts of one canonical code: count[len] for len 1..15, two 16-bit fields per register
-struct Counts {
-    uint32_t r[8];
-    __device__ __forceinline__ uint32_t get(int len) const { return (r[len >> 1] >> ((len & 1) * 16)) & 0xffffu; }
+// Copies n <= 16 bytes whose source and destination do not overlap: the four loads are issued before the
+// first store, so the lane pays ONE memory round trip (on gfx9 a load's data is only usable once every
+// earlier store of the wave has been acknowledged: load/store ping-pong costs a round trip per element).
+__device__ __forceinline__ void copy_quad(uint8_t *dst, const uint8_t *src, uint32_t n) {
+    // reads up to 15 bytes past n: inside the padded buffers, never stored
+    const uint32_t w0 = load_u32(src), w1 = load_u32(src + 4), w2 = load_u32(src + 8), w3 = load_u32(src + 12);
+    if (n == 16u) {
+        store_u32(dst, w0);
+        store_u32(dst + 4, w1);
+        store_u32(dst + 8, w2);
+        store_u32(dst + 12, w3);
+        return;
+    }
+    uint32_t k = 0;
+    if (n >= 4u) store_u32(dst, w0), k = 4u;
+    if (n >= 8u) store_u32(dst + 4, w1), k = 8u;
+    if (n >= 12u) store_u32(dst + 8, w2), k = 12u;
+    uint32_t t = k == 0u ? w0 : k == 4u ? w1 : k == 8u ? w2 : w3;
+    for (; k < n; ++k, t >>= 8) dst[k] = (uint8_t)t;
+}
+
+__device__ __forceinline__ void copy_forward(uint8_t *dst, const uint8_t *src, uint32_t n) {
+    for (uint32_t k = 0; k < n; k += 16u) copy_quad(dst + k, src + k, n - k < 16u ? n - k : 16u);
+}
+
+// LZ77 match: len bytes from dd bytes back; source and destination overlap when dd < len.
+__device__ __forceinline__ void copy_match(uint8_t *dst, uint32_t dd, uint32_t len) {
+    const uint8_t *src = dst - dd;
+    if (dd >= len || dd >= 16u) {  // a quad never reads what it writes
+        for (uint32_t k = 0; k < len; k += 16u) copy_quad(dst + k, src + k, len - k < 16u ? len - k : 16u);
+        return;
+    }
+    // short period (dd < 16, dd < len): the output is the last dd bytes repeated; take them once
+    const uint64_t lo = (uint64_t)load_u32(src) | ((uint64_t)load_u32(src + 4) << 32);
+    const uint64_t hi = (uint64_t)load_u32(src + 8) | ((uint64_t)load_u32(src + 12) << 32);
+    if (dd == 1u) {
+        const uint32_t w = ((uint32_t)lo & 0xffu) * 0x01010101u;
+        uint32_t k = 0;
+        for (; k + 4u <= len; k += 4u) store_u32(dst + k, w);
+        for (; k < len; ++k) dst[k] = (uint8_t)w;
+        return;
+    }
+    uint32_t idx = 0;
+    for (uint32_t k = 0; k < len; ++k) {
+        dst[k] = (uint8_t)(idx < 8u ? lo >> (8u * idx) : hi >> (8u * (idx - 8u)));
+        if (++idx == dd) idx = 0;
+    }
+}
+
+// One canonical code, ready to decode without a per-length loop.  Left-align the next 15 bits MSB-first
+// (v); codes of length L occupy [first[L], first[L] + count[L]) << (15 - L), shorter codes below longer
+// ones, so with limit[L] = (first[L] + count[L]) << (15 - L) (non-decreasing in L) the length of the code
+// at the cursor is 1 + #{L : v >= limit[L]}: fifteen independent compares against register constants, no
+// divergence between lanes.  The symbol is sym[base[len] + (v >> (15 - len))] with
+// base[len] = (first sorted slot of length len) - first[len], kept per lane in LDS.
+struct Code {
+    uint32_t lim[8];  // limit[L], 16 bits each, L = 1..15 (field 0 unused)
+    __device__ __forceinline__ uint32_t limit(int len) const { return (lim[len >> 1] >> ((len & 1) * 16)) & 0xffffu; }
 };
 
-// One symbol of a canonical code: walk the lengths, keeping the first code and the first symbol index of
-// each length.  Returns the symbol or -1 (code not in the set).  `base` = first LDS entry of the code.
-__device__ __forceinline__ int decode_sym(BitReader &b, const Counts &c, const InflateLds &L, int base, int lane) {
-    uint32_t bits = b.peek();
-    int code = 0, first = 0, index = 0;
+// Returns the symbol or -1 (bit pattern outside the code).  `tbl` = 0 literal/length, 1 distance.
+__device__ __forceinline__ int decode_sym(BitReader &b, const Code &c, const InflateLds &L, int tbl, int lane) {
+    const uint32_t v = __brev(b.peek()) >> 17;
+    uint32_t len = 1;
 #pragma unroll
-    for (int len = 1; len <= 15; ++len) {
-        code |= (int)(bits & 1u);
-        bits >>= 1;
-        const int count = (int)c.get(len);
-        if (code - count < first) {
-            b.drop((uint32_t)len);
-            return (int)L.sym[base + index + (code - first)][lane];
-        }
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
-    }
-    return -1;
+    for (int k = 1; k <= 15; ++k) len += v >= c.limit(k) ? 1u : 0u;
+    if (len > 15u) return -1;
+    const int idx = (int)L.base[tbl * 16 + (int)len][lane] + (int)(v >> (15u - len));
+    b.drop(len);
+    return (int)L.sym[(tbl ? kLitSyms : 0) + idx][lane];
 }
 
 // the code-length code: 19 symbols of <= 7 bits, everything in registers
@@ -136,30 +212,32 @@ __device__ __forceinline__ int decode_cl(BitReader &b, const ClCode &c) {
     return -1;
 }
 
-__device__ __forceinline__ void load_counts(Counts &c, const InflateLds &L, int base, int lane) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) c.r[k] = (uint32_t)L.cnt[base + 2 * k][lane] | ((uint32_t)L.cnt[base + 2 * k + 1][lane] << 16);
-    c.r[0] &= 0xffff0000u;  // length 0 = "no code"
-}
-
-// counts -> running offsets (first sorted slot of each length).  False for the sets zlib's inflate_table
+// Per-length counts in L.cnt[base .. base + 15] -> limits (registers), base[] (LDS), and L.cnt becomes the
+// running insertion slot of each length for the symbol placement.  False for the sets zlib's inflate_table
 // rejects: over-subscribed, or incomplete with any code longer than one bit.
-__device__ __forceinline__ bool counts_to_offsets(InflateLds &L, int base, int lane) {
+__device__ __forceinline__ bool build_code(Code &c, InflateLds &L, int tbl, int lane) {
     int left = 1, maxlen = 0;
-    uint32_t off = 0;
+    uint32_t off = 0, first = 0;
     bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.lim[i] = 0u;
+#pragma unroll
     for (int len = 1; len <= 15; ++len) {
-        const uint32_t n = L.cnt[base + len][lane];
+        const uint32_t n = L.cnt[tbl * 16 + len][lane];
         left = (left << 1) - (int)n;
         ok &= left >= 0;
         if (n) maxlen = len;
-        L.cnt[base + len][lane] = (uint16_t)off;
+        const uint32_t lim = ok ? (first + n) << (15 - len) : 0u;  // <= 1 << 15 while not over-subscribed
+        c.lim[len >> 1] |= lim << ((len & 1) * 16);
+        L.base[tbl * 16 + len][lane] = (int16_t)((int)off - (int)first);
+        L.cnt[tbl * 16 + len][lane] = (uint16_t)off;
         off += n;
+        first = (first + n) << 1;
     }
     return ok && (left == 0 || maxlen <= 1);
 }
 
-__device__ void build_fixed(InflateLds &L, Counts &lit, Counts &dist, int lane) {
+__device__ void build_fixed(InflateLds &L, Code &lit, Code &dist, int lane) {
     // RFC 1951 3.2.6: literal/length lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287)
     int k = 0;
     for (int s = 256; s < 280; ++s) L.sym[k++][lane] = (uint16_t)s;
@@ -167,18 +245,20 @@ __device__ void build_fixed(InflateLds &L, Counts &lit, Counts &dist, int lane) 
     for (int s = 280; s < 288; ++s) L.sym[k++][lane] = (uint16_t)s;
     for (int s = 144; s < 256; ++s) L.sym[k++][lane] = (uint16_t)s;
     for (int s = 0; s < 30; ++s) L.sym[kLitSyms + s][lane] = (uint16_t)s;  // codes 30, 31 never decode
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lit.r[i] = 0u, dist.r[i] = 0u;
-    lit.r[3] = 24u << 16;             // len 7
-    lit.r[4] = 152u | (112u << 16);   // len 8, len 9
-    dist.r[2] = 30u << 16;            // len 5
+    for (int i = 0; i < 32; ++i) L.cnt[i][lane] = 0;
+    L.cnt[7][lane] = 24;
+    L.cnt[8][lane] = 152;
+    L.cnt[9][lane] = 112;
+    L.cnt[16 + 5][lane] = 30;
+    (void)build_code(lit, L, 0, lane);
+    (void)build_code(dist, L, 1, lane);
 }
 
 // status bits per block
 constexpr uint32_t kBadHeader = INQ_INFLATE_BAD_HEADER, kBadCode = INQ_INFLATE_BAD_CODE, kInputOverrun = INQ_INFLATE_INPUT_OVERRUN,
                    kOutputSize = INQ_INFLATE_OUTPUT_SIZE, kBadDistance = INQ_INFLATE_BAD_DISTANCE, kBadStored = INQ_INFLATE_BAD_STORED;
 
-__device__ uint32_t read_dynamic_header(BitReader &b, InflateLds &L, Counts &lit, Counts &dist, int lane) {
+__device__ uint32_t read_dynamic_header(BitReader &b, InflateLds &L, Code &lit, Code &dist, int lane) {
     b.refill();
     const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
     if (hlit > 286 || hdist > 30) return kBadHeader;  // zlib: "too many length or distance symbols"
@@ -252,9 +332,7 @@ __device__ uint32_t read_dynamic_header(BitReader &b, InflateLds &L, Counts &lit
         }
         if (pass == 0) {
             if (!has_eob) return kBadHeader;  // zlib: "missing end-of-block"
-            load_counts(lit, L, 0, lane);
-            load_counts(dist, L, 16, lane);
-            if (!counts_to_offsets(L, 0, lane) || !counts_to_offsets(L, 16, lane)) return kBadHeader;
+            if (!build_code(lit, L, 0, lane) || !build_code(dist, L, 1, lane)) return kBadHeader;
             b = mark;
         }
     }
@@ -276,11 +354,13 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
         st = kBadHeader;
     } else {
         const uint8_t *start = a.comp + blk.comp_off;
-        BitReader b{start, start + blk.comp_len, 0ull, 0u};
+        BitReader b;
+        b.end = start + blk.comp_len;
+        b.start(start);
         uint8_t *out = a.out + blk.out_off;
         const uint32_t isize = blk.isize;
         uint32_t o = 0;
-        Counts lit, dist;
+        Code lit, dist;
         bool last = false;
         while (!last && st == 0u) {
             b.refill();
@@ -313,11 +393,9 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
                     st = kOutputSize;
                     break;
                 }
-                for (uint32_t k = 0; k < len; ++k) out[o + k] = q[k];
+                copy_forward(out + o, q, len);
                 o += len;
-                b.p = q + len;
-                b.bb = 0ull;
-                b.bc = 0u;
+                b.start(q + len);
                 continue;
             }
             if (type == 3u) {
@@ -356,7 +434,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
                     len = 3u + ((4u + ((uint32_t)s & 3u)) << eb) + b.take(eb);
                 }
                 b.refill();
-                const int d = decode_sym(b, dist, L, kLitSyms, lane);
+                const int d = decode_sym(b, dist, L, 1, lane);
                 if (d < 0 || d >= 30) {
                     st = kBadCode;
                     break;
@@ -375,12 +453,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
                     st = kOutputSize;
                     break;
                 }
-                uint8_t *dst = out + o;
-                const uint8_t *src = dst - dd;
-                uint32_t k = 0;
-                if (dd >= 4u)
-                    for (; k + 4u <= len; k += 4u) store_u32(dst + k, load_u32(src + k));
-                for (; k < len; ++k) dst[k] = src[k];
+                copy_match(out + o, dd, len);
                 o += len;
             }
         }

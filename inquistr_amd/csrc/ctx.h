@@ -59,4 +59,5 @@ int ensure(inq_ctx *c, DevBuf &b, size_t bytes);
 int call_batch_device_impl(inq_ctx *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream);
 int status_to_code(uint32_t st);
 void span_state_destroy(SpanState *s);
+double span_last_inflate_ms(SpanState *s);  // kernel time of the last inflate launch, < 0 if none
 }  // namespace inq

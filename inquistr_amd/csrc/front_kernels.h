@@ -9,11 +9,11 @@
 namespace inq {
 
 struct InflateArgs {
-    const uint8_t *comp;  // whole BGZF blocks; >= 4 readable bytes behind comp_bytes
+    const uint8_t *comp;  // whole BGZF blocks; >= 32 readable bytes behind comp_bytes
     uint64_t comp_bytes;
     const inq_bgzf_block_t *blocks;
     uint64_t n_blocks;
-    uint8_t *out;
+    uint8_t *out;  // >= 16 writable/readable bytes behind out_bytes
     uint64_t out_bytes;
     uint32_t *block_status;  // [n_blocks] or null
     unsigned int *err;       // OR of the INQ_INFLATE_* bits of all blocks

@@ -29,6 +29,12 @@ struct SpanState {
     uint64_t n_reads = 0, n_cigar_words = 0, n_pairs = 0, n_loci = 0;
 };
 
+double span_last_inflate_ms(SpanState *S) {
+    float ms = 0.f;
+    if (!S || !S->have_ev || hipEventElapsedTime(&ms, S->ev[1], S->ev[2]) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
 void span_state_destroy(SpanState *S) {
     if (!S) return;
     for (DevBuf *b : {&S->comp, &S->blocks, &S->u, &S->block_status, &S->anchors, &S->anchor_cnt, &S->anchor_base, &S->rec_off,
@@ -117,6 +123,7 @@ int bgzf_inflate_impl(inq_ctx *c, const uint8_t *comp, uint64_t comp_bytes, cons
     if ((rc = span_state(c, &S)) != INQ_OK) return rc;
     hipStream_t s = c->stream;
     if ((rc = upload_and_inflate(c, S, comp, comp_bytes, blocks, n_blocks, out_bytes, true, s)) != INQ_OK) return rc;
+    HIP_TRY(c, hipEventRecord(S->ev[2], s));
     if (out_bytes) HIP_TRY(c, hipMemcpyAsync(out, S->u.p, out_bytes, hipMemcpyDeviceToHost, s));
     if (block_status && n_blocks) HIP_TRY(c, hipMemcpyAsync(block_status, S->block_status.p, n_blocks * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));

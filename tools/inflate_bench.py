@@ -1,0 +1,51 @@
+"""Kernel time of the BGZF inflate on BAM-like data: blocks of synthetic records (tools/make_synth_bam)
+compressed like htslib does (zlib level 1..6, 0xff00 bytes per block)."""
+import sys
+import time
+import zlib
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from inquistr_amd import hipcall, synth  # noqa: E402
+from tools import bamio, make_synth_bam  # noqa: E402
+
+
+def make_blocks(n_blocks: int, level: int):
+    wl = synth.WORKLOADS["unphased100k"]
+    need = n_blocks * bamio.BLOCK
+    blob = bytearray()
+    g = 0
+    while len(blob) < need and g < 4000:
+        b = synth.generate_numpy(wl, g, g + 200)
+        data, *_ = make_synth_bam.records_for(b, 0, g * 30)
+        blob += data
+        g += 200
+    base = bytes(blob)
+    comp = [bamio.bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base) - bamio.BLOCK, bamio.BLOCK)]
+    comp = (comp * (n_blocks // len(comp) + 1))[:n_blocks]
+    return b"".join(comp)
+
+
+def main():
+    n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+    level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    comp = make_blocks(n_blocks, level)
+    blocks = hipcall.scan_bgzf(comp)
+    ctx = hipcall.Context(0)
+    out_bytes = int(blocks["isize"].sum())
+    for rep in range(3):
+        t = time.perf_counter()
+        rc, out, st = ctx.bgzf_inflate(comp, blocks)
+        wall = time.perf_counter() - t
+        ms, _ = ctx.timing_read(2)
+        print(f"blocks {len(blocks)} level {level}: comp {len(comp) / 1e6:.1f} MB -> {out_bytes / 1e6:.1f} MB, kernel {ms:.2f} ms "
+              f"= {out_bytes / ms / 1e6:.2f} GB/s out, {len(comp) / ms / 1e6:.2f} GB/s in (call {wall * 1e3:.0f} ms)", flush=True)
+    # spot check against zlib
+    b = blocks[len(blocks) // 2]
+    want = zlib.decompressobj(-15).decompress(comp[int(b["comp_off"]) : int(b["comp_off"]) + int(b["comp_len"])])
+    assert out[int(b["out_off"]) : int(b["out_off"]) + int(b["isize"])].tobytes() == want
+
+
+if __name__ == "__main__":
+    main()
