@@ -202,8 +202,10 @@ typedef struct inq_bgzf_block {
 int inq_bgzf_inflate(inq_ctx_t *ctx, const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks,
                      uint64_t n_blocks, uint8_t *out, uint64_t out_bytes, uint32_t *block_status);
 
-/* One span: consecutive whole BGZF blocks of a coordinate-sorted BAM plus the loci (one contig) whose
- * overlapping records all start inside it. */
+/* One span: whole BGZF blocks of a coordinate-sorted BAM, as one or more SEGMENTS (runs of consecutive
+ * blocks, ascending and disjoint in the file), plus loci whose overlapping records all start inside those
+ * segments.  Segments let one call serve loci that are far apart without inflating what lies between. */
+#define INQ_ANCHOR_SEGMENT_END (1ull << 63)
 typedef struct inq_span {
     const uint8_t *comp;             /* HOST (ideally pinned): the compressed bytes of the blocks        */
     uint64_t comp_bytes;
@@ -211,21 +213,23 @@ typedef struct inq_span {
     uint64_t n_blocks;
     const uint64_t *anchors;         /* ascending offsets into the inflated bytes at which a BAM record
                                         is known to start (virtual offsets of the .bai: chunk begins and
-                                        linear-index entries); anchors[0] = the first record to look at.
-                                        Records are found by following block_size from every anchor to
-                                        the next one, one lane per anchor.                                */
+                                        linear-index entries); every segment opens with one.  Records
+                                        are found by following block_size from each anchor, one lane per
+                                        anchor.                                                           */
+    const uint64_t *anchor_stop;     /* [n_anchors] where chain i ends: the next anchor (the chain must
+                                        land on it), or `end of the segment | INQ_ANCHOR_SEGMENT_END`
+                                        (a record cut by the segment's end is dropped)                    */
     uint64_t n_anchors;
-    int32_t tid;                     /* header().tid(chrom), src/call.rs:287,337                          */
-    uint32_t reserved;               /* must be 0                                                         */
+    const int32_t *locus_tid;        /* [n_loci] header().tid(chrom), src/call.rs:287,337                 */
     const uint32_t *locus_start;     /* [n_loci] un-extended BED coordinates, any order                   */
     const uint32_t *locus_end;
     uint64_t n_loci;
-    uint32_t minlen, support, unphased, reserved2;
+    uint32_t minlen, support, unphased, reserved;
 } inq_span_t;
 
 typedef struct inq_span_stats {
     uint64_t n_records;      /* records found in the span                                   */
-    uint64_t n_reads;        /* of which on the span's contig (the rest lies behind it)      */
+    uint64_t n_reads;        /* of which placed on a contig (unplaced records close the file) */
     uint64_t n_pairs;        /* (locus, read) pairs = records fetch() would yield, summed    */
     uint64_t n_cigar_words;  /* gathered CIGAR words incl. padding                           */
     uint64_t inflated_bytes;

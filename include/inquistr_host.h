@@ -37,7 +37,7 @@ typedef struct inq_call_args {
     const char *sample_name; /* --sample-name, NULL if absent */
     const char *reference;   /* --reference (CRAM only; CRAM is not supported here) */
     int32_t device;          /* HIP device ordinal (not a reference argument) */
-    int32_t reserved;        /* front end: 0 = default (env INQ_FRONTEND=host|device), 1 = host sweep, 2 = device spans */
+    int32_t reserved;        /* front end: 0 = auto (env INQ_FRONTEND=host|device, else device when the loci need >= 48 MiB of BAM), 1 = host sweep, 2 = device spans */
 } inq_call_args_t;
 
 #define INQ_EXIT_OK 0
@@ -64,7 +64,7 @@ void inq_frontend_close(inq_frontend_t *fe);
 /* ---- spans: host half of the DEVICE front end (inq_call_span in inquistr_hip.h), no GPU involved ----
  * Cuts the targets into spans (loci of one contig + the whole BGZF blocks holding every record that
  * overlaps them, found through the .bai), reads the compressed bytes and builds the block table and the
- * record-start anchors.  max_comp_bytes = 0 takes the default (256 MiB, env INQ_SPAN_MB). */
+ * record-start anchors.  max_comp_bytes = 0 takes the default (1 GiB, env INQ_SPAN_MB). */
 typedef struct inq_spans inq_spans_t;
 int inq_spans_open(const inq_call_args_t *args, uint64_t max_comp_bytes, inq_spans_t **out, char *errbuf, size_t errcap);
 uint64_t inq_spans_n_targets(const inq_spans_t *s);

@@ -266,7 +266,8 @@ class Spans:
         return int(self._L.inq_spans_n_targets(self._h))
 
     def spans(self):
-        """Yields dicts of numpy copies: comp (u8), blocks, anchors (u64), tid, locus_start/end, locus_index, file_begin."""
+        """Yields dicts of numpy copies: comp (u8), blocks, anchors / anchor_stop (u64), locus_tid/start/end,
+        locus_index, file_begin."""
         from .hipcall import BGZF_BLOCK_DTYPE, SpanC
 
         while True:
@@ -288,8 +289,8 @@ class Spans:
             n = int(sp.n_loci)
             yield dict(
                 comp=arr(sp.comp, sp.comp_bytes, np.uint8), blocks=arr(sp.blocks, sp.n_blocks, BGZF_BLOCK_DTYPE),
-                anchors=arr(sp.anchors, sp.n_anchors, np.uint64), tid=int(sp.tid),
-                locus_start=arr(sp.locus_start, n, np.uint32), locus_end=arr(sp.locus_end, n, np.uint32),
+                anchors=arr(sp.anchors, sp.n_anchors, np.uint64), anchor_stop=arr(sp.anchor_stop, sp.n_anchors, np.uint64),
+                locus_tid=arr(sp.locus_tid, n, np.int32), locus_start=arr(sp.locus_start, n, np.uint32), locus_end=arr(sp.locus_end, n, np.uint32),
                 locus_index=np.ctypeslib.as_array(idx, shape=(max(n, 1),))[:n].copy(), file_begin=int(fb.value),
                 minlen=int(sp.minlen), support=int(sp.support), unphased=bool(sp.unphased),
             )

@@ -11,8 +11,9 @@
 //       inq_batch_t, reference span ([3P] bam_endpos), soft-clip presence; is_accidental_2d
 //       (src/call.rs:415-477) for the reads that have both a soft clip and an SA tag.
 //   join_count / join_fill : one lane per locus: the records fetch((tid, start-10, end+10)) yields are
-//       those with pos < end_ext && endpos > start_ext; positions ascend, so they lie between two binary
-//       searches (on pos, and on the running maximum of endpos) and keep file order.
+//       those with pos < end_ext && endpos > start_ext; (contig, position) ascends along the file, so they
+//       lie between two binary searches (on the position key, and on the running maximum of the end key)
+//       and keep file order.  A span may cover several contigs and several disjoint pieces of the file.
 // HBM-bound byte/integer work; no LDS tiling to speak of, the inflated bytes are read once by the parse
 // (36 bytes + aux per record) and once by the gather (CIGAR only) - SEQ and QUAL are never touched.
 #include <hip/hip_runtime.h>
@@ -52,23 +53,25 @@ __global__ __launch_bounds__(64) void chain_kernel(ScanArgs a) {
         }
         return;
     }
-    const bool last = i + 1 == a.n_anchors;
-    const uint64_t stop = last ? a.u_bytes : a.anchors[i + 1];
+    // the chain ends at the next anchor (and must land on it exactly), or at the end of its segment, where
+    // the last record may be cut: it lies behind everything the loci of the segment need
+    const uint64_t stop_raw = a.anchor_stop[i];
+    const bool seg_end = (stop_raw & INQ_ANCHOR_SEGMENT_END) != 0;
+    const uint64_t stop = stop_raw & ~INQ_ANCHOR_SEGMENT_END;
     uint64_t n = 0;
-    bool bad = x > a.u_bytes || stop > a.u_bytes || stop < x;
+    bool bad = x > stop || stop > a.u_bytes;
     while (!bad && x < stop) {
-        if (x + 4 > a.u_bytes) break;  // a record cut by the end of the span: behind everything the loci need
+        if (x + 4 > stop) break;
         const uint64_t bs = ld32(a.u + x);
         if (bs < 32 || n == 0xffffffffull) {
             bad = true;
             break;
         }
-        if (x + 4 + bs > a.u_bytes) break;
+        if (x + 4 + bs > stop) break;
         ++n;
         x += 4 + bs;
     }
-    // a chain inside the span must land exactly on the next anchor
-    if (!bad && !last && x != stop) bad = true;
+    if (!bad && !seg_end && x != stop) bad = true;
     if (bad) raise(a.st, FS_CHAIN, 0);
     a.anchor_cnt[i] = bad ? 0u : (uint32_t)n;
 }
@@ -122,7 +125,10 @@ __global__ __launch_bounds__(256) void record_parse_kernel(ScanArgs a) {
     ri.sa_off = 0;
     ri.sa_type = 0;
     ri.err = 0;
-    if (tid != a.tid) {  // behind the contig (the file is sorted by contig, then position)
+    // join key: ascending along a coordinate-sorted file (pos >= -1 for placed records)
+    const int64_t key = ((int64_t)tid << 32) | (int64_t)(uint32_t)(pos + 1);
+    a.key[i] = key;
+    if (tid < 0) {  // unplaced records close the file
         atomicMin(&a.st->n_valid, (unsigned long long)i);
         a.reads[i] = rd;
         a.info[i] = ri;
@@ -134,9 +140,11 @@ __global__ __launch_bounds__(256) void record_parse_kernel(ScanArgs a) {
         a.info[i] = ri;
         return;
     }
-    if (i > 0) {  // coordinate order inside the contig: the join's binary searches rely on it
+    if (i > 0) {  // coordinate order: the join's binary searches rely on it
         const uint8_t *pb = a.u + a.rec_off[i - 1] + 4;
-        if ((int32_t)ld32(pb) == a.tid && (int32_t)ld32(pb + 4) > pos) raise(a.st, FS_UNSORTED, i);
+        const int32_t ptid = (int32_t)ld32(pb);
+        const int64_t pkey = ((int64_t)ptid << 32) | (int64_t)(uint32_t)((int32_t)ld32(pb + 4) + 1);
+        if (ptid < 0 || pkey > key || pos < -1) raise(a.st, FS_UNSORTED, i);
     }
     if (flag & 0x4u) rd.bits |= INQ_READ_UNMAPPED;
     if (flag & 0x10u) rd.bits |= INQ_READ_REVERSE;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void cigar_gather_kernel(ScanArgs a, uint64_t 
     if (lane == 0) {
         if ((rd.bits & INQ_READ_UNMAPPED) || rlen == 0) rlen = 1;  // [3P] bam_endpos
         const int64_t endpos = (int64_t)rd.pos + rlen;
-        a.endpos[i] = endpos;
+        a.endkey[i] = (a.key[i] & ~0xffffffffll) + (endpos + 1);
         rd.cigar_off4 = (uint32_t)unit0;
         // is_accidental_2d is only reached from a soft-clip op (src/call.rs:394)
         if (clip && ri.sa_off) {
@@ -309,27 +317,29 @@ __global__ __launch_bounds__(256) void join_kernel(ScanArgs a, uint64_t n_valid)
     const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (j >= a.n_loci) return;
     const uint32_t s0 = a.locus_start[j], e0 = a.locus_end[j];
+    const int64_t tkey = (int64_t)a.locus_tid[j] << 32;
     uint32_t n = 0;
-    if (s0 >= 10u && e0 >= s0 && e0 <= 0xffffffffu - 10u) {  // out-of-domain loci are reported by the locus kernel
-        const int64_t start_ext = (int64_t)s0 - 10, end_ext = (int64_t)e0 + 10;  // src/call.rs:285-286,335-336
-        // hi = first read with pos >= end_ext
+    if (s0 >= 10u && e0 >= s0 && e0 <= 0x7fffffffu - 11u && tkey >= 0) {  // out-of-domain loci are reported by the locus kernel
+        // src/call.rs:285-286,335-336; both bounds in key space (position + 1)
+        const int64_t kstart = tkey + ((int64_t)s0 - 10 + 1), kend = tkey + ((int64_t)e0 + 10 + 1);
+        // last = first read at or behind end_ext (pos >= end_ext), or on a later contig
         uint64_t lo = 0, hi = n_valid;
         while (lo < hi) {
             const uint64_t m = (lo + hi) >> 1;
-            if ((int64_t)a.reads[m].pos < end_ext) lo = m + 1;
+            if (a.key[m] < kend) lo = m + 1;
             else hi = m;
         }
         const uint64_t last = lo;
-        // first = first read whose running maximum of endpos exceeds start_ext
+        // first read whose running maximum of endpos exceeds start_ext; everything from there on is on this contig
         lo = 0, hi = last;
         while (lo < hi) {
             const uint64_t m = (lo + hi) >> 1;
-            if (a.pmax[m] > start_ext) hi = m;
+            if (a.pmax[m] > kstart) hi = m;
             else lo = m + 1;
         }
         uint64_t w = FILL ? a.locus_pair_off[j] : 0;
         for (uint64_t r = lo; r < last; ++r) {
-            if (a.endpos[r] > start_ext) {  // [3P] htslib: pos < end && endpos > beg
+            if (a.endkey[r] > kstart) {  // [3P] htslib: pos < end && endpos > beg
                 if (FILL) {
                     a.pair_read[w++] = (uint32_t)r;
                     const uint32_t e = a.info[r].err;

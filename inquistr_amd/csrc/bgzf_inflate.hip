@@ -416,7 +416,8 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
                         st = kOutputSize;
                         break;
                     }
-                    out[o++] = (uint8_t)s;
+                    if (!(a.debug_flags & 1u)) out[o] = (uint8_t)s;
+                    ++o;
                     continue;
                 }
                 if (s == 256) break;
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
                     st = kOutputSize;
                     break;
                 }
-                copy_match(out + o, dd, len);
+                if (!(a.debug_flags & 2u)) copy_match(out + o, dd, len);
                 o += len;
             }
         }

@@ -17,13 +17,14 @@ struct InflateArgs {
     uint64_t out_bytes;
     uint32_t *block_status;  // [n_blocks] or null
     unsigned int *err;       // OR of the INQ_INFLATE_* bits of all blocks
+    uint32_t debug_flags;    // timing experiments only: 1 = drop literal stores, 2 = drop match copies
 };
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s);
 
 // scan-side status bits (FrontStatus::err)
 constexpr uint32_t FS_CHAIN = 0x01u;      // a record chain does not land on the next index anchor / record shorter than its fixed part
 constexpr uint32_t FS_RECORD = 0x02u;     // field lengths of a record exceed its block_size
-constexpr uint32_t FS_UNSORTED = 0x04u;   // positions decrease inside the contig
+constexpr uint32_t FS_UNSORTED = 0x04u;   // (contig, position) decreases along the file
 constexpr uint32_t FS_HP_TYPE = 0x08u;    // HP aux of a read offered to a locus is neither C nor i (src/call.rs:482-491 panics)
 constexpr uint32_t FS_SA_TYPE = 0x10u;    // SA aux of such a read is not Z (src/call.rs:429-432 panics)
 constexpr uint32_t FS_SA_FORMAT = 0x20u;  // SA string the reference cannot index / parse (src/call.rs:439-451 panics)
@@ -32,7 +33,7 @@ constexpr uint32_t FS_TOO_BIG = 0x40u;    // more CIGAR than 32-bit offsets in u
 struct FrontStatus {
     unsigned int err;         // FS_* bits
     unsigned int inflate;     // INQ_INFLATE_* bits
-    unsigned long long n_valid;      // records of the span's contig (a prefix of the record list)
+    unsigned long long n_valid;      // placed records (tid >= 0): a prefix of the record list
     unsigned long long first_bad;    // smallest record index that raised an FS_* bit (for the message)
     unsigned int max_reads;   // deepest locus
     unsigned int pad;
@@ -50,6 +51,7 @@ struct ScanArgs {
     const uint8_t *u;  // inflated bytes, >= 8 readable bytes of padding
     uint64_t u_bytes;
     const uint64_t *anchors;
+    const uint64_t *anchor_stop;  // where the chain of anchor i ends; INQ_ANCHOR_SEGMENT_END set = end of a segment
     uint64_t n_anchors;
     uint32_t *anchor_cnt;   // [n_anchors]
     uint64_t *anchor_base;  // [n_anchors + 1] exclusive scan of anchor_cnt
@@ -57,13 +59,14 @@ struct ScanArgs {
     uint64_t n_records;
     inq_read_t *reads;      // [n_records]
     RecInfo *info;          // [n_records]
-    int64_t *endpos;        // [n_records]
-    int64_t *pmax;          // [n_records] running maximum of endpos
+    int64_t *key;           // [n_records] (tid << 32) | (pos + 1): ascending in a coordinate-sorted file
+    int64_t *endkey;        // [n_records] (tid << 32) + (endpos + 1)
+    int64_t *pmax;          // [n_records] running maximum of endkey
     uint64_t *cig_off;      // [n_records + 1] exclusive scan of CIGAR sizes in units of 4 words
     uint32_t *cigar;        // gathered CIGAR words
     uint64_t n_cigar_units;
-    int32_t tid;
     uint32_t unphased;
+    const int32_t *locus_tid;
     const uint32_t *locus_start, *locus_end;
     uint64_t n_loci;
     uint32_t *locus_cnt;       // [n_loci]

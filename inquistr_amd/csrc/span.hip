@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -14,8 +17,8 @@
 namespace inq {
 
 struct SpanState {
-    DevBuf comp, blocks, u, block_status, anchors, anchor_cnt, anchor_base, rec_off, reads, info, endpos, pmax, cig_off, cigar,
-        lstart, lend, locus_cnt, locus_off, pair_read, p1, p2, tmp;
+    DevBuf comp, blocks, u, block_status, anchors, anchor_cnt, anchor_base, rec_off, reads, info, key, endkey, pmax, cig_off, cigar,
+        anchor_stop, ltid, lstart, lend, locus_cnt, locus_off, pair_read, p1, p2, tmp;
     FrontStatus *d_st = nullptr;
     struct Host {  // pinned readback area
         FrontStatus st;
@@ -38,7 +41,7 @@ double span_last_inflate_ms(SpanState *S) {
 void span_state_destroy(SpanState *S) {
     if (!S) return;
     for (DevBuf *b : {&S->comp, &S->blocks, &S->u, &S->block_status, &S->anchors, &S->anchor_cnt, &S->anchor_base, &S->rec_off,
-                      &S->reads, &S->info, &S->endpos, &S->pmax, &S->cig_off, &S->cigar, &S->lstart, &S->lend, &S->locus_cnt,
+                      &S->reads, &S->info, &S->key, &S->endkey, &S->pmax, &S->cig_off, &S->cigar, &S->anchor_stop, &S->ltid, &S->lstart, &S->lend, &S->locus_cnt,
                       &S->locus_off, &S->pair_read, &S->p1, &S->p2, &S->tmp})
         if (b->p) (void)hipFree(b->p);
     if (S->d_st) (void)hipFree(S->d_st);
@@ -108,6 +111,10 @@ int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t c
     ia.out_bytes = out_bytes;
     ia.block_status = want_block_status ? (uint32_t *)S->block_status.p : nullptr;
     ia.err = &S->d_st->inflate;
+    {
+        const char *dbg = std::getenv("INQ_INFLATE_DEBUG");
+        ia.debug_flags = dbg ? (uint32_t)std::atoi(dbg) : 0u;
+    }
     launch_bgzf_inflate(ia, s);
     HIP_TRY(c, hipGetLastError());
     return INQ_OK;
@@ -134,9 +141,9 @@ int bgzf_inflate_impl(inq_ctx *c, const uint8_t *comp, uint64_t comp_bytes, cons
 int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_stats_t *stats) {
     if (!c || !sp || !r) return INQ_ERR_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
-    if (sp->reserved || sp->reserved2 || sp->unphased > 1 || sp->tid < 0) return INQ_ERR_ARG;
-    if (sp->n_loci && (!sp->locus_start || !sp->locus_end || !r->phase1 || !r->phase2)) return INQ_ERR_ARG;
-    if (sp->n_anchors && !sp->anchors) return INQ_ERR_ARG;
+    if (sp->reserved || sp->unphased > 1) return INQ_ERR_ARG;
+    if (sp->n_loci && (!sp->locus_tid || !sp->locus_start || !sp->locus_end || !r->phase1 || !r->phase2)) return INQ_ERR_ARG;
+    if (sp->n_anchors && (!sp->anchors || !sp->anchor_stop)) return INQ_ERR_ARG;
     if (sp->n_loci >= 0xfffffff0ull) return INQ_ERR_ARG;
     if (sp->support == 0) return INQ_ERR_SUPPORT_ZERO;
     const uint64_t nb = sp->n_blocks;
@@ -144,10 +151,14 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     int rc = check_blocks(sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, true);
     if (rc != INQ_OK) return rc;
     for (uint64_t i = 0; i < sp->n_anchors; ++i) {
+        const uint64_t stop = sp->anchor_stop[i] & ~INQ_ANCHOR_SEGMENT_END;
         if (sp->anchors[i] > u_bytes || (i && sp->anchors[i] <= sp->anchors[i - 1])) return INQ_ERR_ARG;
+        if (stop < sp->anchors[i] || stop > u_bytes || (i + 1 < sp->n_anchors && stop > sp->anchors[i + 1])) return INQ_ERR_ARG;
     }
-    for (uint64_t j = 0; j < sp->n_loci; ++j)
+    for (uint64_t j = 0; j < sp->n_loci; ++j) {
+        if (sp->locus_tid[j] < 0) return INQ_ERR_ARG;
         if (sp->locus_start[j] < 10 || sp->locus_end[j] < sp->locus_start[j]) return INQ_ERR_LOCUS;
+    }
     r->n_tie_loci = 0;
     if (sp->n_loci == 0) return INQ_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -157,8 +168,16 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     const uint64_t nl = sp->n_loci, na = sp->n_anchors;
 
     // ---- stage 1: upload, inflate, count the records
+    const bool verbose = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
+    using clk = std::chrono::steady_clock;
+    const auto w0 = clk::now();
+    auto wall = [&](const char *what) {
+        if (verbose) std::fprintf(stderr, "[inq span host] %-28s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(clk::now() - w0).count());
+    };
     HIP_TRY(c, hipEventRecord(S->ev[0], s));
     if ((rc = ensure(c, S->anchors, na * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->anchor_stop, na * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->ltid, nl * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->anchor_cnt, na * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->anchor_base, (na + 1) * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->lstart, nl * 4)) != INQ_OK) return rc;
@@ -169,10 +188,13 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     if ((rc = ensure(c, S->p2, nl * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->tmp, scan_tmp_words(std::max<uint64_t>(std::max(na, nl), 1)) * 8)) != INQ_OK) return rc;
     if (na) HIP_TRY(c, hipMemcpyAsync(S->anchors.p, sp->anchors, na * 8, hipMemcpyHostToDevice, s));
+    if (na) HIP_TRY(c, hipMemcpyAsync(S->anchor_stop.p, sp->anchor_stop, na * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(S->ltid.p, sp->locus_tid, nl * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(S->lstart.p, sp->locus_start, nl * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(S->lend.p, sp->locus_end, nl * 4, hipMemcpyHostToDevice, s));
     if ((rc = upload_and_inflate(c, S, sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, false, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(S->ev[2], s));
+    wall("buffers + uploads enqueued");
 
     ScanArgs a;
     std::memset(&a, 0, sizeof a);
@@ -182,7 +204,8 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     a.n_anchors = na;
     a.anchor_cnt = (uint32_t *)S->anchor_cnt.p;
     a.anchor_base = (uint64_t *)S->anchor_base.p;
-    a.tid = sp->tid;
+    a.anchor_stop = (const uint64_t *)S->anchor_stop.p;
+    a.locus_tid = (const int32_t *)S->ltid.p;
     a.unphased = sp->unphased;
     a.locus_start = (const uint32_t *)S->lstart.p;
     a.locus_end = (const uint32_t *)S->lend.p;
@@ -208,12 +231,14 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     };
     if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
     const uint64_t n_rec = S->h->val[0];
+    wall("inflate + chain count done");
 
     // ---- stage 2: record offsets, fields, CIGAR sizes
     if ((rc = ensure(c, S->rec_off, n_rec * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->reads, n_rec * sizeof(inq_read_t))) != INQ_OK) return rc;
     if ((rc = ensure(c, S->info, n_rec * sizeof(RecInfo))) != INQ_OK) return rc;
-    if ((rc = ensure(c, S->endpos, n_rec * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->key, n_rec * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->endkey, n_rec * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->pmax, n_rec * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->cig_off, (n_rec + 1) * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->tmp, scan_tmp_words(std::max<uint64_t>(std::max(std::max(na, nl), n_rec), 1)) * 8)) != INQ_OK) return rc;
@@ -221,7 +246,8 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     a.n_records = n_rec;
     a.reads = (inq_read_t *)S->reads.p;
     a.info = (RecInfo *)S->info.p;
-    a.endpos = (int64_t *)S->endpos.p;
+    a.key = (int64_t *)S->key.p;
+    a.endkey = (int64_t *)S->endkey.p;
     a.pmax = (int64_t *)S->pmax.p;
     a.cig_off = (uint64_t *)S->cig_off.p;
     S->h->init_n_valid = n_rec;
@@ -235,6 +261,7 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     HIP_TRY(c, hipStreamSynchronize(s));
     if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
     const uint64_t n_valid = S->h->st.n_valid, n_units = S->h->val[1];
+    wall("parse done");
     if (n_valid > n_rec || n_valid >= 0xfffffff0ull || n_units >= 0xffffffffull) {
         if (stats) stats->front_status = FS_TOO_BIG;
         return INQ_ERR_BAM;
@@ -245,7 +272,7 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     a.cigar = (uint32_t *)S->cigar.p;
     a.n_cigar_units = n_units;
     launch_cigar_gather(a, n_valid, s);
-    launch_scan_max_i64(a.endpos, a.pmax, n_valid, (uint64_t *)S->tmp.p, s);
+    launch_scan_max_i64(a.endkey, a.pmax, n_valid, (uint64_t *)S->tmp.p, s);
     HIP_TRY(c, hipEventRecord(S->ev[3], s));
     launch_join_count(a, n_valid, s);
     launch_scan_u32_to_u64(a.locus_cnt, a.locus_pair_off, nl, (uint64_t *)S->tmp.p, s);
@@ -255,6 +282,7 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     HIP_TRY(c, hipStreamSynchronize(s));
     if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
     const uint64_t n_pairs = S->h->val[2];
+    wall("gather + join count done");
     if (n_pairs >= (1ull << 40)) return INQ_ERR_ARG;
 
     // ---- stage 4: pairs, then the locus kernels on the device-resident batch
@@ -294,6 +322,7 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     HIP_TRY(c, hipMemsetAsync(&c->d_status->err, 0, sizeof(unsigned int), s));
     HIP_TRY(c, hipMemsetAsync(&c->d_status->ties, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    wall("call done");
     S->n_reads = n_valid;
     S->n_cigar_words = n_units * 4;
     S->n_pairs = n_pairs;

@@ -58,6 +58,9 @@ class BgzfBlockC(C.Structure):
 BGZF_BLOCK_DTYPE = np.dtype([("comp_off", "<u8"), ("comp_len", "<u4"), ("isize", "<u4"), ("out_off", "<u8")])
 
 
+ANCHOR_SEGMENT_END = 1 << 63
+
+
 class SpanC(C.Structure):
     """inq_span_t"""
 
@@ -67,16 +70,16 @@ class SpanC(C.Structure):
         ("blocks", C.c_void_p),
         ("n_blocks", C.c_uint64),
         ("anchors", C.c_void_p),
+        ("anchor_stop", C.c_void_p),
         ("n_anchors", C.c_uint64),
-        ("tid", C.c_int32),
-        ("reserved", C.c_uint32),
+        ("locus_tid", C.c_void_p),
         ("locus_start", C.c_void_p),
         ("locus_end", C.c_void_p),
         ("n_loci", C.c_uint64),
         ("minlen", C.c_uint32),
         ("support", C.c_uint32),
         ("unphased", C.c_uint32),
-        ("reserved2", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -271,16 +274,20 @@ class Context:
             self._raise(rc)
         return rc, out, status
 
-    def call_span(self, comp, blocks: np.ndarray, anchors: np.ndarray, tid: int, locus_start: np.ndarray,
-                  locus_end: np.ndarray, minlen: int = 5, support: int = 3, unphased: bool = False, check: bool = True):
+    def call_span(self, comp, blocks: np.ndarray, anchors: np.ndarray, anchor_stop: np.ndarray, locus_tid: np.ndarray,
+                  locus_start: np.ndarray, locus_end: np.ndarray, minlen: int = 5, support: int = 3, unphased: bool = False,
+                  check: bool = True):
         """inq_call_span: returns (code, phase1, phase2, n_tie_loci, stats)."""
         comp = np.frombuffer(comp, dtype=np.uint8)
         blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK_DTYPE)
         anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
+        stops = np.ascontiguousarray(anchor_stop, dtype=np.uint64)
+        lt = np.ascontiguousarray(locus_tid, dtype=np.int32)
         ls = np.ascontiguousarray(locus_start, dtype=np.uint32)
         le = np.ascontiguousarray(locus_end, dtype=np.uint32)
-        sp = SpanC(comp.ctypes.data, comp.size, blocks.ctypes.data, len(blocks), anchors.ctypes.data, len(anchors), tid, 0,
-                   ls.ctypes.data, le.ctypes.data, len(ls), minlen, support, 1 if unphased else 0, 0)
+        assert len(stops) == len(anchors) and len(lt) == len(ls) == len(le)
+        sp = SpanC(comp.ctypes.data, comp.size, blocks.ctypes.data, len(blocks), anchors.ctypes.data, stops.ctypes.data,
+                   len(anchors), lt.ctypes.data, ls.ctypes.data, le.ctypes.data, len(ls), minlen, support, 1 if unphased else 0, 0)
         p1 = np.full(len(ls), np.nan)
         p2 = np.full(len(ls), np.nan)
         res = InqResultC(p1.ctypes.data, p2.ctypes.data, None, None, 0)

@@ -28,9 +28,9 @@
 
 using namespace inqhost;
 
-#ifndef INQ_DEFAULT_DEVICE_FRONT
-#define INQ_DEFAULT_DEVICE_FRONT false
-#endif
+// auto front-end choice: the device front end inflates a BGZF block per GPU lane, which takes tens of
+// milliseconds however few blocks there are; below this many compressed bytes the CPU sweep is quicker
+static constexpr uint64_t kDeviceFrontMinBytes = 48ull << 20;
 
 namespace {
 
@@ -248,8 +248,9 @@ private:
     std::string err_;
 };
 
-// Device front end, host half: a loader thread plans the spans, reads their compressed bytes (parallel pread
-// into page-locked buffers when a HIP device is there) and builds block tables and anchors, two spans ahead
+// Device front end, host half: a loader thread plans the spans, reads their compressed bytes (parallel pread;
+// into pageable memory by default: pinning a few hundred MB costs more than the staged copy it saves,
+// INQ_SPAN_PINNED=1 switches) and builds block tables and anchors, two spans ahead
 // of the caller, who feeds inq_call_span().
 class SpanPipeline {
 public:
@@ -338,12 +339,22 @@ private:
                 it = free_.back();
                 free_.pop_back();
             }
+            const auto t0 = std::chrono::steady_clock::now();
             if (!planner_.next(it->plan)) break;
-            uint64_t b = 0, en = 0;
-            if (!loader.extent(it->plan, &b, &en, &e)) return fail(e);
-            if (en - b > (64ull << 30)) return fail("a span of the BAM exceeds 64 GiB (index without usable bins)");
-            if (!fit(*it, (size_t)(en - b) + 64)) return fail("cannot allocate the span buffer");
-            if (!loader.load(it->plan, planner_.anchors(), b, en, it->buf, n_threads_, it->data, &e)) return fail(e);
+            uint64_t nbytes = 0;
+            const auto t1 = std::chrono::steady_clock::now();
+            if (!loader.total_bytes(it->plan, &nbytes, &e)) return fail(e);
+            if (nbytes > (64ull << 30)) return fail("a span of the BAM exceeds 64 GiB (index without usable bins)");
+            if (!fit(*it, (size_t)nbytes + 64)) return fail("cannot allocate the span buffer");
+            const auto t2 = std::chrono::steady_clock::now();
+            if (!loader.load(it->plan, planner_.anchors(), it->buf, n_threads_, it->data, &e)) return fail(e);
+            if (verbose_) {
+                const auto t3 = std::chrono::steady_clock::now();
+                auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                std::fprintf(stderr, "[inq loader] plan %.2f ms, buffer %.2f ms (%s), read+tables %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
+                             ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), nbytes / 1e6, it->plan.segs.size(),
+                             it->data.anchors.size());
+            }
             std::lock_guard<std::mutex> g(mu_);
             ready_.push_back(it);
             cv_item_.notify_one();
@@ -357,6 +368,7 @@ private:
     SpanPlanner planner_;
     int n_threads_;
     bool pinned_;
+    bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[3];
     std::vector<Item *> free_;
     std::deque<Item *> ready_;
@@ -370,7 +382,7 @@ private:
 static uint64_t span_bytes_from_env() {
     const char *e = std::getenv("INQ_SPAN_MB");
     const long v = e ? std::atol(e) : 0;
-    return v > 0 ? (uint64_t)v << 20 : (256ull << 20);
+    return v > 0 ? (uint64_t)v << 20 : (1024ull << 20);  // ~16k..40k BGZF blocks: enough lanes to fill the chip
 }
 
 struct inq_spans {
@@ -468,14 +480,20 @@ static int inq_frontend_next_impl(inq_frontend_t *fe, inq_batch_t *batch, const 
 void inq_frontend_close(inq_frontend_t *fe) { delete fe; }
 
 // front end selection: args->reserved 1 = host sweep (BGZF inflate + record decode on CPU threads),
-// 2 = device (inq_call_span); 0 = INQ_FRONTEND=host|device, else the default
-static bool use_device_front(const inq_call_args_t *args) {
+// 2 = device (inq_call_span); 0 = INQ_FRONTEND=host|device, else by the amount of BAM the loci need
+static bool use_device_front(const inq_call_args_t *args, const Prepared &P) {
     if (args->reserved == 1) return false;
     if (args->reserved == 2) return true;
     const char *e = std::getenv("INQ_FRONTEND");
     if (e && std::strcmp(e, "host") == 0) return false;
     if (e && std::strcmp(e, "device") == 0) return true;
-    return INQ_DEFAULT_DEVICE_FRONT;
+    // auto: plan without reading anything and count the compressed bytes the loci need
+    SpanPlanner planner(*P.bam, P.targets, ~0ull >> 1);
+    SpanPlan plan;
+    uint64_t bytes = 0;
+    while (planner.next(plan))
+        for (const Segment &g : plan.segs) bytes += (g.vo_limit >> 16) - (g.vo_begin >> 16) + 32768;
+    return bytes >= kDeviceFrontMinBytes;
 }
 
 // fills p1 / p2 through the device front end; returns an exit status
@@ -498,7 +516,8 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, std::v
     const int n_io = (int)std::max<uint64_t>(1, std::min<uint64_t>(args->threads, 32));
     std::vector<double> b1, b2;
     {
-        SpanPipeline pipe(args->bam, *F->P.bam, F->P.targets, span_bytes_from_env(), n_io, true);
+        const char *pin_env = std::getenv("INQ_SPAN_PINNED");
+        SpanPipeline pipe(args->bam, *F->P.bam, F->P.targets, span_bytes_from_env(), n_io, pin_env ? pin_env[0] == '1' : false);
         bool joined = false;
         for (;;) {
             SpanPipeline::Item *it = nullptr;
@@ -527,8 +546,9 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, std::v
             sp.blocks = it->data.blocks.data();
             sp.n_blocks = it->data.blocks.size();
             sp.anchors = it->data.anchors.data();
+            sp.anchor_stop = it->data.anchor_stop.data();
             sp.n_anchors = it->data.anchors.size();
-            sp.tid = it->plan.tid;
+            sp.locus_tid = it->plan.locus_tid.data();
             sp.locus_start = it->plan.locus_start.data();
             sp.locus_end = it->plan.locus_end.data();
             sp.n_loci = it->plan.locus_start.size();
@@ -591,7 +611,7 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     const size_t n = F->P.targets.size();
     std::vector<double> p1(n, NAN), p2(n, NAN);
 
-    if (use_device_front(args)) {
+    if (use_device_front(args, F->P)) {
         int drc = run_device_front(args, F, p1, p2, errbuf, errcap, &t_front, &t_dev);
         if (drc != INQ_EXIT_OK) return drc;
         drc = write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
@@ -930,8 +950,9 @@ static int inq_spans_next_impl(inq_spans_t *S, inq_span_t *sp, const uint32_t **
     sp->blocks = it->data.blocks.data();
     sp->n_blocks = it->data.blocks.size();
     sp->anchors = it->data.anchors.data();
+    sp->anchor_stop = it->data.anchor_stop.data();
     sp->n_anchors = it->data.anchors.size();
-    sp->tid = it->plan.tid;
+    sp->locus_tid = it->plan.locus_tid.data();
     sp->locus_start = it->plan.locus_start.data();
     sp->locus_end = it->plan.locus_end.data();
     sp->n_loci = it->plan.locus_start.size();

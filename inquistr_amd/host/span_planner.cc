@@ -5,6 +5,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -56,61 +58,59 @@ uint64_t BaiAnchors::limit_after(int tid, int64_t x) {
 
 // ---------------------------------------------------------------- planner
 SpanPlanner::SpanPlanner(const BamFile &bam, const std::vector<RepeatInterval> &targets, uint64_t max_comp_bytes)
-    : bam_(bam), anch_(bam.index()), max_comp_(max_comp_bytes ? max_comp_bytes : (256ull << 20)) {
-    std::vector<std::pair<int, uint32_t>> order;
-    for (uint32_t i = 0; i < targets.size(); ++i) order.emplace_back(bam_.tid(targets[i].chrom), i);
-    std::stable_sort(order.begin(), order.end(), [&](const auto &a, const auto &b) {
-        if (a.first != b.first) return a.first < b.first;
-        return targets[a.second].start < targets[b.second].start;
-    });
-    for (auto &o : order) {
-        if (o.first < 0 || (size_t)o.first >= bam_.index().refs.size()) continue;  // no index entry: nothing to fetch
-        const RepeatInterval &t = targets[o.second];
-        if (groups_.empty() || groups_.back().tid != o.first) groups_.push_back({o.first, {}});
-        groups_.back().loci.push_back({t.start, t.end, o.second});
+    : bam_(bam), anch_(bam.index()), max_comp_(max_comp_bytes ? max_comp_bytes : (1024ull << 20)) {
+    for (uint32_t i = 0; i < targets.size(); ++i) {
+        const int tid = bam_.tid(targets[i].chrom);
+        if (tid < 0 || (size_t)tid >= bam_.index().refs.size()) continue;  // no index entry: nothing to fetch
+        loci_.push_back({tid, targets[i].start, targets[i].end, i});
     }
+    if (const char *e = std::getenv("INQ_SPAN_GAP_BYTES")) gap_ = (uint64_t)std::strtoull(e, nullptr, 10);  // tests: force segments
+    std::stable_sort(loci_.begin(), loci_.end(), [](const Locus &a, const Locus &b) {
+        if (a.tid != b.tid) return a.tid < b.tid;
+        return a.start < b.start;
+    });
 }
 
 bool SpanPlanner::next(SpanPlan &out) {
-    constexpr uint64_t kGap = 4ull << 20;  // compressed bytes worth reading through rather than starting a new span
+    const uint64_t kGap = gap_;  // compressed bytes worth reading through rather than opening a segment
     const BaiIndex &idx = bam_.index();
-    for (; g_ < groups_.size(); ++g_, j_ = 0) {
-        const Group &G = groups_[g_];
-        while (j_ < G.loci.size()) {
-            const Locus &L0 = G.loci[j_];
-            // src/call.rs:285-286,335-336 (start >= 10 was checked by the driver)
-            const uint64_t vo0 = idx.scan_start(G.tid, (int64_t)L0.start - 10);
-            uint64_t lim = vo0 ? anch_.limit_after(G.tid, (int64_t)L0.end + 10) : 0;
-            if (vo0 == 0 || lim <= vo0) {  // no record can overlap this window
-                ++j_;
-                continue;
-            }
-            out = SpanPlan();
-            out.tid = G.tid;
-            out.vo_begin = vo0;
-            auto take = [&](const Locus &L) {
-                out.locus_index.push_back(L.index);
-                out.locus_start.push_back(L.start);
-                out.locus_end.push_back(L.end);
-            };
-            take(L0);
-            size_t j = j_ + 1;
-            for (; j < G.loci.size(); ++j) {
-                const Locus &L = G.loci[j];
-                const uint64_t vj = idx.scan_start(G.tid, (int64_t)L.start - 10);
-                if (vj == 0 || vj < vo0) break;
-                const uint64_t lj = std::max(lim, anch_.limit_after(G.tid, (int64_t)L.end + 10));
-                if ((vj >> 16) > (lim >> 16) + kGap) break;                 // jump the gap with a new span
-                if ((lj >> 16) - (vo0 >> 16) > max_comp_) break;            // span full
-                lim = lj;
-                take(L);
-            }
-            out.vo_limit = lim;
-            j_ = j;
-            return true;
+    out = SpanPlan();
+    uint64_t bytes = 0;  // compressed bytes of the closed segments
+    auto seg_bytes = [](const Segment &g) { return (g.vo_limit >> 16) - (g.vo_begin >> 16) + 65536; };
+    for (; j_ < loci_.size(); ++j_) {
+        const Locus &L = loci_[j_];
+        // src/call.rs:285-286,335-336 (start >= 10 was checked by the driver)
+        const uint64_t vo = idx.scan_start(L.tid, (int64_t)L.start - 10);
+        const uint64_t lim = vo ? anch_.limit_after(L.tid, (int64_t)L.end + 10) : 0;
+        if (vo == 0 || lim <= vo) continue;  // no record can overlap this window: the row stays NaN
+        bool extend = false;
+        if (!out.segs.empty()) {
+            const Segment &S = out.segs.back();
+            if (vo < S.vo_begin) break;  // index not monotone: start over with a new span
+            extend = (vo >> 16) <= (S.vo_limit >> 16) + kGap;
+            Segment grown = S;
+            if (extend) grown.vo_limit = std::max(S.vo_limit, lim);
+            const uint64_t after = extend ? bytes + seg_bytes(grown) : bytes + seg_bytes(S) + (lim >> 16) - (vo >> 16) + 65536;
+            if (after > max_comp_) break;  // span full (it holds at least one locus)
         }
+        if (extend) {
+            Segment &S = out.segs.back();
+            S.vo_limit = std::max(S.vo_limit, lim);
+            S.tid_last = L.tid;
+        } else {
+            if (!out.segs.empty()) bytes += seg_bytes(out.segs.back());
+            Segment g;
+            g.vo_begin = vo;
+            g.vo_limit = lim;
+            g.tid_first = g.tid_last = L.tid;
+            out.segs.push_back(g);
+        }
+        out.locus_index.push_back(L.index);
+        out.locus_tid.push_back(L.tid);
+        out.locus_start.push_back(L.start);
+        out.locus_end.push_back(L.end);
     }
-    return false;
+    return !out.segs.empty();
 }
 
 // ---------------------------------------------------------------- loader
@@ -157,7 +157,7 @@ static uint32_t bgzf_block_size(const uint8_t *h, size_t avail, uint32_t *head_l
     return (uint32_t)bsize + 1;
 }
 
-bool SpanLoader::extent(const SpanPlan &p, uint64_t *begin, uint64_t *end, std::string *err) const {
+bool SpanLoader::extent(const Segment &p, uint64_t *begin, uint64_t *end, std::string *err) const {
     *begin = p.vo_begin >> 16;
     const uint64_t lb = p.vo_limit >> 16;
     if (*begin >= size_) {
@@ -188,88 +188,136 @@ bool SpanLoader::extent(const SpanPlan &p, uint64_t *begin, uint64_t *end, std::
     return true;
 }
 
-bool SpanLoader::load(const SpanPlan &p, BaiAnchors &anch, uint64_t begin, uint64_t end, uint8_t *buf, int n_threads,
-                      SpanData &out, std::string *err) const {
+bool SpanLoader::total_bytes(const SpanPlan &p, uint64_t *bytes, std::string *err) const {
+    *bytes = 0;
+    for (const Segment &g : p.segs) {
+        uint64_t b, e;
+        if (!extent(g, &b, &e, err)) return false;
+        *bytes += e - b;
+    }
+    return true;
+}
+
+bool SpanLoader::load(const SpanPlan &p, BaiAnchors &anch, uint8_t *buf, int n_threads, SpanData &out, std::string *err) const {
     out.blocks.clear();
     out.anchors.clear();
-    out.comp_bytes = end - begin;
-    out.file_begin = begin;
-    const uint64_t n = end - begin;
-    // parallel pread: the page cache (or the device underneath) serves several streams faster than one
-    const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(n_threads, 1), n >> 22));
-    bool ok = true;
-    if (nt == 1) {
-        ok = pread_all(fd_, buf, begin, n);
-    } else {
-        std::vector<std::thread> th;
-        std::vector<char> res((size_t)nt, 1);
-        for (int t = 0; t < nt; ++t) {
-            const uint64_t lo = n * (uint64_t)t / (uint64_t)nt, hi = n * (uint64_t)(t + 1) / (uint64_t)nt;
-            th.emplace_back([&, t, lo, hi] { res[(size_t)t] = pread_all(fd_, buf + lo, begin + lo, hi - lo) ? 1 : 0; });
-        }
-        for (auto &x : th) x.join();
-        for (char r : res) ok = ok && r;
-    }
-    if (!ok) {
-        if (err) *err = "read error in BAM file";
-        return false;
-    }
-    // block table: hop from header to header
-    std::vector<uint64_t> starts;  // file offset of every block
-    uint64_t q = 0, uo = 0;
-    while (q < n) {
-        uint32_t head = 0;
-        const uint32_t bs = bgzf_block_size(buf + q, (size_t)(n - q), &head);
-        if (!bs || q + bs > n || bs < head + 8) {
-            if (err) *err = "not a BGZF block at offset " + std::to_string(begin + q);
-            return false;
-        }
-        const uint32_t isize = le32(buf + q + bs - 4);
-        if (isize > 65536) {
-            if (err) *err = "BGZF block with ISIZE > 64 KiB at offset " + std::to_string(begin + q);
-            return false;
-        }
-        inq_bgzf_block_t b;
-        b.comp_off = q + head;
-        b.comp_len = bs - head - 8;
-        b.isize = isize;
-        b.out_off = uo;
-        out.blocks.push_back(b);
-        starts.push_back(begin + q);
-        uo += isize;
-        q += bs;
-    }
-    // anchors: the contig's index offsets inside [vo_begin, vo_limit], as offsets into the inflated bytes
-    const auto &A = anch.ref(p.tid).anchors;
-    auto lo = std::lower_bound(A.begin(), A.end(), p.vo_begin), hi = std::upper_bound(A.begin(), A.end(), p.vo_limit);
-    out.anchors.reserve((size_t)(hi - lo) + 2);
-    auto map_vo = [&](uint64_t v, uint64_t *u) -> bool {
-        const uint64_t co = v >> 16, within = v & 0xffff;
-        if (co == end && within == 0) {
-            *u = uo;
-            return true;
-        }
-        auto it = std::lower_bound(starts.begin(), starts.end(), co);
-        if (it == starts.end() || *it != co) return false;
-        const inq_bgzf_block_t &b = out.blocks[(size_t)(it - starts.begin())];
-        if (within > b.isize) return false;
-        *u = b.out_off + within;
-        return true;
+    out.anchor_stop.clear();
+    out.comp_bytes = 0;
+    out.file_begin = p.segs.empty() ? 0 : p.segs[0].vo_begin >> 16;
+    // 1. where every segment goes in buf
+    struct Piece {
+        uint64_t begin, end, at;
     };
-    uint64_t u0;
-    if (!map_vo(p.vo_begin, &u0)) {
-        if (err) *err = "index offset does not match the BGZF blocks of the file";
-        return false;
+    std::vector<Piece> pieces;
+    for (const Segment &g : p.segs) {
+        uint64_t b, e;
+        if (!extent(g, &b, &e, err)) return false;
+        if (!pieces.empty() && b < pieces.back().end) {
+            if (err) *err = "index offsets of neighbouring loci overlap out of order";
+            return false;
+        }
+        pieces.push_back({b, e, out.comp_bytes});
+        out.comp_bytes += e - b;
     }
-    out.anchors.push_back(u0);
-    for (auto it = lo; it != hi; ++it) {
-        uint64_t u;
-        if ((*it >> 16) >= end && !((*it >> 16) == end && (*it & 0xffff) == 0)) break;
-        if (!map_vo(*it, &u)) {
+    // 2. parallel pread: the page cache (or the device underneath) serves several streams faster than one
+    {
+        struct Job {
+            uint64_t off, n, at;
+        };
+        std::vector<Job> jobs;
+        const uint64_t chunk = std::max<uint64_t>(4ull << 20, out.comp_bytes / (uint64_t)std::max(n_threads, 1) / 4 + 1);
+        for (const Piece &pc : pieces)
+            for (uint64_t o = pc.begin; o < pc.end; o += chunk) jobs.push_back({o, std::min(chunk, pc.end - o), pc.at + (o - pc.begin)});
+        std::atomic<size_t> nextj{0};
+        std::atomic<bool> ok{true};
+        auto work = [&] {
+            for (;;) {
+                const size_t k = nextj.fetch_add(1);
+                if (k >= jobs.size()) return;
+                if (!pread_all(fd_, buf + jobs[k].at, jobs[k].off, jobs[k].n)) ok = false;
+            }
+        };
+        const int nt = (int)std::min<size_t>((size_t)std::max(n_threads, 1), jobs.size());
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        if (!ok) {
+            if (err) *err = "read error in BAM file";
+            return false;
+        }
+    }
+    // 3. block table (hop from header to header) and anchors, segment by segment
+    uint64_t uo = 0;
+    for (size_t si = 0; si < p.segs.size(); ++si) {
+        const Segment &g = p.segs[si];
+        const Piece &pc = pieces[si];
+        const uint64_t n = pc.end - pc.begin;
+        const size_t first_block = out.blocks.size();
+        std::vector<uint64_t> starts;  // file offset of every block of the segment
+        uint64_t q = 0;
+        while (q < n) {
+            uint32_t head = 0;
+            const uint8_t *h = buf + pc.at + q;
+            const uint32_t bs = bgzf_block_size(h, (size_t)(n - q), &head);
+            if (!bs || q + bs > n || bs < head + 8) {
+                if (err) *err = "not a BGZF block at offset " + std::to_string(pc.begin + q);
+                return false;
+            }
+            const uint32_t isize = le32(h + bs - 4);
+            if (isize > 65536) {
+                if (err) *err = "BGZF block with ISIZE > 64 KiB at offset " + std::to_string(pc.begin + q);
+                return false;
+            }
+            inq_bgzf_block_t b;
+            b.comp_off = pc.at + q + head;
+            b.comp_len = bs - head - 8;
+            b.isize = isize;
+            b.out_off = uo;
+            out.blocks.push_back(b);
+            starts.push_back(pc.begin + q);
+            uo += isize;
+            q += bs;
+        }
+        const uint64_t seg_u_end = uo;
+        auto map_vo = [&](uint64_t v, uint64_t *u) -> bool {
+            const uint64_t co = v >> 16, within = v & 0xffff;
+            if (co == pc.end && within == 0) {
+                *u = seg_u_end;
+                return true;
+            }
+            auto it = std::lower_bound(starts.begin(), starts.end(), co);
+            if (it == starts.end() || *it != co) return false;
+            const inq_bgzf_block_t &b = out.blocks[first_block + (size_t)(it - starts.begin())];
+            if (within > b.isize) return false;
+            *u = b.out_off + within;
+            return true;
+        };
+        const size_t first_anchor = out.anchors.size();
+        uint64_t u0;
+        if (!map_vo(g.vo_begin, &u0)) {
             if (err) *err = "index offset does not match the BGZF blocks of the file";
             return false;
         }
-        if (u > out.anchors.back()) out.anchors.push_back(u);  // (block, isize) and (next block, 0) name the same byte
+        out.anchors.push_back(u0);
+        // the index offsets of every contig with records in the segment, in file order
+        for (int tid = g.tid_first; tid <= g.tid_last; ++tid) {
+            const auto &A = anch.ref(tid).anchors;
+            auto lo = std::lower_bound(A.begin(), A.end(), g.vo_begin), hi = std::upper_bound(A.begin(), A.end(), g.vo_limit);
+            for (auto it = lo; it != hi; ++it) {
+                const uint64_t co = *it >> 16;
+                if (co > pc.end || (co == pc.end && (*it & 0xffff) != 0)) break;
+                if (co < pc.begin) continue;
+                uint64_t u;
+                if (!map_vo(*it, &u)) {
+                    if (err) *err = "index offset does not match the BGZF blocks of the file";
+                    return false;
+                }
+                if (u > out.anchors.back() && u < seg_u_end) out.anchors.push_back(u);  // (block, isize) == (next block, 0)
+            }
+        }
+        for (size_t k = first_anchor; k < out.anchors.size(); ++k)
+            out.anchor_stop.push_back(k + 1 < out.anchors.size() ? out.anchors[k + 1] : (seg_u_end | INQ_ANCHOR_SEGMENT_END));
     }
     return true;
 }

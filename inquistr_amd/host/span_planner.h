@@ -1,8 +1,9 @@
 // span_planner.h — host side of the device front end: which bytes of the BAM a group of loci needs.
 //
 // The reference asks htslib for every locus separately (bam.fetch((tid, start-10, end+10)),
-// src/call.rs:288,338); here the loci of a contig, sorted by start, are cut into SPANS: runs of loci plus
-// the range of whole BGZF blocks that holds every record overlapping any of them.  The host never
+// src/call.rs:288,338); here the loci, sorted by (contig, start), are cut into SPANS: runs of loci plus the
+// whole BGZF blocks that hold every record overlapping any of them, as one or more segments of the file
+// (loci far apart get their own segment, so what lies between is neither read nor inflated).  The host never
 // inflates: it reads the compressed bytes, walks the 18-byte BGZF headers for the block table and takes
 // from the .bai (a) where to start (linear index), (b) where it can stop (the first chunk of a bin that
 // starts behind the last window: everything at smaller positions lies in front of it in a coordinate-
@@ -37,12 +38,18 @@ private:
     std::vector<PerRef> refs_;
 };
 
-struct SpanPlan {
-    int tid = -1;
-    std::vector<uint32_t> locus_index;  // into the target list
-    std::vector<uint32_t> locus_start, locus_end;
+// A run of consecutive BGZF blocks: from the block of vo_begin to the block of vo_limit.
+struct Segment {
     uint64_t vo_begin = 0;  // first record to look at
     uint64_t vo_limit = 0;  // record start (or end of data) behind everything needed
+    int tid_first = -1, tid_last = -1;  // contigs whose records lie in the segment
+};
+
+struct SpanPlan {
+    std::vector<Segment> segs;  // ascending, disjoint
+    std::vector<uint32_t> locus_index;  // into the target list
+    std::vector<int32_t> locus_tid;
+    std::vector<uint32_t> locus_start, locus_end;
 };
 
 class SpanPlanner {
@@ -55,25 +62,23 @@ public:
 
 private:
     struct Locus {
-        uint32_t start, end, index;
-    };
-    struct Group {
         int tid;
-        std::vector<Locus> loci;
+        uint32_t start, end, index;
     };
     const BamFile &bam_;
     BaiAnchors anch_;
     uint64_t max_comp_;
-    std::vector<Group> groups_;
-    size_t g_ = 0, j_ = 0;
+    uint64_t gap_ = 128ull << 10;  // a gap of compressed bytes up to this is read through rather than skipped
+    std::vector<Locus> loci_;  // sorted by (tid, start)
+    size_t j_ = 0;
 };
 
 // One loaded span: compressed bytes (caller's buffer), block table, anchors.
 struct SpanData {
     std::vector<inq_bgzf_block_t> blocks;
-    std::vector<uint64_t> anchors;
+    std::vector<uint64_t> anchors, anchor_stop;
     uint64_t comp_bytes = 0;
-    uint64_t file_begin = 0;  // file offset of comp[0]
+    uint64_t file_begin = 0;  // file offset of the first segment
 };
 
 class SpanLoader {
@@ -82,12 +87,13 @@ public:
     ~SpanLoader();
     bool open(const std::string &path, std::string *err);
     uint64_t file_size() const { return size_; }
-    // Byte range [begin, end) of whole BGZF blocks a plan needs (reads one block header at the limit).
-    bool extent(const SpanPlan &p, uint64_t *begin, uint64_t *end, std::string *err) const;
-    // Reads [begin, end) into buf with n_threads preads, walks the block headers, maps the plan's .bai
-    // anchors to offsets in the inflated byte string.
-    bool load(const SpanPlan &p, BaiAnchors &anch, uint64_t begin, uint64_t end, uint8_t *buf, int n_threads, SpanData &out,
-              std::string *err) const;
+    // Byte range [begin, end) of whole BGZF blocks a segment needs (reads one block header at the limit).
+    bool extent(const Segment &g, uint64_t *begin, uint64_t *end, std::string *err) const;
+    // Total compressed bytes of a plan (sum of its segments' extents).
+    bool total_bytes(const SpanPlan &p, uint64_t *bytes, std::string *err) const;
+    // Reads every segment into buf (back to back) with n_threads preads, walks the block headers, maps the
+    // .bai anchors inside each segment to offsets in the inflated byte string.
+    bool load(const SpanPlan &p, BaiAnchors &anch, uint8_t *buf, int n_threads, SpanData &out, std::string *err) const;
 
 private:
     int fd_ = -1;

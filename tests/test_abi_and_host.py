@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     L = hipcall.load()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.inq_abi_version() == 1
+    assert L.inq_abi_version() == 2
     assert b"no CPU fallback" in L.inq_strerror(B.INQ_ERR_NO_DEVICE)
 
 
@@ -47,7 +47,10 @@ def test_struct_layout_matches_header():
     assert C.sizeof(B.InqBatchC) == 4 * 8 + 6 * 8 + 4 * 4
     assert C.sizeof(B.InqResultC) == 5 * 8
     hdr = open(os.path.join(ROOT, "include", "inquistr_hip.h")).read()
-    for name, val in (("INQ_ERR_ARG", -1), ("INQ_ERR_INDEX", -7), ("INQ_ERR_NO_DEVICE", -10)):
+    assert C.sizeof(hipcall.BgzfBlockC) == 24 == hipcall.BGZF_BLOCK_DTYPE.itemsize
+    assert C.sizeof(hipcall.SpanC) == 11 * 8 + 4 * 4 and C.sizeof(hipcall.SpanStatsC) == 5 * 8 + 2 * 4 + 8 + 5 * 8
+    for name, val in (("INQ_ERR_ARG", -1), ("INQ_ERR_INDEX", -7), ("INQ_ERR_NO_DEVICE", -10), ("INQ_ERR_INFLATE", -11),
+                      ("INQ_ERR_BAM", -12), ("INQ_ERR_AUX", -13)):
         assert re.search(rf"{name} = {val}\b", hdr) and getattr(B, name) == val
 
 

@@ -146,21 +146,25 @@ def _locus_view(batch_or_arrays, j):
     return out
 
 
-@pytest.mark.parametrize("seed,unphased,span_bytes", [(1, False, 0), (2, True, 20_000), (3, False, 3_000), (4, True, 1), (5, False, 0)])
-def test_call_span_matches_oracle_and_host_emulation(ctx, tmp_path, seed, unphased, span_bytes):
+@pytest.mark.parametrize("seed,unphased,span_bytes,gap", [(1, False, 0, None), (2, True, 20_000, None), (3, False, 3_000, None),
+                                                          (4, True, 1, None), (5, False, 0, 0), (6, True, 30_000, 0)])
+def test_call_span_matches_oracle_and_host_emulation(ctx, tmp_path, monkeypatch, seed, unphased, span_bytes, gap):
     from inquistr_amd import call
     from tests import gen
     from tests.test_host_frontend import _expected, _make_case
     from tests.test_host_spans import emulate_span
+    from tools import bamio
 
+    if gap is not None:
+        monkeypatch.setenv("INQ_SPAN_GAP_BYTES", str(gap))  # spans made of several segments of the file
     minlen, support = 5, [3, 1, 2, 3][seed % 4]
-    bam, bed, loci, recs = _make_case(tmp_path, seed, ultra_long=(seed == 3))
+    bam, bed, loci, recs = _make_case(tmp_path, seed, ultra_long=(seed == 3), block=bamio.BLOCK if gap is None else 1500)
     sp = call.Spans(bam, region_file=bed, minlen=minlen, support=support, threads=2, unphased=unphased, max_comp_bytes=span_bytes)
     got1 = np.full(len(loci), np.nan)
     got2 = np.full(len(loci), np.nan)
     for span in sp.spans():
-        rc, p1, p2, ties, stats = ctx.call_span(span["comp"], span["blocks"], span["anchors"], span["tid"], span["locus_start"],
-                                                span["locus_end"], minlen, support, unphased)
+        rc, p1, p2, ties, stats = ctx.call_span(span["comp"], span["blocks"], span["anchors"], span["anchor_stop"], span["locus_tid"],
+                                                span["locus_start"], span["locus_end"], minlen, support, unphased)
         assert rc == 0
         idx = span["locus_index"]
         got1[idx], got2[idx] = p1, p2

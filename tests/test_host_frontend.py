@@ -80,7 +80,7 @@ def test_text_side_matches_kats(kat):
 REFS = [("chr1", 400_000), ("chr2", 300_000), ("chr10", 250_000), ("chrX", 200_000), ("chrEmpty", 50_000)]
 
 
-def _make_case(tmp_path, seed, n_loci=60, ultra_long=False):
+def _make_case(tmp_path, seed, n_loci=60, ultra_long=False, block=bamio.BLOCK):
     """Random coordinate-sorted BAM + BED.  Returns (bam, bed, loci, records_by_tid)."""
     rng = random.Random(seed)
     loci = []
@@ -110,7 +110,7 @@ def _make_case(tmp_path, seed, n_loci=60, ultra_long=False):
             recs[t].append(py.Record(pos=rng.randint(0, REFS[t][1] - 2000), cigar=gen.random_cigar(rng, 9), mapq=60,
                                      hp=("C", rng.choice([1, 2]))))
     bam = str(tmp_path / f"case{seed}.sorted.bam")
-    w = bamio.BamWriter(bam, REFS)
+    w = bamio.BamWriter(bam, REFS, block=block)
     k = 0
     for t in range(len(REFS)):
         recs[t].sort(key=lambda r: r.pos)  # stable: file order among equal positions = insertion order

@@ -11,17 +11,28 @@ from tests.test_host_frontend import _expected, _make_case
 from tools import bamio
 
 
+SEG_END = 1 << 63
+
+
 def emulate_span(sp):
-    """The batch the device builds from one span, in plain Python: zlib inflate, record chain from the
-    first anchor, htslib's overlap rule per locus."""
+    """The batch the device builds from one span, in plain Python: zlib inflate, record chains from the
+    anchors of every segment, htslib's overlap rule per locus."""
     u = bamio.inflate_span(sp["comp"], sp["blocks"])
     anchors = [int(a) for a in sp["anchors"]]
-    recs = list(bamio.read_records(u, anchors[0]))
-    starts = {r["off"] for r in recs}
-    cut = recs[-1]["off"] if recs else 0
-    for a in anchors:  # every anchor the chain reaches must be a record start
-        assert a in starts or a > cut, a
-    reads = [r for r in recs if r["tid"] == sp["tid"]]
+    stops = [int(a) for a in sp["anchor_stop"]]
+    recs = []
+    for k, (a, st) in enumerate(zip(anchors, stops)):
+        end = st & ~SEG_END
+        chain = list(bamio.read_records(u[:end], a))
+        nxt = chain[-1]["next"] if chain else a
+        if st & SEG_END:
+            assert nxt <= end
+        else:
+            assert nxt == end == anchors[k + 1], (k, nxt, end)  # a chain lands on the next anchor
+        recs += chain
+    reads = [r for r in recs if r["tid"] >= 0]
+    keys = [(r["tid"], r["pos"]) for r in reads]
+    assert keys == sorted(keys)
     bb = B.BatchBuilder(minlen=sp["minlen"], support=sp["support"], unphased=sp["unphased"])
     ends = []
     for r in reads:
@@ -34,29 +45,35 @@ def emulate_span(sp):
                     phase=(hp[1] & 0xFF) if hp and hp[0] in "Ci" else None,
                     reverse=bool(r["flag"] & 0x10), unmapped=bool(r["flag"] & 0x4),
                     is_2d=bool(has_clip and r["sa"] and py.is_accidental_2d(rec)))
-    for s, e in zip(sp["locus_start"], sp["locus_end"]):
+    for t, s, e in zip(sp["locus_tid"], sp["locus_start"], sp["locus_end"]):
         lo, hi = int(s) - 10, int(e) + 10
-        bb.add_locus(int(s), int(e), [i for i, r in enumerate(reads) if r["pos"] < hi and ends[i] > lo])
+        bb.add_locus(int(s), int(e), [i for i, r in enumerate(reads) if r["tid"] == int(t) and r["pos"] < hi and ends[i] > lo])
     return bb.build()
 
 
-@pytest.mark.parametrize("seed,unphased,span_bytes", [(1, False, 0), (2, True, 20_000), (3, False, 3_000), (4, True, 1)])
-def test_spans_reproduce_per_locus_fetch(tmp_path, orc, seed, unphased, span_bytes):
+@pytest.mark.parametrize("seed,unphased,span_bytes,gap", [(1, False, 0, None), (2, True, 20_000, None), (3, False, 3_000, None),
+                                                          (4, True, 1, None), (5, False, 0, 0), (6, True, 30_000, 0)])
+def test_spans_reproduce_per_locus_fetch(tmp_path, orc, monkeypatch, seed, unphased, span_bytes, gap):
+    if gap is not None:
+        monkeypatch.setenv("INQ_SPAN_GAP_BYTES", str(gap))  # every gap between loci opens a new segment
     minlen, support = 5, [3, 1, 2, 3][seed % 4]
-    bam, bed, loci, recs = _make_case(tmp_path, seed, ultra_long=(seed == 3))
+    # small BGZF blocks when segments are wanted: the test file is far smaller than real gaps
+    bam, bed, loci, recs = _make_case(tmp_path, seed, ultra_long=(seed == 3), block=bamio.BLOCK if gap is None else 1500)
     sp = call.Spans(bam, region_file=bed, minlen=minlen, support=support, threads=3, unphased=unphased, max_comp_bytes=span_bytes)
     assert sp.n_targets == len(loci)
     got1 = np.full(len(loci), np.nan)
     got2 = np.full(len(loci), np.nan)
     seen = np.zeros(len(loci), dtype=int)
-    n_spans = 0
+    n_spans = n_segments = 0
     for span in sp.spans():
         n_spans += 1
+        n_segments += int((span["anchor_stop"] >= np.uint64(SEG_END)).sum())
         # whole blocks, dense output offsets, ascending anchors inside the inflated bytes
         blocks = span["blocks"]
         assert (blocks["out_off"][1:] == blocks["out_off"][:-1] + blocks["isize"][:-1]).all() and blocks["out_off"][0] == 0
         total = int(blocks["out_off"][-1] + blocks["isize"][-1])
         assert (np.diff(span["anchors"].astype(np.int64)) > 0).all() and int(span["anchors"][-1]) <= total
+        assert int(span["anchor_stop"][-1]) == total | SEG_END
         batch = emulate_span(span)
         code, res = orc.call_batch(batch)
         assert code == 0
@@ -66,6 +83,8 @@ def test_spans_reproduce_per_locus_fetch(tmp_path, orc, seed, unphased, span_byt
     assert seen.max() == 1  # a locus belongs to one span; loci in no span have no record near them
     if span_bytes and span_bytes < 50_000:
         assert n_spans > 3
+    if gap == 0 and not span_bytes:
+        assert n_spans == 1 and n_segments > 1  # all contigs in one call, made of several pieces of the file
     want1, want2 = _expected(loci, recs, unphased, minlen, support)
     assert gen.same_f64(got1, want1) and gen.same_f64(got2, want2)
     sp.close()

@@ -80,8 +80,9 @@ def bgzf_block(data: bytes, level: int = 1) -> bytes:
 
 
 class BamWriter:
-    def __init__(self, path: str, refs: Sequence[Tuple[str, int]], header_text: Optional[str] = None, level: int = 1):
-        self.path, self.refs, self.level = path, list(refs), level
+    def __init__(self, path: str, refs: Sequence[Tuple[str, int]], header_text: Optional[str] = None, level: int = 1,
+                 block: int = BLOCK):
+        self.path, self.refs, self.level, self.block = path, list(refs), level, block
         if header_text is None:
             header_text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
         h = b"BAM\1" + struct.pack("<I", len(header_text)) + header_text.encode() + struct.pack("<I", len(refs))
@@ -107,16 +108,16 @@ class BamWriter:
     def close(self, write_index: bool = True):
         data = bytes(self.buf)
         coff, out = [], bytearray()
-        for i in range(0, max(len(data), 1), BLOCK):
+        for i in range(0, max(len(data), 1), self.block):
             coff.append(len(out))
-            out += bgzf_block(data[i : i + BLOCK], self.level)
+            out += bgzf_block(data[i : i + self.block], self.level)
         end_coff = len(out)
         out += EOF_BLOCK
         with open(self.path, "wb") as f:
             f.write(out)
 
         def vo(u):
-            blk, within = divmod(u, BLOCK)
+            blk, within = divmod(u, self.block)
             if blk >= len(coff):
                 return end_coff << 16
             return (coff[blk] << 16) | within
@@ -236,5 +237,5 @@ def read_records(u: bytes, off: int):
         if cg and cg[0] == "B" and cg[1][0] in "Ii" and words and pos >= 0 and (words[0] & 15) == 4 and (words[0] >> 4) == l_seq \
                 and len(cg[1][1]) >= len(words):
             words = [w & 0xFFFFFFFF for w in cg[1][1]]
-        yield dict(off=off, tid=tid, pos=pos, mapq=mapq, flag=flag, cigar=words, hp=hp, sa=sa)
+        yield dict(off=off, next=b + bs, tid=tid, pos=pos, mapq=mapq, flag=flag, cigar=words, hp=hp, sa=sa)
         off = b + bs
