@@ -164,6 +164,7 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * deeper-locus kernels (defaults 8192 / 1024); "max_reads_hint" = N > 0 promises that no locus of the
  * following batches is offered more than N reads (N <= 64 skips both extra launches; a violated promise
  * is reported as INQ_ERR_ARG), 0 (default) = unknown;
+ * "verify_crc" = 0 skips the CRC32 check of the device front end (default 1);
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);
@@ -195,6 +196,7 @@ typedef struct inq_bgzf_block {
 #define INQ_INFLATE_OUTPUT_SIZE 0x08u   /* more or fewer bytes than isize                                      */
 #define INQ_INFLATE_BAD_DISTANCE 0x10u  /* a match reaches in front of the block                               */
 #define INQ_INFLATE_BAD_STORED 0x20u    /* stored block LEN / NLEN mismatch                                    */
+#define INQ_INFLATE_BAD_CRC 0x40u       /* inflated bytes do not match the CRC32 of the block's trailer        */
 
 /* Inflates n_blocks BGZF payloads; every pointer is HOST memory (the call uploads, runs one lane per
  * block, downloads, synchronises).  block_status may be NULL.  Returns INQ_ERR_INFLATE if any block

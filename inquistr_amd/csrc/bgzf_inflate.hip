@@ -467,10 +467,62 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
     if (st) atomicOr(a.err, st);
 }
 
+// ---------------------------------------------------------------- CRC32 of the inflated blocks
+// htslib checks every block against the CRC32 in its trailer ([3P] bgzf.c check_header / inflate_block);
+// a mismatch is a read error, i.e. a panic in the reference (src/call.rs:295,346).  One lane per block
+// again: slice-by-4 with the 4 KB table shared by the workgroup in LDS, 16 bytes per load.
+__global__ __launch_bounds__(kLanes) void bgzf_crc32_kernel(InflateArgs a) {
+    __shared__ uint32_t T[4][256];
+    for (int i = (int)threadIdx.x; i < 256; i += kLanes) {
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        T[0][i] = c;
+    }
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < 256; i += kLanes) {
+        uint32_t c = T[0][i];
+        for (int t = 1; t < 4; ++t) {
+            c = T[0][c & 0xffu] ^ (c >> 8);
+            T[t][i] = c;
+        }
+    }
+    __syncthreads();
+    const uint64_t bi = (uint64_t)blockIdx.x * kLanes + threadIdx.x;
+    if (bi >= a.n_blocks) return;
+    const inq_bgzf_block_t blk = a.blocks[bi];
+    // blocks the inflate kernel rejected keep their status; extents were checked there
+    if (a.block_status && a.block_status[bi]) return;
+    if (blk.comp_off > a.comp_bytes || (uint64_t)blk.comp_len + 8u > a.comp_bytes - blk.comp_off || blk.out_off > a.out_bytes ||
+        (uint64_t)blk.isize > a.out_bytes - blk.out_off)
+        return;
+    const uint8_t *p = a.out + blk.out_off;
+    const uint32_t n = blk.isize;
+    uint32_t crc = 0xffffffffu, k = 0;
+    auto word = [&](uint32_t w) {
+        crc ^= w;
+        crc = T[3][crc & 0xffu] ^ T[2][(crc >> 8) & 0xffu] ^ T[1][(crc >> 16) & 0xffu] ^ T[0][crc >> 24];
+    };
+    for (; k + 16u <= n; k += 16u) {
+        const uint32_t w0 = load_u32(p + k), w1 = load_u32(p + k + 4), w2 = load_u32(p + k + 8), w3 = load_u32(p + k + 12);
+        word(w0);
+        word(w1);
+        word(w2);
+        word(w3);
+    }
+    for (; k < n; ++k) crc = T[0][(crc ^ p[k]) & 0xffu] ^ (crc >> 8);
+    crc = ~crc;
+    const uint32_t want = load_u32(a.comp + blk.comp_off + blk.comp_len);
+    if (crc != want) {
+        if (a.block_status) a.block_status[bi] = INQ_INFLATE_BAD_CRC;
+        atomicOr(a.err, INQ_INFLATE_BAD_CRC);
+    }
+}
+
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s) {
     if (!a.n_blocks) return;
     const uint64_t grid = (a.n_blocks + kLanes - 1) / kLanes;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
+    if (a.verify_crc) hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
 }
 
 }  // namespace inq

@@ -354,6 +354,10 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
         c->max_reads_hint = (uint32_t)value;
         return INQ_OK;
     }
+    if (std::strcmp(key, "verify_crc") == 0) {
+        c->verify_crc = value != 0;
+        return INQ_OK;
+    }
     if (std::strcmp(key, "nt_loads") == 0) {
         c->nt_loads = value < 0 ? -1 : (value != 0);
         return INQ_OK;

@@ -38,6 +38,7 @@ struct inq_ctx {
     uint32_t call_hint = 0;       // set by the host-buffer entry, which sees the offsets, for its own launch
     int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
     bool timing = false;
+    bool verify_crc = true;  // device front end: check inflated blocks against their CRC32
     std::vector<inq::EvTriple> ev_pool;
     size_t ev_used = 0;
     inq::SpanState *span = nullptr;  // created on first use by the device front end

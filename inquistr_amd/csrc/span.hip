@@ -78,7 +78,8 @@ int check_blocks(const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_
     uint64_t next = 0;
     for (uint64_t i = 0; i < n_blocks; ++i) {
         const inq_bgzf_block_t &b = blocks[i];
-        if (b.comp_off > comp_bytes || b.comp_len > comp_bytes - b.comp_off) return INQ_ERR_ARG;
+        // payload + the 8-byte CRC32 / ISIZE trailer of the block
+        if (b.comp_off > comp_bytes || (uint64_t)b.comp_len + 8u > comp_bytes - b.comp_off) return INQ_ERR_ARG;
         if (b.isize > 65536u || b.out_off > out_bytes || b.isize > out_bytes - b.out_off) return INQ_ERR_ARG;
         if (dense && b.out_off != next) return INQ_ERR_ARG;
         next = b.out_off + b.isize;
@@ -111,6 +112,7 @@ int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t c
     ia.out_bytes = out_bytes;
     ia.block_status = want_block_status ? (uint32_t *)S->block_status.p : nullptr;
     ia.err = &S->d_st->inflate;
+    ia.verify_crc = c->verify_crc ? 1u : 0u;
     {
         const char *dbg = std::getenv("INQ_INFLATE_DEBUG");
         ia.debug_flags = dbg ? (uint32_t)std::atoi(dbg) : 0u;

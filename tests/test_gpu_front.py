@@ -115,10 +115,21 @@ def test_inflate_reports_corruption(ctx):
         zlib_ok = len(alt) == n
     except zlib.error:
         zlib_ok = False
-    if zlib_ok:
-        assert status[1] == 0 and out[n : 2 * n].tobytes() == alt
+    if zlib_ok:  # inflates, to other bytes: only the CRC32 of the trailer notices
+        assert status[1] == 0x40 and out[n : 2 * n].tobytes() == alt and rc == hipcall.INQ_ERR_INFLATE
     else:
         assert status[1] != 0 and rc == hipcall.INQ_ERR_INFLATE
+    # a wrong CRC32 in the trailer (htslib: read error); not looked at with verify_crc = 0
+    bad_crc = bytearray(good + good + good)
+    bad_crc[int(blocks[2]["comp_off"]) + int(blocks[2]["comp_len"])] ^= 1
+    rc, out, status = ctx.bgzf_inflate(bytes(bad_crc), blocks, check=False)
+    assert rc == hipcall.INQ_ERR_INFLATE and list(status) == [0, 0, 0x40] and out.tobytes() == data * 3
+    ctx.set_option("verify_crc", 0)
+    try:
+        rc, out, status = ctx.bgzf_inflate(bytes(bad_crc), blocks, check=False)
+        assert rc == 0 and not status.any()
+    finally:
+        ctx.set_option("verify_crc", 1)
     # wrong ISIZE
     blocks2 = blocks.copy()
     blocks2["isize"][1] -= 1
