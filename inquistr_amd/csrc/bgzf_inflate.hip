@@ -48,19 +48,21 @@ __device__ __forceinline__ void store_u32(uint8_t *p, uint32_t w) { __builtin_me
 // Bit cursor over the payload.  The compressed bytes are fetched 16 at a time, one fetch AHEAD of their
 // use (cur = being consumed, nxt = in flight), so the decoder waits for a load issued ~10 symbols ago.
 struct BitReader {
-    const uint8_t *p;    // first byte NOT yet handed to the bit buffer (drives overrun / stored-block math)
-    const uint8_t *end;  // end of this block's deflate payload
+    const uint8_t *p;     // first byte NOT yet handed to the bit buffer (drives overrun / stored-block math)
+    const uint8_t *end;   // end of this block's deflate payload
+    const uint8_t *hard;  // last address a 16-byte fetch may start at (inside the padding of the whole buffer)
     uint64_t bb;
     uint32_t bc;
     const uint8_t *fetch;  // address of nxt
     uint64_t cur_lo, cur_hi, nxt_lo, nxt_hi;
     uint32_t cur_n;        // dwords left in cur
+    // Unconditional load from a clamped address: what lies behind the payload (trailer, next block) is
+    // only ever consumed by a corrupt stream, which overrun() then reports.  No branch around the load:
+    // a conditional one makes the compiler stage it through temporaries and wait for it on the spot.
     __device__ __forceinline__ void load16(const uint8_t *q, uint64_t &lo, uint64_t &hi) const {
-        if (q < end) {  // the buffer carries >= 16 bytes of padding behind the last payload
-            lo = (uint64_t)load_u32(q) | ((uint64_t)load_u32(q + 4) << 32);
-            hi = (uint64_t)load_u32(q + 8) | ((uint64_t)load_u32(q + 12) << 32);
-        } else
-            lo = hi = 0ull;  // zeros behind the payload; overrun() reports their use
+        q = q < hard ? q : hard;
+        lo = (uint64_t)load_u32(q) | ((uint64_t)load_u32(q + 4) << 32);
+        hi = (uint64_t)load_u32(q + 8) | ((uint64_t)load_u32(q + 12) << 32);
     }
     __device__ __forceinline__ void start(const uint8_t *from) {  // (re)position at a byte
         p = from;
@@ -70,6 +72,8 @@ struct BitReader {
         load16(from + 16, nxt_lo, nxt_hi);
         fetch = from + 16;
         cur_n = 4u;
+        // settle cur here, once, rather than in front of every use inside the decode loop
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     __device__ __forceinline__ void refill() {  // afterwards bc > 32
         if (bc <= 32u) {
@@ -109,9 +113,14 @@ struct BitReader {
 // Copies n <= 16 bytes whose source and destination do not overlap: the four loads are issued before the
 // first store, so the lane pays ONE memory round trip (on gfx9 a load's data is only usable once every
 // earlier store of the wave has been acknowledged: load/store ping-pong costs a round trip per element).
-__device__ __forceinline__ void copy_quad(uint8_t *dst, const uint8_t *src, uint32_t n) {
-    // reads up to 15 bytes past n: inside the padded buffers, never stored
-    const uint32_t w0 = load_u32(src), w1 = load_u32(src + 4), w2 = load_u32(src + 8), w3 = load_u32(src + 12);
+struct Quad {
+    uint32_t w0, w1, w2, w3;
+};
+__device__ __forceinline__ Quad load_quad(const uint8_t *src) {  // reads 16 bytes: inside the padded buffers
+    return Quad{load_u32(src), load_u32(src + 4), load_u32(src + 8), load_u32(src + 12)};
+}
+__device__ __forceinline__ void store_quad(uint8_t *dst, const Quad &q, uint32_t n) {  // the first n <= 16 bytes of q
+    const uint32_t w0 = q.w0, w1 = q.w1, w2 = q.w2, w3 = q.w3;
     if (n == 16u) {
         store_u32(dst, w0);
         store_u32(dst + 4, w1);
@@ -125,6 +134,10 @@ __device__ __forceinline__ void copy_quad(uint8_t *dst, const uint8_t *src, uint
     if (n >= 12u) store_u32(dst + 8, w2), k = 12u;
     uint32_t t = k == 0u ? w0 : k == 4u ? w1 : k == 8u ? w2 : w3;
     for (; k < n; ++k, t >>= 8) dst[k] = (uint8_t)t;
+}
+__device__ __forceinline__ void copy_quad(uint8_t *dst, const uint8_t *src, uint32_t n) {
+    const Quad q = load_quad(src);
+    store_quad(dst, q, n);
 }
 
 __device__ __forceinline__ void copy_forward(uint8_t *dst, const uint8_t *src, uint32_t n) {
@@ -356,12 +369,20 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
         const uint8_t *start = a.comp + blk.comp_off;
         BitReader b;
         b.end = start + blk.comp_len;
+        b.hard = a.comp + a.comp_bytes + 32;  // the buffer carries 64 bytes of padding
         b.start(start);
         uint8_t *out = a.out + blk.out_off;
         const uint32_t isize = blk.isize;
         uint32_t o = 0;
         Code lit, dist;
         bool last = false;
+        // A match of <= 16 bytes is split in time: its loads are issued when it is decoded, its stores when
+        // the NEXT match (or the end of the block) comes up, so the memory round trip overlaps the decoding
+        // of the symbols in between.  Literals in between go to other addresses; a later match that reads
+        // these bytes issues its loads after these stores, which is all same-lane ordering needs.
+        Quad pend = {0u, 0u, 0u, 0u};
+        uint8_t *pend_dst = out;
+        uint32_t pend_n = 0;
         while (!last && st == 0u) {
             b.refill();
             if (b.overrun(start)) {
@@ -454,10 +475,22 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
                     st = kOutputSize;
                     break;
                 }
-                if (!(a.debug_flags & 2u)) copy_match(out + o, dd, len);
+                if (pend_n) {
+                    store_quad(pend_dst, pend, pend_n);
+                    pend_n = 0;
+                }
+                if (!(a.debug_flags & 2u)) {
+                    if (len <= 16u && dd >= len) {
+                        pend = load_quad(out + o - dd);
+                        pend_dst = out + o;
+                        pend_n = len;
+                    } else
+                        copy_match(out + o, dd, len);
+                }
                 o += len;
             }
         }
+        if (pend_n) store_quad(pend_dst, pend, pend_n);
         if (st == 0u) {
             if (o != isize) st = kOutputSize;
             else if (b.overrun(start)) st = kInputOverrun;

@@ -9,7 +9,7 @@
 namespace inq {
 
 struct InflateArgs {
-    const uint8_t *comp;  // whole BGZF blocks; >= 32 readable bytes behind comp_bytes
+    const uint8_t *comp;  // whole BGZF blocks; >= 64 readable bytes behind comp_bytes
     uint64_t comp_bytes;
     const inq_bgzf_block_t *blocks;
     uint64_t n_blocks;

@@ -10,6 +10,7 @@ from tests.test_host_frontend import _make_case
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
+ap.add_argument("--frontend", default=None, choices=[None, "host", "device"])
 a = ap.parse_args()
 bad = 0
 with tempfile.TemporaryDirectory() as td:
@@ -19,12 +20,12 @@ with tempfile.TemporaryDirectory() as td:
         bam, bed, loci, recs = _make_case(pathlib.Path(td), seed, n_loci=30 + (i % 5) * 25, ultra_long=(i % 4 == 0))
         out = os.path.join(td, "o.inq")
         with open(out, "w") as f:
-            call.genotype_repeats(bam, None, bed, 5, [3, 1, 2][i % 3], threads, unphased, None, None, out=f)
+            call.genotype_repeats(bam, None, bed, 5, [3, 1, 2][i % 3], threads, unphased, None, None, out=f, frontend=a.frontend)
         want = _expected_text(loci, recs, unphased, 5, [3, 1, 2][i % 3], f"case{seed}.sorted", threads)
         if open(out).read() != want:
             bad += 1
             print(f"MISMATCH seed={seed} unphased={unphased} threads={threads}", flush=True)
         for p in (bam, bam + ".bai", bed):
             os.unlink(p)
-print(f"e2e soak done: {a.cases} cases, {bad} mismatches")
+print(f"e2e soak done ({a.frontend or 'auto'} front end): {a.cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
