@@ -12,7 +12,9 @@ from typing import Optional, Tuple
 import numpy as np
 
 from .batch import (
+    INQ_ERR_ARG,
     INQ_ERR_AUX,
+    INQ_ERR_LOCUS,
     INQ_ERR_BAM,
     INQ_ERR_INFLATE,
     INQ_ERR_NO_DEVICE,

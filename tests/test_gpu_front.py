@@ -248,3 +248,103 @@ def test_device_front_end_error_classes(tmp_path):
     with pytest.raises(call.CallError) as e:
         run([ok[0], py.Record(pos=4700, cigar=[("M", 500)], hp=("C", 1))] + ok[1:], sort=False)
     assert e.value.status == 101
+
+
+def test_device_front_end_region_string_and_long_cigar_tag(tmp_path):
+    """-r with one locus; reads with 70 000 CIGAR ops (real CIGAR in CG:B,I behind <l_seq>S<ref>N) through the
+    device record scan; both front ends must print the row the Python restatement gives."""
+    from inquistr_amd import call
+    from oracle import pyoracle as py
+    from tests import gen
+    from tools import bamio
+
+    rng = random.Random(9)
+    big = gen.random_cigar(rng, 70_000)
+    span = py.reference_end(py.Record(pos=0, cigar=big))
+    start = 1000 + span // 2
+    recs = [py.Record(pos=1000, cigar=big, mapq=60, hp=("C", 1), tid=0) for _ in range(3)]
+    recs += [py.Record(pos=start - 200, cigar=[("M", 150), ("I", 30 + k), ("M", 400)], hp=("i", 2), tid=0) for k in range(3)]
+    recs.sort(key=lambda r: r.pos)
+    bam = str(tmp_path / "long.bam")
+    w = bamio.BamWriter(bam, [("chr7", span + 100_000)])
+    for i, r in enumerate(recs):
+        w.add(f"r{i}", 0, 0, r.pos, 60, r.cigar, [("HP", r.hp[0], r.hp[1])], l_seq=5)
+    w.close()
+    a, b = py.genotype_repeat_phased(recs, 0, start, start + 100, 5, 3)
+    want = py.format_header("S") + "\n" + py.format_row("chr7", start, start + 100, a, b) + "\n"
+    for fe in ("host", "device"):
+        out = tmp_path / f"{fe}.inq"
+        with open(out, "w") as f:
+            call.genotype_repeats(bam, f"chr7:{start}-{start + 100}", None, 5, 3, 1, False, "S", None, out=f, frontend=fe)
+        assert out.read_text() == want, fe
+
+
+@pytest.mark.parametrize("workload,loci", [("phased10k", 3000), ("expansion50k", 1500)])
+def test_device_front_end_on_synthetic_workloads(tmp_path, workload, loci):
+    """The benchmark's BAM generator at a few thousand loci: HP-phased reads, soft clips, 2000-op reads;
+    device front end = host front end, byte for byte, with -t 1 (BED order) and -t 4 (sorted)."""
+    from inquistr_amd import call, synth
+    from tools import make_synth_bam
+
+    prefix = str(tmp_path / "w")
+    make_synth_bam.write(workload, loci, prefix)
+    wl = synth.WORKLOADS[workload]
+    for threads in (1, 4):
+        texts = {}
+        for fe in ("host", "device"):
+            out = tmp_path / f"{fe}{threads}.inq"
+            with open(out, "w") as f:
+                call.genotype_repeats(prefix + ".bam", None, prefix + ".bed", wl.minlen, wl.support, threads, wl.unphased, "S", None,
+                                      out=f, frontend=fe)
+            texts[fe] = out.read_text()
+        assert texts["host"] == texts["device"] and texts["host"].count("\n") == loci + 1
+        assert "NaN\tNaN" not in texts["host"].split("\n", 2)[1]
+
+
+def test_call_span_rejects_malformed_spans(ctx, tmp_path):
+    """Shape errors are caught on the host before any kernel runs; device-detected ones come back as codes."""
+    from inquistr_amd import call
+    from tests.test_host_frontend import _make_case
+
+    bam, bed, loci, recs = _make_case(tmp_path, 21, n_loci=20)
+    span = next(iter(call.Spans(bam, region_file=bed).spans()))
+    args = [span[k] for k in ("comp", "blocks", "anchors", "anchor_stop", "locus_tid", "locus_start", "locus_end")]
+
+    def run(**kw):
+        a = dict(zip(("comp", "blocks", "anchors", "anchor_stop", "locus_tid", "locus_start", "locus_end"), args))
+        a.update(kw)
+        return ctx.call_span(a["comp"], a["blocks"], a["anchors"], a["anchor_stop"], a["locus_tid"], a["locus_start"], a["locus_end"],
+                             5, 3, False, check=False)[0]
+
+    assert run() == 0
+    # anchors out of order / behind the inflated bytes / stop in front of its anchor
+    bad = span["anchors"].copy()
+    bad[[0, 1]] = bad[[1, 0]]
+    assert run(anchors=bad) == hipcall.INQ_ERR_ARG
+    stops = span["anchor_stop"].copy()
+    stops[0] = 0
+    assert run(anchor_stop=stops) == hipcall.INQ_ERR_ARG
+    # block table that is not dense, or points outside comp
+    blocks = span["blocks"].copy()
+    blocks["out_off"][1] += 1
+    assert run(blocks=blocks) == hipcall.INQ_ERR_ARG
+    blocks = span["blocks"].copy()
+    blocks["comp_len"][-1] += 1 << 20
+    assert run(blocks=blocks) == hipcall.INQ_ERR_ARG
+    # locus out of domain, negative contig
+    ls = span["locus_start"].copy()
+    ls[0] = 5
+    assert run(locus_start=ls) == hipcall.INQ_ERR_LOCUS
+    lt = span["locus_tid"].copy()
+    lt[0] = -1
+    assert run(locus_tid=lt) == hipcall.INQ_ERR_ARG
+    # an anchor that is not a record start: the chain does not land on the next anchor
+    bad = span["anchors"].copy()
+    if len(bad) > 2:
+        bad[1] += 1
+        assert run(anchors=bad) == hipcall.INQ_ERR_BAM
+    # a flipped payload byte: CRC32 (or the inflate itself) notices
+    comp = span["comp"].copy()
+    comp[int(span["blocks"]["comp_off"][0]) + 30] ^= 0x10
+    assert run(comp=comp) == hipcall.INQ_ERR_INFLATE
+    assert run() == 0  # the ctx is usable after every error
