@@ -65,7 +65,7 @@ def cpu_baseline(wl, sample_loci: int):
     }
 
 
-def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str = ""):
+def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str = "", cpu_modes: str = "CBA"):
     """L2: BAM + BED -> .inq.  The product CLI (C++ sweep front end + HIP kernels) next to this bench's CPU
     baseline leg at that level: oracle/ref_shaped_call, the reference's control flow (BASELINE.md §3 modes
     A / B / C) around the oracle — a CPU restatement, not the Rust binary.  Outputs are compared byte for
@@ -118,14 +118,15 @@ def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str =
     res["gpu_cli"] = {"seconds": t_gpu, "loci_per_s": loci / t_gpu, "threads": threads,
                       "front_end": "device" if t_dev <= t_host else "host"}
     for mode, thr in (("C", 1), ("B", threads), ("A", threads)):
+        if mode not in cpu_modes:
+            continue
         t, out = timed([ref, prefix + ".bam", prefix + ".bed", mode, str(thr), str(int(wl.unphased)), str(wl.minlen),
                         str(wl.support), "S"], 1 if mode == "A" else reps)
         same = sorted(out.splitlines()) == sorted(out_gpu.splitlines()) if mode == "C" else out == out_gpu
         res[f"cpu_{mode}"] = {"seconds": t, "loci_per_s": loci / t, "threads": thr, "inq_identical": bool(same)}
     return {"level": "L2 end-to-end BAM+BED -> .inq", "workload": workload, "loci": loci,
             "bam_mb": os.path.getsize(prefix + ".bam") / 1e6, "bam_gen_s": gen_s, **res,
-            "speedup_vs_A": res["cpu_A"]["seconds"] / t_gpu, "speedup_vs_B": res["cpu_B"]["seconds"] / t_gpu,
-            "speedup_vs_C": res["cpu_C"]["seconds"] / t_gpu,
+            **{f"speedup_vs_{m}": res[f"cpu_{m}"]["seconds"] / t_gpu for m in "ABC" if f"cpu_{m}" in res},
             "note": "CPU modes = oracle/ref_shaped_call: CPU restatement of the reference's control flow, not the Rust binary"}
 
 
@@ -147,9 +148,10 @@ def main():
     ap.add_argument("--l2-loci", type=int, default=20_000)
     ap.add_argument("--l2-threads", type=int, default=0)
     ap.add_argument("--l2-keep", default="", help="directory to keep / reuse the generated BAM in")
+    ap.add_argument("--l2-cpu-modes", default="CBA", help="which CPU baseline modes to time (A is slow on large inputs)")
     args = ap.parse_args()
     if args.l2:
-        print(json.dumps(l2_end_to_end(args.workload, args.l2_loci, args.l2_threads or host_threads(), 2, args.l2_keep)), flush=True)
+        print(json.dumps(l2_end_to_end(args.workload, args.l2_loci, args.l2_threads or host_threads(), 2, args.l2_keep, args.l2_cpu_modes)), flush=True)
         return
 
     import torch

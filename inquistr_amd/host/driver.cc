@@ -1,5 +1,6 @@
 // driver.cc — `call::genotype_repeats` (src/call.rs:76-159) on top of the front end and the HIP library,
 // plus the C ABI of include/inquistr_host.h.
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -13,6 +14,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -301,7 +303,7 @@ private:
     void release_buf(Item &it) {
         if (it.buf) {
             if (it.pinned) inq_free_pinned(it.buf);
-            else std::free(it.buf);
+            else ::munmap(it.buf, it.cap);
         }
         it.buf = nullptr;
         it.cap = 0;
@@ -313,8 +315,17 @@ private:
         void *p = nullptr;
         if (pinned_ && inq_alloc_pinned(want, &p) == INQ_OK) it.pinned = true;
         else {
-            p = std::malloc(want);
+            // anonymous mapping with transparent huge pages where the kernel offers them: a span is hundreds of
+            // MB written once by pread; 4 KB pages cost a fault each on the way in and a free on the way out
+            const size_t huge = 2u << 20;
+            const size_t len = (want + huge - 1) / huge * huge;
+            p = ::mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (p == MAP_FAILED) p = nullptr;
+            else (void)::madvise(p, len, MADV_HUGEPAGE);
             it.pinned = false;
+            it.buf = (uint8_t *)p;
+            it.cap = p ? len : 0;
+            return p != nullptr;
         }
         it.buf = (uint8_t *)p;
         it.cap = p ? want : 0;
@@ -502,22 +513,42 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, std::v
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const int timing = std::getenv("INQ_TIMING") ? (std::getenv("INQ_TIMING")[0] == '2' ? 2 : 1) : 0;
+    const auto t_begin = clk::now();
+    bool leak_all = false;  // set after a clean run when the process is about to exit (INQ_FAST_EXIT)
     inq_ctx_t *ctx = nullptr;
     int hrc = INQ_OK;
     std::thread ctx_thread([&] { hrc = inq_ctx_create(args->device, &ctx); });
     struct CtxGuard {
         inq_ctx_t *&c;
         std::thread &t;
+        int timing;
+        const bool &leak;
         ~CtxGuard() {
             if (t.joinable()) t.join();
+            if (leak) return;
+            const auto t0 = std::chrono::steady_clock::now();
             inq_ctx_destroy(c);
+            if (timing)
+                std::fprintf(stderr, "[inq timing] ctx destroy %.3fs\n",
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         }
-    } cg{ctx, ctx_thread};
+    } cg{ctx, ctx_thread, timing, leak_all};
     const int n_io = (int)std::max<uint64_t>(1, std::min<uint64_t>(args->threads, 32));
     std::vector<double> b1, b2;
     {
         const char *pin_env = std::getenv("INQ_SPAN_PINNED");
-        SpanPipeline pipe(args->bam, *F->P.bam, F->P.targets, span_bytes_from_env(), n_io, pin_env ? pin_env[0] == '1' : false);
+        // the CLI sets INQ_FAST_EXIT: it is about to leave the process, so the span buffers (unmapping a GB
+        // of touched pages takes ~0.1 s) and the device context are left to the operating system
+        const bool fast_exit = std::getenv("INQ_FAST_EXIT") != nullptr;
+        struct PipeHolder {
+            SpanPipeline *p;
+            const bool &leak;
+            ~PipeHolder() {
+                if (!leak) delete p;
+            }
+        } holder{new SpanPipeline(args->bam, *F->P.bam, F->P.targets, span_bytes_from_env(), n_io, pin_env ? pin_env[0] == '1' : false),
+                 leak_all};
+        SpanPipeline &pipe = *holder.p;
         bool joined = false;
         for (;;) {
             SpanPipeline::Item *it = nullptr;
@@ -587,7 +618,10 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, std::v
             pipe.release(it);
         }
         if (!joined) ctx_thread.join();
+        leak_all = fast_exit;  // only after a clean run: error paths tear down normally
+        if (timing) std::fprintf(stderr, "[inq timing] spans done at %.3fs after the start of the device path\n", secs(t_begin, clk::now()));
     }
+    if (timing) std::fprintf(stderr, "[inq timing] loader joined at %.3fs\n", secs(t_begin, clk::now()));
     if (hrc != INQ_OK) {  // no GPU is an error even for an empty target list
         set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
         return INQ_EXIT_ERROR;
@@ -611,13 +645,20 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     const size_t n = F->P.targets.size();
     std::vector<double> p1(n, NAN), p2(n, NAN);
 
-    if (use_device_front(args, F->P)) {
+    const auto t_open = clk::now();
+    const bool device_front = use_device_front(args, F->P);
+    if (device_front) {
+        const auto t_choice = clk::now();
         int drc = run_device_front(args, F, p1, p2, errbuf, errcap, &t_front, &t_dev);
         if (drc != INQ_EXIT_OK) return drc;
+        const auto t_run = clk::now();
         drc = write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
         if (timing)
-            std::fprintf(stderr, "[inq timing] device front end: waiting for spans %.3fs  device calls %.3fs  total %.3fs\n", t_front,
-                         t_dev, secs(t_start, clk::now()));
+            std::fprintf(stderr,
+                         "[inq timing] device front end: open+targets %.3fs  front-end choice %.3fs  spans %.3fs (waiting for the loader "
+                         "%.3fs, device calls %.3fs)  output %.3fs  total %.3fs\n",
+                         secs(t_start, t_open), secs(t_open, t_choice), secs(t_choice, t_run), t_front, t_dev, secs(t_run, clk::now()),
+                         secs(t_start, clk::now()));
         return drc;
     }
 
@@ -754,11 +795,19 @@ static int write_rows(const inq_call_args_t *args, inq_frontend *F, const std::v
     if (args->threads > 1) {
         // genotypes_vec.sort_unstable() with Ord = (human_compare(chrom), start), :33-38,141.  Equal keys
         // are in completion order in the reference (nondeterministic); BED order is kept here.
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            int c = human_compare(F->P.targets[x].chrom, F->P.targets[y].chrom);
-            if (c != 0) return c < 0;
-            return F->P.targets[x].start < F->P.targets[y].start;
-        });
+        // The contig names are ranked once (a BED has few distinct ones), the rows sorted on integers.
+        std::map<std::string, uint32_t> rank;
+        for (const auto &t : F->P.targets) rank.emplace(t.chrom, 0u);
+        std::vector<const std::string *> names;
+        for (auto &kv : rank) names.push_back(&kv.first);
+        std::stable_sort(names.begin(), names.end(), [](const std::string *a, const std::string *b) { return human_compare(*a, *b) < 0; });
+        for (size_t i = 0, r = 0; i < names.size(); ++i) {
+            if (i && human_compare(*names[i - 1], *names[i]) != 0) ++r;  // names that compare equal share a rank
+            rank[*names[i]] = (uint32_t)r;
+        }
+        std::vector<uint64_t> key(n);
+        for (size_t i = 0; i < n; ++i) key[i] = ((uint64_t)rank[F->P.targets[i].chrom] << 32) | F->P.targets[i].start;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
     }
     std::string text = format_header(F->P.sample) + "\n";
     text.reserve(64 * (n + 1));
