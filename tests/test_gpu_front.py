@@ -348,3 +348,72 @@ def test_call_span_rejects_malformed_spans(ctx, tmp_path):
     comp[int(span["blocks"]["comp_off"][0]) + 30] ^= 0x10
     assert run(comp=comp) == hipcall.INQ_ERR_INFLATE
     assert run() == 0  # the ctx is usable after every error
+
+
+def test_inflate_fuzz_agrees_with_zlib_on_mutated_streams(ctx):
+    """Thousands of damaged DEFLATE payloads: the kernel must accept exactly what zlib accepts (stream ends, ISIZE
+    bytes produced), with the same bytes, and flag everything else - without faulting or hanging on any of them."""
+    rng = random.Random(2024)
+    base = []
+    for k in range(24):
+        n = rng.choice([40, 300, 2000, 9000])
+        kind = k % 4
+        if kind == 0:
+            data = bytes(rng.choice(b"ACGTN=") for _ in range(n))
+        elif kind == 1:
+            data = bytes(rng.getrandbits(8) for _ in range(n))
+        elif kind == 2:
+            data = (bytes(rng.getrandbits(8) for _ in range(17)) * (n // 17 + 1))[:n]
+        else:
+            data = b"".join(struct.pack("<I", rng.randint(1, 400) << 4 | rng.choice([0, 1, 2, 4])) for _ in range(n // 4))
+        level, strategy = rng.choice([(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                      (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_HUFFMAN_ONLY)])
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        base.append((co.compress(data) + co.flush(), len(data)))
+    payloads, isizes = [], []
+    for _ in range(4000):
+        p, n = rng.choice(base)
+        p = bytearray(p)
+        for _ in range(rng.choice([0, 1, 1, 1, 2, 5])):
+            how = rng.random()
+            at = rng.randrange(len(p))
+            if how < 0.6:
+                p[at] ^= 1 << rng.randrange(8)
+            elif how < 0.8:
+                p[at] = rng.getrandbits(8)
+            elif how < 0.9 and len(p) > 8:
+                del p[rng.randrange(len(p) // 2, len(p)):]  # truncate
+            else:
+                p[at:at] = bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 4)))  # insert
+        payloads.append(bytes(p))
+        isizes.append(n if rng.random() < 0.9 else max(0, n + rng.choice([-1, 1, 7])))
+    # lay the payloads out like BGZF blocks: payload + 8 trailer bytes (CRC not checked here)
+    comp = bytearray()
+    blocks = np.zeros(len(payloads), dtype=hipcall.BGZF_BLOCK_DTYPE)
+    uo = 0
+    for i, (p, n) in enumerate(zip(payloads, isizes)):
+        blocks[i] = (len(comp), len(p), n, uo)
+        comp += p + bytes(8)
+        uo += n
+    ctx.set_option("verify_crc", 0)
+    try:
+        rc, out, status = ctx.bgzf_inflate(bytes(comp), blocks, check=False)
+    finally:
+        ctx.set_option("verify_crc", 1)
+    n_ok = 0
+    for i, (p, n) in enumerate(zip(payloads, isizes)):
+        d = zlib.decompressobj(-15)
+        try:
+            got = d.decompress(p, n + 1)  # one byte more than the block may hold
+            accept = d.eof and len(got) == n
+        except zlib.error:
+            accept, got = False, b""
+        o = int(blocks[i]["out_off"])
+        if accept:
+            n_ok += 1
+            assert status[i] == 0, (i, hex(int(status[i])))
+            assert out[o : o + n].tobytes() == got, i
+        else:
+            assert status[i] != 0, (i, len(p), n)
+    assert 400 < n_ok < 3600  # the corpus exercises both outcomes
+    assert (rc == 0) == (n_ok == len(payloads))
