@@ -521,4 +521,9 @@ void launch_scan_max_i64(const int64_t *in, int64_t *out, uint64_t n, uint64_t *
     run_scan<MaxOp, LoadI64, false>(LoadI64{in}, out, n, (int64_t *)tmp, s);
 }
 
+// An empty launch makes the runtime load this translation unit's code object now (inq_ctx_create, on the
+// context thread) instead of in front of the first real launch.
+__global__ void preload_scan_kernel() {}
+void preload_scan(hipStream_t s) { hipLaunchKernelGGL(preload_scan_kernel, dim3(1), dim3(64), 0, s); }
+
 }  // namespace inq

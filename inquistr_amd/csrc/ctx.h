@@ -60,5 +60,8 @@ int ensure(inq_ctx *c, DevBuf &b, size_t bytes);
 int call_batch_device_impl(inq_ctx *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream);
 int status_to_code(uint32_t st);
 void span_state_destroy(SpanState *s);
+void preload_locus(hipStream_t s);
+void preload_inflate(hipStream_t s);
+void preload_scan(hipStream_t s);
 double span_last_inflate_ms(SpanState *s);  // kernel time of the last inflate launch, < 0 if none
 }  // namespace inq

@@ -490,6 +490,27 @@ static int inq_frontend_next_impl(inq_frontend_t *fe, inq_batch_t *batch, const 
 
 void inq_frontend_close(inq_frontend_t *fe) { delete fe; }
 
+// The device context is created on its own thread from the first instruction of the command: HIP start-up
+// (0.1 - 0.3 s) is the longest fixed cost of a run and overlaps opening the BAM, the BED, the .bai and the
+// first reads of the file.
+struct AsyncCtx {
+    inq_ctx_t *ctx = nullptr;
+    int hrc = INQ_OK;
+    std::thread th;
+    bool leak = false;  // set after a clean run when the process is about to exit (INQ_FAST_EXIT)
+    void start(int device) {
+        th = std::thread([this, device] { hrc = inq_ctx_create(device, &ctx); });
+    }
+    bool wait() {
+        if (th.joinable()) th.join();
+        return hrc == INQ_OK;
+    }
+    ~AsyncCtx() {
+        if (th.joinable()) th.join();
+        if (!leak) inq_ctx_destroy(ctx);
+    }
+};
+
 // front end selection: args->reserved 1 = host sweep (BGZF inflate + record decode on CPU threads),
 // 2 = device (inq_call_span); 0 = INQ_FRONTEND=host|device, else by the amount of BAM the loci need
 static bool use_device_front(const inq_call_args_t *args, const Prepared &P) {
@@ -508,31 +529,15 @@ static bool use_device_front(const inq_call_args_t *args, const Prepared &P) {
 }
 
 // fills p1 / p2 through the device front end; returns an exit status
-static int run_device_front(const inq_call_args_t *args, inq_frontend *F, std::vector<double> &p1, std::vector<double> &p2,
-                            char *errbuf, size_t errcap, double *t_front, double *t_dev) {
+static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncCtx &actx, std::vector<double> &p1,
+                            std::vector<double> &p2, char *errbuf, size_t errcap, double *t_front, double *t_dev) {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const int timing = std::getenv("INQ_TIMING") ? (std::getenv("INQ_TIMING")[0] == '2' ? 2 : 1) : 0;
     const auto t_begin = clk::now();
-    bool leak_all = false;  // set after a clean run when the process is about to exit (INQ_FAST_EXIT)
-    inq_ctx_t *ctx = nullptr;
-    int hrc = INQ_OK;
-    std::thread ctx_thread([&] { hrc = inq_ctx_create(args->device, &ctx); });
-    struct CtxGuard {
-        inq_ctx_t *&c;
-        std::thread &t;
-        int timing;
-        const bool &leak;
-        ~CtxGuard() {
-            if (t.joinable()) t.join();
-            if (leak) return;
-            const auto t0 = std::chrono::steady_clock::now();
-            inq_ctx_destroy(c);
-            if (timing)
-                std::fprintf(stderr, "[inq timing] ctx destroy %.3fs\n",
-                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-        }
-    } cg{ctx, ctx_thread, timing, leak_all};
+    bool &leak_all = actx.leak;
+    inq_ctx_t *&ctx = actx.ctx;
+    int &hrc = actx.hrc;
     const int n_io = (int)std::max<uint64_t>(1, std::min<uint64_t>(args->threads, 32));
     std::vector<double> b1, b2;
     {
@@ -563,7 +568,7 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, std::v
             }
             if (nb == 0) break;
             if (!joined) {
-                ctx_thread.join();
+                actx.wait();
                 joined = true;
             }
             if (hrc != INQ_OK) {
@@ -617,7 +622,7 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, std::v
             }
             pipe.release(it);
         }
-        if (!joined) ctx_thread.join();
+        if (!joined) actx.wait();
         leak_all = fast_exit;  // only after a clean run: error paths tear down normally
         if (timing) std::fprintf(stderr, "[inq timing] spans done at %.3fs after the start of the device path\n", secs(t_begin, clk::now()));
     }
@@ -638,6 +643,8 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     auto t_start = clk::now();
     double t_front = 0, t_dev = 0;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    AsyncCtx actx;
+    if (args) actx.start(args->device);
     inq_frontend_t *F = nullptr;
     int rc = inq_frontend_open_impl(args, &F, errbuf, errcap);
     if (rc != INQ_EXIT_OK) return rc;
@@ -649,7 +656,7 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     const bool device_front = use_device_front(args, F->P);
     if (device_front) {
         const auto t_choice = clk::now();
-        int drc = run_device_front(args, F, p1, p2, errbuf, errcap, &t_front, &t_dev);
+        int drc = run_device_front(args, F, actx, p1, p2, errbuf, errcap, &t_front, &t_dev);
         if (drc != INQ_EXIT_OK) return drc;
         const auto t_run = clk::now();
         drc = write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
@@ -663,22 +670,12 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     }
 
     auto t_prep = clk::now();
-    // HIP runtime start-up (~0.2 s) overlaps the first BAM sweeps
-    inq_ctx_t *ctx = nullptr;
-    int hrc = INQ_OK;
-    std::thread ctx_thread([&] { hrc = inq_ctx_create(args->device, &ctx); });
-    struct CtxGuard {
-        inq_ctx_t *&c;
-        std::thread &t;
-        ~CtxGuard() {
-            if (t.joinable()) t.join();
-            inq_ctx_destroy(c);
-        }
-    } cg{ctx, ctx_thread};
+    inq_ctx_t *&ctx = actx.ctx;
+    int &hrc = actx.hrc;
     bool ctx_ready = false;
     auto need_ctx = [&]() -> bool {
         if (!ctx_ready) {
-            ctx_thread.join();
+            actx.wait();
             ctx_ready = true;
         }
         if (hrc != INQ_OK) {
@@ -813,7 +810,7 @@ static int write_rows(const inq_call_args_t *args, inq_frontend *F, const std::v
     text.reserve(64 * (n + 1));
     for (uint32_t i : order) {
         const RepeatInterval &t = F->P.targets[i];
-        text += format_row(t.chrom, t.start, t.end, p1[i], p2[i]);
+        append_row(text, t.chrom, t.start, t.end, p1[i], p2[i]);
         text += '\n';
         if (text.size() > (1u << 20)) {
             if (!write_all(out_fd, text)) {

@@ -1,28 +1,69 @@
 #include "inq_text.h"
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 
 namespace inqhost {
 
-std::string format_f64(double v) {
-    if (std::isnan(v)) return "NaN";
+// decimal digits of a non-negative integer, appended
+static void append_u64(std::string &out, uint64_t v) {
+    char buf[24];
+    int n = 0;
+    do {
+        buf[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) out.push_back(buf[--n]);
+}
+
+// Rust's `{}` for f64 restricted to what the path produces: NaN, integers and halves ((a + b) as f64 / 2.0,
+// src/call.rs:518) of at most 2^53 in magnitude print without exponent; anything else falls back to printf
+void append_f64(std::string &out, double v) {
+    if (std::isnan(v)) {
+        out += "NaN";
+        return;
+    }
+    const double a = std::fabs(v);
+    if (a < 9007199254740992.0) {
+        const uint64_t twice = (uint64_t)(a * 2.0);
+        if ((double)twice == a * 2.0) {  // an integer or a half
+            if (std::signbit(v)) out.push_back('-');
+            append_u64(out, twice >> 1);
+            if (twice & 1u) out += ".5";
+            return;
+        }
+    }
     char buf[64];
     double ip;
-    double frac = std::modf(v, &ip);
-    if (frac == 0.0) {
-        if (v == 0.0 && std::signbit(v)) return "-0";
-        std::snprintf(buf, sizeof buf, "%.0f", v);
-        return buf;
-    }
-    // halves are the only fractions the path produces ((a + b) as f64 / 2.0, src/call.rs:518)
-    std::snprintf(buf, sizeof buf, "%s%.0f.5", v < 0 ? "-" : "", std::fabs(ip));
-    return buf;
+    const double frac = std::modf(v, &ip);
+    if (frac == 0.0) std::snprintf(buf, sizeof buf, "%.0f", v);
+    else std::snprintf(buf, sizeof buf, "%s%.0f.5", v < 0 ? "-" : "", std::fabs(ip));
+    out += buf;
+}
+
+std::string format_f64(double v) {
+    std::string s;
+    append_f64(s, v);
+    return s;
+}
+
+void append_row(std::string &out, const std::string &chrom, uint32_t start, uint32_t end, double p1, double p2) {
+    out += chrom;
+    out.push_back('\t');
+    append_u64(out, start);
+    out.push_back('\t');
+    append_u64(out, end);
+    out.push_back('\t');
+    append_f64(out, p1);
+    out.push_back('\t');
+    append_f64(out, p2);
 }
 
 std::string format_row(const std::string &chrom, uint32_t start, uint32_t end, double p1, double p2) {
-    return chrom + "\t" + std::to_string(start) + "\t" + std::to_string(end) + "\t" + format_f64(p1) + "\t" +
-           format_f64(p2);
+    std::string s;
+    append_row(s, chrom, start, end, p1, p2);
+    return s;
 }
 
 std::string format_header(const std::string &sample) {

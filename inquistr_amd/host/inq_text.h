@@ -9,6 +9,9 @@ namespace inqhost {
 std::string format_f64(double v);
 // Genotype Display, src/call.rs:57-65
 std::string format_row(const std::string &chrom, uint32_t start, uint32_t end, double p1, double p2);
+// the same, appended to a growing buffer (no temporaries: the output of 10^5 .. 10^6 rows is on the critical path)
+void append_row(std::string &out, const std::string &chrom, uint32_t start, uint32_t end, double p1, double p2);
+void append_f64(std::string &out, double v);
 // src/call.rs:101
 std::string format_header(const std::string &sample);
 // src/call.rs:91-100: file_stem, then every ".bam" and ".cram" removed
