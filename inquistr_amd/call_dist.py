@@ -5,8 +5,9 @@ collective; the only exchange is the gather of the per-shard rows to rank 0, whi
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         -m inquistr_amd.call_dist sample.bam -R loci.bed -t 8 > sample.inq
 
-Each rank sweeps the BAM only over its own contiguous slice of the (contig, start)-sorted targets
-with the C++ front end and feeds its own GPU through the C ABI; the reference's counterpart is the
+Each rank runs the C++ driver on its own contiguous slice of the (contig, start)-sorted targets: it reads
+only the part of the BAM that slice needs and inflates, scans and calls it on its own GPU (device front
+end), or sweeps it on the host for small inputs; the reference's counterpart is the
 rayon loop over loci (src/call.rs:115-136), which shares nothing but the output Vec.
 """
 from __future__ import annotations
@@ -16,24 +17,11 @@ import functools
 import os
 import sys
 import tempfile
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional
 
 import numpy as np
 
 from . import call as hostcall
-from .batch import Batch
-
-
-def _hip_compute(device: int) -> Callable[[Batch], Tuple[np.ndarray, np.ndarray]]:
-    from . import hipcall
-
-    ctx = hipcall.Context(device)
-
-    def run(b: Batch):
-        _, res = ctx.call_batch(b)
-        return res.phase1, res.phase2
-
-    return run
 
 
 def _cuts_by_file_bytes(bamp: str, sorted_targets, world: int) -> List[int]:
@@ -68,7 +56,8 @@ def _cuts_by_file_bytes(bamp: str, sorted_targets, world: int) -> List[int]:
 def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: Optional[str], minlen: int = 5,
                                  support: int = 3, threads: int = 1, unphased: bool = False,
                                  sample_name: Optional[str] = None, out=None, rank: int = 0, world: int = 1,
-                                 device: int = 0, compute: Optional[Callable] = None, group=None) -> None:
+                                 device: int = 0, compute: Optional[Callable] = None, group=None,
+                                 frontend: Optional[str] = None) -> None:
     """Same arguments as call.genotype_repeats plus (rank, world).  Rank 0 writes header + rows."""
     import torch
     import torch.distributed as dist
@@ -90,18 +79,38 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
     p1 = np.full(len(mine), np.nan)
     p2 = np.full(len(mine), np.nan)
     if mine:
-        compute = compute or _hip_compute(device)
         with tempfile.NamedTemporaryFile("w", suffix=".bed", delete=False) as f:
             for i in mine:
                 f.write(f"{targets[i][0]}\t{targets[i][1]}\t{targets[i][2]}\n")
             sub_bed = f.name
         try:
-            fe = hostcall.FrontEnd(bamp, region_file=sub_bed, minlen=minlen, support=support, threads=threads,
-                                   unphased=unphased, sample_name=sample_name)
-            for batch, idx in fe.batches():
-                a, b = compute(batch)
-                p1[idx], p2[idx] = a, b
-            fe.close()
+            if compute is None:
+                # the product path: the C++ driver on this rank's slice, which picks the device front end
+                # (inflate + record scan + join on this rank's GPU) or the host sweep by the amount of BAM.
+                # The rows come back as text; integers, halves and NaN survive that exactly.
+                with tempfile.NamedTemporaryFile("w+", suffix=".inq", delete=False) as rows:
+                    rows_path = rows.name
+                try:
+                    with open(rows_path, "w") as rf:
+                        hostcall.genotype_repeats(bamp, None, sub_bed, minlen, support, threads, unphased, sample_name, None,
+                                                  out=rf, device=device, frontend=frontend)
+                    got = {}
+                    with open(rows_path) as rf:
+                        next(rf)
+                        for line in rf:
+                            c, s0, e0, a, b = line.rstrip("\n").split("\t")
+                            got[(c, int(s0), int(e0))] = (float(a), float(b))
+                finally:
+                    os.unlink(rows_path)
+                for k, i in enumerate(mine):
+                    p1[k], p2[k] = got[tuple(targets[i])]
+            else:  # tests: per-batch compute supplied by the caller (the oracle, on CPU-only machines)
+                fe = hostcall.FrontEnd(bamp, region_file=sub_bed, minlen=minlen, support=support, threads=threads,
+                                       unphased=unphased, sample_name=sample_name)
+                for batch, idx in fe.batches():
+                    a, b = compute(batch)
+                    p1[idx], p2[idx] = a, b
+                fe.close()
         finally:
             os.unlink(sub_bed)
     if world > 1:
@@ -157,6 +166,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("-o", "--output", help="write the .inq here instead of stdout (gloo prints connection notes on stdout)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-device", action="store_true", help="all ranks on device 0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--frontend", default=None, choices=["host", "device"], help="default: by the amount of BAM each rank reads")
     a = ap.parse_args(argv)
     import torch
     import torch.distributed as dist
@@ -174,7 +184,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     out = open(a.output, "w") if (a.output and rank == 0) else None
     try:
         genotype_repeats_distributed(a.bam, a.region, a.region_file, a.minlen, a.support, a.threads, a.unphased,
-                                     a.sample_name, out=out, rank=rank, world=world, device=device)
+                                     a.sample_name, out=out, rank=rank, world=world, device=device, frontend=a.frontend)
     except hostcall.CallError as e:
         if rank == 0:
             print(e.message, file=sys.stderr)

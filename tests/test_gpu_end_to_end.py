@@ -74,3 +74,27 @@ def test_reference_bed_fixture_on_plumbing_bam(tmp_path):
             call.genotype_repeats(bam, None, bed, 5, 3, 4, unphased, "sample", None, out=f)
         want = _expected_text([("chr7", start, end, 0)], {0: recs}, unphased, 5, 3, "sample", 4)
         assert open(out).read() == want
+
+
+@pytest.mark.parametrize("frontend", ["device", "host"])
+def test_one_process_per_gpu_rehearsal(tmp_path, frontend):
+    """`python -m torch.distributed.run ... -m inquistr_amd.call_dist` with two ranks (gloo, both on this box's one
+    GPU): every rank runs the C++ driver on its slice, rank 0 gathers; the .inq equals the single-process CLI's."""
+    import subprocess
+    import sys
+
+    from inquistr_amd import call
+    from tools import make_synth_bam
+
+    prefix = str(tmp_path / "w")
+    make_synth_bam.write("phased10k", 4000, prefix)
+    single = tmp_path / "single.inq"
+    with open(single, "w") as f:
+        call.genotype_repeats(prefix + ".bam", None, prefix + ".bed", 5, 3, 4, False, "S", None, out=f, frontend=frontend)
+    out = tmp_path / "dist.inq"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", "-m", "inquistr_amd.call_dist", prefix + ".bam", "-R", prefix + ".bed", "-t", "4",
+           "--sample-name", "S", "--backend", "gloo", "--same-device", "--frontend", frontend, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.read_text() == single.read_text() and out.read_text().count("\n") == 4001
