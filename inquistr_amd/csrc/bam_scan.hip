@@ -85,7 +85,15 @@ __device__ __forceinline__ uint64_t aux_size(uint32_t t, const uint8_t *v, const
     case 'i': case 'I': case 'f': return 4;
     case 'd': return 8;
     case 'Z': case 'H': {
+        // NUL search four bytes per load: methylation strings (MM:Z) of long reads run to tens of KB and
+        // usually sit in front of the HP tag that phasing tools append
         const uint8_t *q = v;
+        while (q + 4 <= end) {
+            const uint32_t w = ld32(q);
+            const uint32_t z = (w - 0x01010101u) & ~w & 0x80808080u;  // high bit set in every zero byte (lowest one exact)
+            if (z) return (uint64_t)(q - v) + (uint64_t)(__ffs((int)z) >> 3);  // bit 8k+7 -> __ffs = 8k+8 -> k+1 bytes incl. the NUL
+            q += 4;
+        }
         while (q < end && *q) ++q;
         return q < end ? (uint64_t)(q - v) + 1 : 0;
     }

@@ -417,3 +417,27 @@ def test_inflate_fuzz_agrees_with_zlib_on_mutated_streams(ctx):
             assert status[i] != 0, (i, len(p), n)
     assert 400 < n_ok < 3600  # the corpus exercises both outcomes
     assert (rc == 0) == (n_ok == len(payloads))
+
+
+def test_device_aux_walk_skips_long_strings_of_every_length(tmp_path):
+    """HP behind a Z tag of every length 0..70 and of 20 000 bytes (methylation strings sit in front of the HP tag
+    phasing tools append): the word-at-a-time NUL search must land on the next tag for every alignment."""
+    from inquistr_amd import call
+    from tools import bamio
+
+    lens = list(range(0, 71)) + [20_000, 20_001, 20_002, 20_003]
+    bam = str(tmp_path / "aux.bam")
+    w = bamio.BamWriter(bam, [("chr1", 100000)])
+    for i, n in enumerate(lens):
+        hp = 1 + i % 2
+        w.add(f"r{i}", 0, 0, 4800, 60, [("M", 210), ("I", 12 if hp == 1 else 30), ("M", 300)],
+              [("ML", "B", ("C", [7] * (i % 5))), ("MM", "Z", "C+m," * (n // 4) + "x" * (n % 4)), ("HP", "C", hp), ("SA", "Z", "chr1,1,+,5M,0,0;")],
+              l_seq=i % 3)
+    w.close()
+    texts = {}
+    for fe in ("host", "device"):
+        out = tmp_path / f"{fe}.inq"
+        with open(out, "w") as f:
+            call.genotype_repeats(bam, "chr1:5000-5050", None, 5, 3, 1, False, "S", None, out=f, frontend=fe)
+        texts[fe] = out.read_text()
+    assert texts["device"] == texts["host"] == "chromosome\tbegin\tend\tS_H1\tS_H2\nchr1\t5000\t5050\t12\t30\n"
