@@ -69,7 +69,7 @@ def cpu_baseline(wl, sample_loci: int, budget_s: float = 10.0):
     }
 
 
-def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str = "", cpu_modes: str = "CBA"):
+def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str = "", cpu_modes: str = "CBA", seq: bool = False):
     """L2: BAM + BED -> .inq.  The product CLI (C++ sweep front end + HIP kernels) next to this bench's CPU
     baseline leg at that level: oracle/ref_shaped_call, the reference's control flow (BASELINE.md §3 modes
     A / B / C) around the oracle — a CPU restatement, not the Rust binary.  Outputs are compared byte for
@@ -82,10 +82,10 @@ def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str =
 
     wl = synth.WORKLOADS[workload]
     tmp = keep or tempfile.mkdtemp(prefix="inq_l2_")
-    prefix = os.path.join(tmp, f"{workload}_{loci}")
+    prefix = os.path.join(tmp, f"{workload}_{loci}" + ("_seq" if seq else ""))
     t0 = time.time()
     if not os.path.exists(prefix + ".bam"):
-        make_synth_bam.write(workload, loci, prefix)
+        make_synth_bam.write(workload, loci, prefix, seq=seq)
     gen_s = time.time() - t0
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
     cli = os.path.join(ROOT, "inquistr_amd", "lib", "inquistr")
@@ -129,6 +129,7 @@ def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str =
         same = sorted(out.splitlines()) == sorted(out_gpu.splitlines()) if mode == "C" else out == out_gpu
         res[f"cpu_{mode}"] = {"seconds": t, "loci_per_s": loci / t, "threads": thr, "inq_identical": bool(same)}
     return {"level": "L2 end-to-end BAM+BED -> .inq", "workload": workload, "loci": loci,
+            "records": "SEQ + QUAL + ML/MM tags, HP last (real long-read record shape)" if seq else "SEQ '*' (CIGAR-only records)",
             "bam_mb": os.path.getsize(prefix + ".bam") / 1e6, "bam_gen_s": gen_s, **res,
             **{f"speedup_vs_{m}": res[f"cpu_{m}"]["seconds"] / t_gpu for m in "ABC" if f"cpu_{m}" in res},
             "note": "CPU modes = oracle/ref_shaped_call: CPU restatement of the reference's control flow, not the Rust binary"}
@@ -153,9 +154,10 @@ def main():
     ap.add_argument("--l2-threads", type=int, default=0)
     ap.add_argument("--l2-keep", default="", help="directory to keep / reuse the generated BAM in")
     ap.add_argument("--l2-cpu-modes", default="CBA", help="which CPU baseline modes to time (A is slow on large inputs)")
+    ap.add_argument("--l2-seq", action="store_true", help="records carry SEQ / QUAL / MM / ML like a real long-read BAM (~30 KB each)")
     args = ap.parse_args()
     if args.l2:
-        print(json.dumps(l2_end_to_end(args.workload, args.l2_loci, args.l2_threads or host_threads(), 2, args.l2_keep, args.l2_cpu_modes)), flush=True)
+        print(json.dumps(l2_end_to_end(args.workload, args.l2_loci, args.l2_threads or host_threads(), 2, args.l2_keep, args.l2_cpu_modes, args.l2_seq)), flush=True)
         return
 
     import torch

@@ -64,7 +64,7 @@ void inq_frontend_close(inq_frontend_t *fe);
 /* ---- spans: host half of the DEVICE front end (inq_call_span in inquistr_hip.h), no GPU involved ----
  * Cuts the targets into spans (loci of one contig + the whole BGZF blocks holding every record that
  * overlaps them, found through the .bai), reads the compressed bytes and builds the block table and the
- * record-start anchors.  max_comp_bytes = 0 takes the default (1 GiB, env INQ_SPAN_MB). */
+ * record-start anchors.  max_comp_bytes = 0 takes the default (2 GiB, env INQ_SPAN_MB). */
 typedef struct inq_spans inq_spans_t;
 int inq_spans_open(const inq_call_args_t *args, uint64_t max_comp_bytes, inq_spans_t **out, char *errbuf, size_t errcap);
 uint64_t inq_spans_n_targets(const inq_spans_t *s);

@@ -361,6 +361,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
     if (bi >= a.n_blocks) return;
     const inq_bgzf_block_t blk = a.blocks[bi];
     uint32_t st = 0;
+    const uint64_t clk0 = (a.debug_flags & 4u) ? clock64() : 0ull;
     // host-checked, re-checked: the block's extents lie inside the buffers
     if (blk.comp_off > a.comp_bytes || (uint64_t)blk.comp_len > a.comp_bytes - blk.comp_off || blk.out_off > a.out_bytes ||
         (uint64_t)blk.isize > a.out_bytes - blk.out_off) {
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
     }
     if (a.block_status) a.block_status[bi] = st;
     if (st) atomicOr(a.err, st);
+    if ((a.debug_flags & 4u) && a.block_status) a.block_status[bi] = (uint32_t)((clock64() - clk0) >> 10);  // shader kilo-cycles of this lane
 }
 
 // ---------------------------------------------------------------- CRC32 of the inflated blocks

@@ -17,7 +17,7 @@ struct InflateArgs {
     uint64_t out_bytes;
     uint32_t *block_status;  // [n_blocks] or null
     unsigned int *err;       // OR of the INQ_INFLATE_* bits of all blocks
-    uint32_t debug_flags;    // timing experiments only: 1 = drop literal stores, 2 = drop match copies
+    uint32_t debug_flags;    // timing experiments only: 1 = drop literal stores, 2 = drop match copies, 4 = block_status receives shader kilo-cycles
     uint32_t verify_crc;     // also check every block against the CRC32 of its trailer (comp holds whole blocks)
 };
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s);

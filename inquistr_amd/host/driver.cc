@@ -393,7 +393,7 @@ private:
 static uint64_t span_bytes_from_env() {
     const char *e = std::getenv("INQ_SPAN_MB");
     const long v = e ? std::atol(e) : 0;
-    return v > 0 ? (uint64_t)v << 20 : (1024ull << 20);  // ~16k..40k BGZF blocks: enough lanes to fill the chip
+    return v > 0 ? (uint64_t)v << 20 : (2048ull << 20);  // 30k..80k BGZF blocks: one to two rounds of the chip's 49 152 inflate lanes
 }
 
 struct inq_spans {

@@ -58,7 +58,7 @@ uint64_t BaiAnchors::limit_after(int tid, int64_t x) {
 
 // ---------------------------------------------------------------- planner
 SpanPlanner::SpanPlanner(const BamFile &bam, const std::vector<RepeatInterval> &targets, uint64_t max_comp_bytes)
-    : bam_(bam), anch_(bam.index()), max_comp_(max_comp_bytes ? max_comp_bytes : (1024ull << 20)) {
+    : bam_(bam), anch_(bam.index()), max_comp_(max_comp_bytes ? max_comp_bytes : (2048ull << 20)) {
     for (uint32_t i = 0; i < targets.size(); ++i) {
         const int tid = bam_.tid(targets[i].chrom);
         if (tid < 0 || (size_t)tid >= bam_.index().refs.size()) continue;  // no index entry: nothing to fetch

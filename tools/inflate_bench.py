@@ -6,12 +6,17 @@ import zlib
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from inquistr_amd import hipcall, synth  # noqa: E402
 from tools import bamio, make_synth_bam  # noqa: E402
 
 
-def make_blocks(n_blocks: int, level: int):
+def make_blocks(n_blocks: int, level: int, kind: str = "cigar"):
+    if kind == "qual":  # what most of a real long-read BAM is: base qualities (Phred 0..50) and packed bases
+        rng = np.random.default_rng(3)
+        base = (rng.integers(0, 51, 64 * bamio.BLOCK, dtype=np.uint8)).tobytes()
+        comp = [bamio.bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base), bamio.BLOCK)]
+        return b"".join((comp * (n_blocks // len(comp) + 1))[:n_blocks])
     wl = synth.WORKLOADS["unphased100k"]
     need = n_blocks * bamio.BLOCK
     blob = bytearray()
@@ -30,20 +35,28 @@ def make_blocks(n_blocks: int, level: int):
 def main():
     n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    comp = make_blocks(n_blocks, level)
+    kind = sys.argv[3] if len(sys.argv) > 3 else "cigar"
+    comp = make_blocks(n_blocks, level, kind)
     blocks = hipcall.scan_bgzf(comp)
-    ctx = hipcall.Context(0)
+    import os
+
+    alt = os.environ.get("INQ_LIB")  # another build of libinquistr_hip.so (A/B)
+    ctx = hipcall.Context(0, lib=hipcall.load(alt)) if alt else hipcall.Context(0)
     out_bytes = int(blocks["isize"].sum())
     for rep in range(3):
         t = time.perf_counter()
         rc, out, st = ctx.bgzf_inflate(comp, blocks, check=False)
         wall = time.perf_counter() - t
         ms, _ = ctx.timing_read(2)
-        print(f"blocks {len(blocks)} level {level}: comp {len(comp) / 1e6:.1f} MB -> {out_bytes / 1e6:.1f} MB, kernel {ms:.2f} ms "
+        print(f"blocks {len(blocks)} level {level} {kind}: comp {len(comp) / 1e6:.1f} MB -> {out_bytes / 1e6:.1f} MB, kernel {ms:.2f} ms "
               f"= {out_bytes / ms / 1e6:.2f} GB/s out, {len(comp) / ms / 1e6:.2f} GB/s in (call {wall * 1e3:.0f} ms)", flush=True)
     import os
 
     if os.environ.get("INQ_INFLATE_DEBUG"):
+        if int(os.environ["INQ_INFLATE_DEBUG"]) & 4:
+            kc = st.astype(np.float64)
+            print(f"shader kilo-cycles per lane: median {np.median(kc):.0f}, max {kc.max():.0f}; with the kernel time above that is "
+                  f"{kc.max() * 1024 / (ms * 1e-3) / 1e9:.2f} GHz if the slowest lane spans the kernel")
         return
     # spot check against zlib
     b = blocks[len(blocks) // 2]

@@ -2,7 +2,7 @@
 """Writes a synthetic workload (inquistr_amd/synth.py) as a coordinate-sorted BAM + .bai + BED:
 the end-to-end (L2) form of BASELINE.json's configs.  Measurement plumbing, never the product.
 10 000 loci per contig (chr1, chr2, ...), reads carry HP:C, SEQ is '*' (l_seq = 0).
-usage: tools/make_synth_bam.py <workload> <n_loci> <out_prefix>"""
+usage: tools/make_synth_bam.py <workload> <n_loci> <out_prefix> [seq]   (seq: records with SEQ / QUAL / MM / ML like a real long-read BAM)"""
 from __future__ import annotations
 
 import os
@@ -84,19 +84,57 @@ def records_for(batch, tid: int, first_read_id: int):
     return out.tobytes(), so, pos[order], end[order]
 
 
-def write(workload: str, n_loci: int, prefix: str, level: int = 1):
+def records_with_seq(batch, tid: int, first_read_id: int, rng: np.random.Generator):
+    """Like records_for, but every record carries what a real long-read BAM does around the CIGAR: SEQ (random
+    bases) and QUAL (random Phred 0..50) of the read's query length, a methylation-style ML:B,C array and MM:Z
+    string, and HP:C as the LAST tag (where phasing tools append it).  Record by record: ~30 KB each."""
+    r = batch.reads
+    n = len(r)
+    ncig = r["n_cigar"].astype(np.int64)
+    off = r["cigar_off4"].astype(np.int64) * 4
+    w = batch.cigar.astype(np.int64)
+    consumed = np.where(np.isin(w & 15, (0, 2, 3, 7, 8)), w >> 4, 0)
+    query = np.where(np.isin(w & 15, (0, 1, 4, 7, 8)), w >> 4, 0)
+    span = np.add.reduceat(consumed, off) if n else np.zeros(0, dtype=np.int64)
+    qlen = np.add.reduceat(query, off) if n else np.zeros(0, dtype=np.int64)
+    pos = r["pos"].astype(np.int64)
+    end = pos + np.maximum(span, 1)
+    order = np.argsort(pos, kind="stable")
+    bins = reg2bin_vec(pos, end)
+    parts, sizes = [], []
+    for k in order:
+        l_seq = int(min(qlen[k], 60_000))
+        name = b"r%010d\0" % (first_read_id + int(k))
+        words = batch.cigar[off[k] : off[k] + ncig[k]].astype("<u4").tobytes()
+        seq = rng.integers(0, 256, (l_seq + 1) // 2, dtype=np.uint8).tobytes()
+        qual = rng.integers(0, 51, l_seq, dtype=np.uint8).tobytes()
+        n_mod = l_seq // 25
+        ml = b"MLBC" + struct.pack("<I", n_mod) + rng.integers(0, 256, n_mod, dtype=np.uint8).tobytes()
+        mm = b"MMZC+m," + b",".join(b"%d" % v for v in rng.integers(0, 40, n_mod)) + b";\0"
+        aux = b"NMi" + struct.pack("<i", 17) + ml + mm + b"HPC" + bytes([int(r["phase"][k])])
+        core = struct.pack("<iiBBHHHIiii", tid, int(pos[k]), len(name), int(r["mapq"][k]), int(bins[k]), int(ncig[k]), 0, l_seq, -1, -1, 0)
+        body = core + name + words + seq + qual + aux
+        parts.append(struct.pack("<I", len(body)) + body)
+        sizes.append(len(body) + 4)
+    return b"".join(parts), np.array(sizes, dtype=np.int64), pos[order], end[order]
+
+
+def write(workload: str, n_loci: int, prefix: str, level: int = 1, seq: bool = False):
     wl = synth.WORKLOADS[workload]
     n_contigs = (n_loci + LOCI_PER_CONTIG - 1) // LOCI_PER_CONTIG
     refs = [(f"chr{c + 1}", CONTIG_LEN) for c in range(n_contigs)]
     w = bamio.BamWriter(prefix + ".bam", refs, level=level)
     bed = open(prefix + ".bed", "w")
     step = 256 if wl.heavy_pct else 2000
+    if seq:
+        step = 64
+    rng = np.random.default_rng(12345)
     rid = 0
     for c in range(n_contigs):
         c_lo, c_hi = c * LOCI_PER_CONTIG, min(n_loci, (c + 1) * LOCI_PER_CONTIG)
         for g0 in range(c_lo, c_hi, step):
             b = synth.generate_numpy(wl, g0, min(c_hi, g0 + step))
-            blob, sizes, beg, end = records_for(b, c, rid)
+            blob, sizes, beg, end = records_with_seq(b, c, rid, rng) if seq else records_for(b, c, rid)
             u0 = len(w.buf)
             w.buf += blob
             offs = u0 + np.concatenate([[0], np.cumsum(sizes)])
@@ -110,5 +148,5 @@ def write(workload: str, n_loci: int, prefix: str, level: int = 1):
 
 
 if __name__ == "__main__":
-    n = write(sys.argv[1], int(sys.argv[2]), sys.argv[3])
+    n = write(sys.argv[1], int(sys.argv[2]), sys.argv[3], seq=len(sys.argv) > 4 and sys.argv[4] == "seq")
     print(f"wrote {sys.argv[3]}.bam/.bai/.bed: {n} reads, {os.path.getsize(sys.argv[3] + '.bam') / 1e6:.1f} MB")
