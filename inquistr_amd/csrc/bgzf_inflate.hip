@@ -30,6 +30,10 @@ namespace inq {
 namespace {
 
 constexpr int kLanes = 64;
+#ifndef INQ_LITERAL_RUN
+#define INQ_LITERAL_RUN 4
+#endif
+constexpr int kLiteralRun = INQ_LITERAL_RUN;
 constexpr int kLitSyms = 288, kDistSyms = 32;
 
 struct InflateLds {
@@ -427,20 +431,31 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
             if (type == 1u) build_fixed(L, lit, dist, lane);
             else if ((st = read_dynamic_header(b, L, lit, dist, lane)) != 0u) break;
             for (;;) {
-                b.refill();
-                int s = decode_sym(b, lit, L, 0, lane);
-                if (s < 256) {
-                    if (s < 0) {
-                        st = kBadCode;
-                        break;
-                    }
-                    if (o >= isize) {
-                        st = kOutputSize;
+                // Up to kLiteralRun literals in a tight inner loop before the wave looks at lengths and
+                // distances: with 64 lanes some lane has a match in almost every round, so the (long) match
+                // path below is executed by the wave every time it is reached - once per run of literals
+                // instead of once per symbol.  A lane that meets a non-literal waits for the others here.
+                int s = 0;
+                bool pending = false;  // s holds a non-literal symbol (or an error) to deal with
+#pragma unroll 1
+                for (int k = 0; k < kLiteralRun; ++k) {
+                    b.refill();
+                    s = decode_sym(b, lit, L, 0, lane);
+                    if (s >= 256 || s < 0 || o >= isize) {
+                        pending = true;
                         break;
                     }
                     if (!(a.debug_flags & 1u)) out[o] = (uint8_t)s;
                     ++o;
-                    continue;
+                }
+                if (!pending) continue;
+                if (s < 0) {
+                    st = kBadCode;
+                    break;
+                }
+                if (s < 256) {  // a literal with no room left
+                    st = kOutputSize;
+                    break;
                 }
                 if (s == 256) break;
                 s -= 257;
