@@ -178,17 +178,27 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint32_t dd, uint32_t l
 // at the cursor is 1 + #{L : v >= limit[L]}: fifteen independent compares against register constants, no
 // divergence between lanes.  The symbol is sym[base[len] + (v >> (15 - len))] with
 // base[len] = (first sorted slot of length len) - first[len], kept per lane in LDS.
+typedef short short2v __attribute__((ext_vector_type(2)));
+
 struct Code {
-    uint32_t lim[8];  // limit[L], 16 bits each, L = 1..15 (field 0 unused)
-    __device__ __forceinline__ uint32_t limit(int len) const { return (lim[len >> 1] >> ((len & 1) * 16)) & 0xffffu; }
+    // limit[L] - 1 as a signed 16-bit field, two lengths per register (L = 2k in the low half, 2k + 1 in the
+    // high half; L = 0 holds 0x7fff so it never counts): v >= limit[L]  <=>  (limit[L] - 1) - v < 0, which
+    // packed 16-bit subtract / arithmetic shift / add evaluate for two lengths per instruction.
+    uint32_t lim[8];
 };
 
 // Returns the symbol or -1 (bit pattern outside the code).  `tbl` = 0 literal/length, 1 distance.
 __device__ __forceinline__ int decode_sym(BitReader &b, const Code &c, const InflateLds &L, int tbl, int lane) {
-    const uint32_t v = __brev(b.peek()) >> 17;
-    uint32_t len = 1;
+    const uint32_t v = __brev(b.peek()) >> 17;  // next 15 bits, first bit of the stream on top
+    const short2v vv = {(short)v, (short)v};
+    short2v acc = {0, 0};
 #pragma unroll
-    for (int k = 1; k <= 15; ++k) len += v >= c.limit(k) ? 1u : 0u;
+    for (int k = 0; k < 8; ++k) {
+        short2v lm;
+        __builtin_memcpy(&lm, &c.lim[k], 4);
+        acc += (lm - vv) >> 15;  // -1 for every length whose limit v has reached
+    }
+    const uint32_t len = 1u - (uint32_t)(int)(acc.x + acc.y);
     if (len > 15u) return -1;
     const int idx = (int)L.base[tbl * 16 + (int)len][lane] + (int)(v >> (15u - len));
     b.drop(len);
@@ -238,6 +248,7 @@ __device__ __forceinline__ bool build_code(Code &c, InflateLds &L, int tbl, int 
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 8; ++i) c.lim[i] = 0u;
+    c.lim[0] = 0x7fffu;  // length 0 never counts
 #pragma unroll
     for (int len = 1; len <= 15; ++len) {
         const uint32_t n = L.cnt[tbl * 16 + len][lane];
@@ -245,7 +256,7 @@ __device__ __forceinline__ bool build_code(Code &c, InflateLds &L, int tbl, int 
         ok &= left >= 0;
         if (n) maxlen = len;
         const uint32_t lim = ok ? (first + n) << (15 - len) : 0u;  // <= 1 << 15 while not over-subscribed
-        c.lim[len >> 1] |= lim << ((len & 1) * 16);
+        c.lim[len >> 1] |= ((lim - 1u) & 0xffffu) << ((len & 1) * 16);  // limit 0 -> -1: every v has reached it
         L.base[tbl * 16 + len][lane] = (int16_t)((int)off - (int)first);
         L.cnt[tbl * 16 + len][lane] = (uint16_t)off;
         off += n;
