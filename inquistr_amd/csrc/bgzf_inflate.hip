@@ -40,6 +40,7 @@ struct InflateLds {
     uint16_t sym[kLitSyms + kDistSyms][kLanes];  // sorted symbols: [0,288) literal/length, [288,320) distance
     uint16_t cnt[32][kLanes];                    // construction scratch: [0,16) literal/length, [16,32) distance
     int16_t base[32][kLanes];                    // base[len] of the two codes (see Code)
+    uint4 stage[kLanes];                         // the next 16 compressed bytes of every lane, written by an LDS-DMA load
 };
 
 __device__ __forceinline__ uint32_t load_u32(const uint8_t *p) {
@@ -57,35 +58,45 @@ struct BitReader {
     const uint8_t *hard;  // last address a 16-byte fetch may start at (inside the padding of the whole buffer)
     uint64_t bb;
     uint32_t bc;
-    const uint8_t *fetch;  // address of nxt
-    uint64_t cur_lo, cur_hi, nxt_lo, nxt_hi;
+    const uint8_t *fetch;  // address of the 16 bytes in flight / waiting in LDS
+    uint64_t cur_lo, cur_hi;
     uint32_t cur_n;        // dwords left in cur
+    InflateLds *lds;       // stage[lane] receives the prefetch
+    int lane;
     // Unconditional load from a clamped address: what lies behind the payload (trailer, next block) is
-    // only ever consumed by a corrupt stream, which overrun() then reports.  No branch around the load:
-    // a conditional one makes the compiler stage it through temporaries and wait for it on the spot.
+    // only ever consumed by a corrupt stream, which overrun() then reports.
+    __device__ __forceinline__ const uint8_t *clamp(const uint8_t *q) const { return q < hard ? q : hard; }
     __device__ __forceinline__ void load16(const uint8_t *q, uint64_t &lo, uint64_t &hi) const {
-        q = q < hard ? q : hard;
+        q = clamp(q);
         lo = (uint64_t)load_u32(q) | ((uint64_t)load_u32(q + 4) << 32);
         hi = (uint64_t)load_u32(q + 8) | ((uint64_t)load_u32(q + 12) << 32);
+    }
+    // The prefetch is a global -> LDS load (no register destination): a register destination carried around
+    // the decode loop makes the compiler stage the load through temporaries and wait for it on the spot,
+    // which turns the prefetch into a blocking read (measured: 20 % of the kernel).  The LDS-DMA is tracked
+    // by the compiler as a pending LDS write, so the wait lands in front of the ds_read that consumes it,
+    // 16 input bytes later.  Destination = wave-uniform base + lane * 16.
+    __device__ __forceinline__ void prefetch16(const uint8_t *q) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)clamp(q),
+                                         (__attribute__((address_space(3))) void *)&lds->stage[0], 16, 0, 0);
     }
     __device__ __forceinline__ void start(const uint8_t *from) {  // (re)position at a byte
         p = from;
         bb = 0ull;
         bc = 0u;
         load16(from, cur_lo, cur_hi);
-        load16(from + 16, nxt_lo, nxt_hi);
         fetch = from + 16;
         cur_n = 4u;
-        // settle cur here, once, rather than in front of every use inside the decode loop
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        prefetch16(fetch);
     }
     __device__ __forceinline__ void refill() {  // afterwards bc > 32
         if (bc <= 32u) {
             if (cur_n == 0u) {
-                cur_lo = nxt_lo;
-                cur_hi = nxt_hi;
+                const uint4 v = lds->stage[lane];
+                cur_lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                cur_hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
                 fetch += 16;
-                load16(fetch, nxt_lo, nxt_hi);
+                prefetch16(fetch);
                 cur_n = 4u;
             }
             const uint32_t w = (uint32_t)cur_lo;
@@ -322,7 +333,7 @@ __device__ uint32_t read_dynamic_header(BitReader &b, InflateLds &L, Code &lit, 
         }
         if (left != 0) return kBadHeader;  // zlib: an incomplete code-length code is an error
     }
-    const BitReader mark = b;  // pass 2 starts here again
+    const BitReader mark = b;  // pass 2 starts here again (the staged 16 bytes are re-fetched on restore)
     for (int i = 0; i < 32; ++i) L.cnt[i][lane] = 0;
     const int total = hlit + hdist;
     bool has_eob = false;
@@ -362,6 +373,7 @@ __device__ uint32_t read_dynamic_header(BitReader &b, InflateLds &L, Code &lit, 
             if (!has_eob) return kBadHeader;  // zlib: "missing end-of-block"
             if (!build_code(lit, L, 0, lane) || !build_code(dist, L, 1, lane)) return kBadHeader;
             b = mark;
+            b.prefetch16(b.fetch);  // the LDS slot holds a later fetch of pass 1
         }
     }
     return 0u;
@@ -384,6 +396,8 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
     } else {
         const uint8_t *start = a.comp + blk.comp_off;
         BitReader b;
+        b.lds = &L;
+        b.lane = lane;
         b.end = start + blk.comp_len;
         b.hard = a.comp + a.comp_bytes + 32;  // the buffer carries 64 bytes of padding
         b.start(start);
