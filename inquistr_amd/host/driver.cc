@@ -544,7 +544,8 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
         const char *pin_env = std::getenv("INQ_SPAN_PINNED");
         // the CLI sets INQ_FAST_EXIT: it is about to leave the process, so the span buffers (unmapping a GB
         // of touched pages takes ~0.1 s) and the device context are left to the operating system
-        const bool fast_exit = std::getenv("INQ_FAST_EXIT") != nullptr;
+        const char *fast_env = std::getenv("INQ_FAST_EXIT");
+        const bool fast_exit = fast_env && fast_env[0] == '1';
         struct PipeHolder {
             SpanPipeline *p;
             const bool &leak;

@@ -11,6 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/tools/make_synth_bam.py unphased100k $LOCI /tmp/front_prof > $OUT/gen.log 2>&1 || { tail $OUT/gen.log; exit 1; }
 export INQ_FRONTEND=device
+export INQ_FAST_EXIT=0  # the CLI normally leaves through _Exit, which would skip the profiler's output
 CLI="$ROOT/inquistr_amd/lib/inquistr call /tmp/front_prof.bam -R /tmp/front_prof.bed -t 16 -u --sample-name S"
 $CLI > $OUT/device.inq 2> $OUT/device.err || { tail $OUT/device.err; exit 1; }
 INQ_FRONTEND=host $CLI > $OUT/host.inq 2>/dev/null
