@@ -17,7 +17,11 @@ with tempfile.TemporaryDirectory() as td:
     for i in range(a.cases):
         seed = 5000 + i
         unphased, threads = bool(i & 1), [1, 4, 7][i % 3]
-        bam, bed, loci, recs = _make_case(pathlib.Path(td), seed, n_loci=30 + (i % 5) * 25, ultra_long=(i % 4 == 0))
+        if a.frontend == "device":  # vary how the file is cut into spans and segments, and the BGZF block size
+            os.environ["INQ_SPAN_GAP_BYTES"] = str([0, 128 << 10, 2000][i % 3])
+            os.environ["INQ_SPAN_MB"] = "0" if i % 2 else "1"
+        bam, bed, loci, recs = _make_case(pathlib.Path(td), seed, n_loci=30 + (i % 5) * 25, ultra_long=(i % 4 == 0),
+                                          block=[0xFF00, 1500, 9000][i % 3] if a.frontend == "device" else 0xFF00)
         out = os.path.join(td, "o.inq")
         with open(out, "w") as f:
             call.genotype_repeats(bam, None, bed, 5, [3, 1, 2][i % 3], threads, unphased, None, None, out=f, frontend=a.frontend)
