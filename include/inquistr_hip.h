@@ -245,6 +245,17 @@ typedef struct inq_span_stats {
  * of locus_start/locus_end; pair_call / pair_bits are not produced (pass NULL).  stats may be NULL. */
 int inq_call_span(inq_ctx_t *ctx, const inq_span_t *span, inq_result_t *result, inq_span_stats_t *stats);
 
+/* Two-step form for files of many spans: inq_span_stage uploads the compressed bytes, the block table and the
+ * anchors of a span into one of three device-side slots on the library's copy stream and returns when they are
+ * there; inq_call_span_staged then runs the span from that slot without uploading.  inq_span_stage may be
+ * called from another host thread while an inq_call_span / inq_call_span_staged of an EARLIER span is in
+ * progress on the same ctx (different slot): the upload of span k+1 then overlaps the inflate of span k.
+ * A slot may be staged again once the call that used it has returned.  span->comp must be the same pointer
+ * and sizes in both calls. */
+int inq_span_stage(inq_ctx_t *ctx, const inq_span_t *span, int slot);
+int inq_call_span_staged(inq_ctx_t *ctx, const inq_span_t *span, int slot, inq_result_t *result,
+                         inq_span_stats_t *stats);
+
 /* Test / debug: copies the batch the last inq_call_span built on the device into caller-allocated HOST
  * arrays sized from that call's stats: cigar[n_cigar_words], reads[n_reads], pair_read[n_pairs],
  * locus_pair_off[n_loci + 1].  Any pointer may be NULL. */

@@ -94,6 +94,7 @@ int inq_ctx_create(int device_id, inq_ctx_t **out) {
     if (hipMalloc((void **)&c->d_status, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_NOMEM);
     if (hipMemset(c->d_status, 0, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_HIP);
     if (hipHostMalloc((void **)&c->h_status, sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) return fail(INQ_ERR_NOMEM);
+    if (span_state_init(c) != INQ_OK) return fail(INQ_ERR_HIP);
     // load the code objects while the caller is still busy opening its input
     preload_locus(c->stream);
     preload_inflate(c->stream);

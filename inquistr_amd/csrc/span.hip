@@ -28,6 +28,15 @@ struct SpanState {
     } *h = nullptr;
     hipEvent_t ev[6] = {};
     bool have_ev = false;
+    // inq_span_stage: compressed bytes + block table + anchors of up to three spans, uploaded on their own
+    // stream (possibly by another host thread) while an earlier span is being inflated
+    struct Stage {
+        DevBuf comp, blocks, anchors, anchor_stop;
+        const void *host_comp = nullptr;
+        uint64_t comp_bytes = 0, n_blocks = 0, n_anchors = 0;
+        bool valid = false;
+    } stage[3];
+    hipStream_t copy_stream = nullptr;
     // the batch the last inq_call_span built
     uint64_t n_reads = 0, n_cigar_words = 0, n_pairs = 0, n_loci = 0;
 };
@@ -44,6 +53,10 @@ void span_state_destroy(SpanState *S) {
                       &S->reads, &S->info, &S->key, &S->endkey, &S->pmax, &S->cig_off, &S->cigar, &S->anchor_stop, &S->ltid, &S->lstart, &S->lend, &S->locus_cnt,
                       &S->locus_off, &S->pair_read, &S->p1, &S->p2, &S->tmp})
         if (b->p) (void)hipFree(b->p);
+    for (auto &g : S->stage)
+        for (DevBuf *b : {&g.comp, &g.blocks, &g.anchors, &g.anchor_stop})
+            if (b->p) (void)hipFree(b->p);
+    if (S->copy_stream) (void)hipStreamDestroy(S->copy_stream);
     if (S->d_st) (void)hipFree(S->d_st);
     if (S->h) (void)hipHostFree(S->h);
     if (S->have_ev)
@@ -55,18 +68,22 @@ void span_state_destroy(SpanState *S) {
 
 using namespace inq;
 
+int inq::span_state_init(inq_ctx *c) {
+    SpanState *S = new (std::nothrow) SpanState();
+    if (!S) return INQ_ERR_NOMEM;
+    c->span = S;
+    HIP_TRY(c, hipMalloc((void **)&S->d_st, sizeof(FrontStatus)));
+    HIP_TRY(c, hipHostMalloc((void **)&S->h, sizeof(SpanState::Host), hipHostMallocDefault));
+    for (auto &e : S->ev) HIP_TRY(c, hipEventCreate(&e));
+    S->have_ev = true;
+    HIP_TRY(c, hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking));
+    return INQ_OK;
+}
+
 namespace {
 
 int span_state(inq_ctx *c, SpanState **out) {
-    if (!c->span) {
-        SpanState *S = new (std::nothrow) SpanState();
-        if (!S) return INQ_ERR_NOMEM;
-        c->span = S;
-        HIP_TRY(c, hipMalloc((void **)&S->d_st, sizeof(FrontStatus)));
-        HIP_TRY(c, hipHostMalloc((void **)&S->h, sizeof(SpanState::Host), hipHostMallocDefault));
-        for (auto &e : S->ev) HIP_TRY(c, hipEventCreate(&e));
-        S->have_ev = true;
-    }
+    if (!c->span) return INQ_ERR_HIP;  // created with the ctx (span_state_init): two host threads may come here at once
     *out = c->span;
     return INQ_OK;
 }
@@ -89,24 +106,33 @@ int check_blocks(const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_
 
 // uploads the compressed bytes and the block table, clears the front status, inflates into S->u
 int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks,
-                       uint64_t n_blocks, uint64_t out_bytes, bool want_block_status, hipStream_t s) {
+                       uint64_t n_blocks, uint64_t out_bytes, bool want_block_status, hipStream_t s,
+                       const SpanState::Stage *staged = nullptr) {
     int rc;
     constexpr size_t kPad = 64;
-    if ((rc = ensure(c, S->comp, comp_bytes + kPad)) != INQ_OK) return rc;
-    if ((rc = ensure(c, S->blocks, n_blocks * sizeof(inq_bgzf_block_t))) != INQ_OK) return rc;
+    const void *d_comp, *d_blocks;
+    if (staged) {  // already on the device (inq_span_stage)
+        d_comp = staged->comp.p;
+        d_blocks = staged->blocks.p;
+    } else {
+        if ((rc = ensure(c, S->comp, comp_bytes + kPad)) != INQ_OK) return rc;
+        if ((rc = ensure(c, S->blocks, n_blocks * sizeof(inq_bgzf_block_t))) != INQ_OK) return rc;
+        if (comp_bytes) HIP_TRY(c, hipMemcpyAsync(S->comp.p, comp, comp_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync((uint8_t *)S->comp.p + comp_bytes, 0, kPad, s));
+        if (n_blocks) HIP_TRY(c, hipMemcpyAsync(S->blocks.p, blocks, n_blocks * sizeof(inq_bgzf_block_t), hipMemcpyHostToDevice, s));
+        d_comp = S->comp.p;
+        d_blocks = S->blocks.p;
+    }
     if ((rc = ensure(c, S->u, out_bytes + kPad)) != INQ_OK) return rc;
     if (want_block_status && (rc = ensure(c, S->block_status, n_blocks * 4)) != INQ_OK) return rc;
-    if (comp_bytes) HIP_TRY(c, hipMemcpyAsync(S->comp.p, comp, comp_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemsetAsync((uint8_t *)S->comp.p + comp_bytes, 0, kPad, s));
-    if (n_blocks) HIP_TRY(c, hipMemcpyAsync(S->blocks.p, blocks, n_blocks * sizeof(inq_bgzf_block_t), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync((uint8_t *)S->u.p + out_bytes, 0, kPad, s));
     HIP_TRY(c, hipMemsetAsync(S->d_st, 0, sizeof(FrontStatus), s));
     HIP_TRY(c, hipMemsetAsync(&S->d_st->first_bad, 0xff, sizeof(unsigned long long), s));
     HIP_TRY(c, hipEventRecord(S->ev[1], s));
     InflateArgs ia;
-    ia.comp = (const uint8_t *)S->comp.p;
+    ia.comp = (const uint8_t *)d_comp;
     ia.comp_bytes = comp_bytes;
-    ia.blocks = (const inq_bgzf_block_t *)S->blocks.p;
+    ia.blocks = (const inq_bgzf_block_t *)d_blocks;
     ia.n_blocks = n_blocks;
     ia.out = (uint8_t *)S->u.p;
     ia.out_bytes = out_bytes;
@@ -140,8 +166,8 @@ int bgzf_inflate_impl(inq_ctx *c, const uint8_t *comp, uint64_t comp_bytes, cons
     return S->h->st.inflate ? INQ_ERR_INFLATE : INQ_OK;
 }
 
-int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_stats_t *stats) {
-    if (!c || !sp || !r) return INQ_ERR_ARG;
+int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_stats_t *stats, int slot) {
+    if (!c || !sp || !r || slot > 2) return INQ_ERR_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (sp->reserved || sp->unphased > 1) return INQ_ERR_ARG;
     if (sp->n_loci && (!sp->locus_tid || !sp->locus_start || !sp->locus_end || !r->phase1 || !r->phase2)) return INQ_ERR_ARG;
@@ -168,6 +194,12 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     if ((rc = span_state(c, &S)) != INQ_OK) return rc;
     hipStream_t s = c->stream;
     const uint64_t nl = sp->n_loci, na = sp->n_anchors;
+    const SpanState::Stage *staged = nullptr;
+    if (slot >= 0) {  // the span inq_span_stage put there, and nothing else
+        const SpanState::Stage &g = S->stage[slot];
+        if (!g.valid || g.host_comp != sp->comp || g.comp_bytes != sp->comp_bytes || g.n_blocks != nb || g.n_anchors != na) return INQ_ERR_ARG;
+        staged = &g;
+    }
 
     // ---- stage 1: upload, inflate, count the records
     const bool verbose = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
@@ -177,8 +209,10 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
         if (verbose) std::fprintf(stderr, "[inq span host] %-28s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(clk::now() - w0).count());
     };
     HIP_TRY(c, hipEventRecord(S->ev[0], s));
-    if ((rc = ensure(c, S->anchors, na * 8)) != INQ_OK) return rc;
-    if ((rc = ensure(c, S->anchor_stop, na * 8)) != INQ_OK) return rc;
+    if (!staged) {
+        if ((rc = ensure(c, S->anchors, na * 8)) != INQ_OK) return rc;
+        if ((rc = ensure(c, S->anchor_stop, na * 8)) != INQ_OK) return rc;
+    }
     if ((rc = ensure(c, S->ltid, nl * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->anchor_cnt, na * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->anchor_base, (na + 1) * 8)) != INQ_OK) return rc;
@@ -189,12 +223,12 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     if ((rc = ensure(c, S->p1, nl * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->p2, nl * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, S->tmp, scan_tmp_words(std::max<uint64_t>(std::max(na, nl), 1)) * 8)) != INQ_OK) return rc;
-    if (na) HIP_TRY(c, hipMemcpyAsync(S->anchors.p, sp->anchors, na * 8, hipMemcpyHostToDevice, s));
-    if (na) HIP_TRY(c, hipMemcpyAsync(S->anchor_stop.p, sp->anchor_stop, na * 8, hipMemcpyHostToDevice, s));
+    if (na && !staged) HIP_TRY(c, hipMemcpyAsync(S->anchors.p, sp->anchors, na * 8, hipMemcpyHostToDevice, s));
+    if (na && !staged) HIP_TRY(c, hipMemcpyAsync(S->anchor_stop.p, sp->anchor_stop, na * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(S->ltid.p, sp->locus_tid, nl * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(S->lstart.p, sp->locus_start, nl * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(S->lend.p, sp->locus_end, nl * 4, hipMemcpyHostToDevice, s));
-    if ((rc = upload_and_inflate(c, S, sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, false, s)) != INQ_OK) return rc;
+    if ((rc = upload_and_inflate(c, S, sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, false, s, staged)) != INQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(S->ev[2], s));
     wall("buffers + uploads enqueued");
 
@@ -202,11 +236,11 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     std::memset(&a, 0, sizeof a);
     a.u = (const uint8_t *)S->u.p;
     a.u_bytes = u_bytes;
-    a.anchors = (const uint64_t *)S->anchors.p;
+    a.anchors = (const uint64_t *)(staged ? staged->anchors.p : S->anchors.p);
     a.n_anchors = na;
     a.anchor_cnt = (uint32_t *)S->anchor_cnt.p;
     a.anchor_base = (uint64_t *)S->anchor_base.p;
-    a.anchor_stop = (const uint64_t *)S->anchor_stop.p;
+    a.anchor_stop = (const uint64_t *)(staged ? staged->anchor_stop.p : S->anchor_stop.p);
     a.locus_tid = (const int32_t *)S->ltid.p;
     a.unphased = sp->unphased;
     a.locus_start = (const uint32_t *)S->lstart.p;
@@ -353,6 +387,39 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     return status_to_code(S->h->ks.err);
 }
 
+// Runs on whatever host thread calls it, on the copy stream; touches only stage[slot] (and ctx->last_err on failure).
+int span_stage_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
+    if (!c || !sp || slot < 0 || slot > 2) return INQ_ERR_ARG;
+    const uint64_t nb = sp->n_blocks, na = sp->n_anchors;
+    const uint64_t u_bytes = nb ? sp->blocks[nb - 1].out_off + sp->blocks[nb - 1].isize : 0;
+    int rc = check_blocks(sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, true);
+    if (rc != INQ_OK) return rc;
+    if (na && (!sp->anchors || !sp->anchor_stop)) return INQ_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    SpanState *S;
+    if ((rc = span_state(c, &S)) != INQ_OK) return rc;
+    SpanState::Stage &g = S->stage[slot];
+    g.valid = false;
+    constexpr size_t kPad = 64;
+    hipStream_t s = S->copy_stream;
+    if ((rc = ensure(c, g.comp, sp->comp_bytes + kPad)) != INQ_OK) return rc;
+    if ((rc = ensure(c, g.blocks, nb * sizeof(inq_bgzf_block_t))) != INQ_OK) return rc;
+    if ((rc = ensure(c, g.anchors, na * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, g.anchor_stop, na * 8)) != INQ_OK) return rc;
+    if (sp->comp_bytes) HIP_TRY(c, hipMemcpyAsync(g.comp.p, sp->comp, sp->comp_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync((uint8_t *)g.comp.p + sp->comp_bytes, 0, kPad, s));
+    if (nb) HIP_TRY(c, hipMemcpyAsync(g.blocks.p, sp->blocks, nb * sizeof(inq_bgzf_block_t), hipMemcpyHostToDevice, s));
+    if (na) HIP_TRY(c, hipMemcpyAsync(g.anchors.p, sp->anchors, na * 8, hipMemcpyHostToDevice, s));
+    if (na) HIP_TRY(c, hipMemcpyAsync(g.anchor_stop.p, sp->anchor_stop, na * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    g.host_comp = sp->comp;
+    g.comp_bytes = sp->comp_bytes;
+    g.n_blocks = nb;
+    g.n_anchors = na;
+    g.valid = true;
+    return INQ_OK;
+}
+
 int fetch_batch_impl(inq_ctx *c, uint32_t *cigar, inq_read_t *reads, uint32_t *pair_read, uint64_t *locus_pair_off) {
     if (!c || !c->span) return INQ_ERR_ARG;
     SpanState *S = c->span;
@@ -380,9 +447,29 @@ int inq_bgzf_inflate(inq_ctx_t *c, const uint8_t *comp, uint64_t comp_bytes, con
     }
 }
 
+int inq_span_stage(inq_ctx_t *c, const inq_span_t *span, int slot) {
+    try {
+        return span_stage_impl(c, span, slot);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
+int inq_call_span_staged(inq_ctx_t *c, const inq_span_t *span, int slot, inq_result_t *result, inq_span_stats_t *stats) {
+    try {
+        return slot < 0 ? INQ_ERR_ARG : call_span_impl(c, span, result, stats, slot);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
 int inq_call_span(inq_ctx_t *c, const inq_span_t *span, inq_result_t *result, inq_span_stats_t *stats) {
     try {
-        return call_span_impl(c, span, result, stats);
+        return call_span_impl(c, span, result, stats, -1);
     } catch (const std::bad_alloc &) {
         return INQ_ERR_NOMEM;
     } catch (...) {

@@ -47,6 +47,8 @@ ABI_SYMBOLS = (
     "inq_abi_version",
     "inq_bgzf_inflate",
     "inq_call_span",
+    "inq_span_stage",
+    "inq_call_span_staged",
     "inq_span_fetch_batch",
 )
 
@@ -199,6 +201,10 @@ def load(path: Optional[str] = None):
     L.inq_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp]
     L.inq_call_span.restype = C.c_int
     L.inq_call_span.argtypes = [vp, C.POINTER(SpanC), C.POINTER(InqResultC), C.POINTER(SpanStatsC)]
+    L.inq_span_stage.restype = C.c_int
+    L.inq_span_stage.argtypes = [vp, C.POINTER(SpanC), C.c_int]
+    L.inq_call_span_staged.restype = C.c_int
+    L.inq_call_span_staged.argtypes = [vp, C.POINTER(SpanC), C.c_int, C.POINTER(InqResultC), C.POINTER(SpanStatsC)]
     L.inq_span_fetch_batch.restype = C.c_int
     L.inq_span_fetch_batch.argtypes = [vp, vp, vp, vp, vp]
     if path is None:
@@ -278,8 +284,9 @@ class Context:
 
     def call_span(self, comp, blocks: np.ndarray, anchors: np.ndarray, anchor_stop: np.ndarray, locus_tid: np.ndarray,
                   locus_start: np.ndarray, locus_end: np.ndarray, minlen: int = 5, support: int = 3, unphased: bool = False,
-                  check: bool = True):
-        """inq_call_span: returns (code, phase1, phase2, n_tie_loci, stats)."""
+                  check: bool = True, stage_slot: Optional[int] = None):
+        """inq_call_span: returns (code, phase1, phase2, n_tie_loci, stats).  stage_slot: go through
+        inq_span_stage + inq_call_span_staged with that slot instead."""
         comp = np.frombuffer(comp, dtype=np.uint8)
         blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK_DTYPE)
         anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
@@ -294,7 +301,12 @@ class Context:
         p2 = np.full(len(ls), np.nan)
         res = InqResultC(p1.ctypes.data, p2.ctypes.data, None, None, 0)
         stats = SpanStatsC()
-        rc = self._L.inq_call_span(self._h, C.byref(sp), C.byref(res), C.byref(stats))
+        if stage_slot is None:
+            rc = self._L.inq_call_span(self._h, C.byref(sp), C.byref(res), C.byref(stats))
+        else:
+            rc = self._L.inq_span_stage(self._h, C.byref(sp), stage_slot)
+            if rc == INQ_OK:
+                rc = self._L.inq_call_span_staged(self._h, C.byref(sp), stage_slot, C.byref(res), C.byref(stats))
         if rc != INQ_OK and check:
             self._raise(rc)
         return rc, p1, p2, int(res.n_tie_loci), stats

@@ -14,6 +14,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -262,10 +263,17 @@ public:
         uint8_t *buf = nullptr;
         size_t cap = 0;
         bool pinned = false;
+        int slot = 0;        // index of this item: also its device-side staging slot
+        bool staged = false; // the loader already uploaded it (inq_span_stage)
     };
+    // stage: called on the loader thread for every loaded span with the filled inq_span_t; returns true when the
+    // span now sits in device slot `slot` (the upload then overlaps the caller's work on earlier spans)
+    using StageFn = std::function<bool(const inq_span_t &, int slot)>;
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
-                 uint64_t max_comp_bytes, int n_threads, bool pinned)
-        : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned) {
+                 uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr)
+        : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
+          stage_(std::move(stage)) {
+        for (int i = 0; i < 3; ++i) slots_[i].slot = i;
         for (auto &it : slots_) free_.push_back(&it);
         th_ = std::thread([this] { run(); });
     }
@@ -277,6 +285,20 @@ public:
         cv_free_.notify_all();
         th_.join();
         for (auto &it : slots_) release_buf(it);
+    }
+    static void fill_span(const Item &it, inq_span_t *sp) {  // the data part; the caller adds minlen / support / unphased
+        std::memset(sp, 0, sizeof *sp);
+        sp->comp = it.buf;
+        sp->comp_bytes = it.data.comp_bytes;
+        sp->blocks = it.data.blocks.data();
+        sp->n_blocks = it.data.blocks.size();
+        sp->anchors = it.data.anchors.data();
+        sp->anchor_stop = it.data.anchor_stop.data();
+        sp->n_anchors = it.data.anchors.size();
+        sp->locus_tid = it.plan.locus_tid.data();
+        sp->locus_start = it.plan.locus_start.data();
+        sp->locus_end = it.plan.locus_end.data();
+        sp->n_loci = it.plan.locus_start.size();
     }
     // 1 = item, 0 = done, -1 = error
     int next(Item *&out, std::string *err) {
@@ -359,12 +381,18 @@ private:
             if (!fit(*it, (size_t)nbytes + 64)) return fail("cannot allocate the span buffer");
             const auto t2 = std::chrono::steady_clock::now();
             if (!loader.load(it->plan, planner_.anchors(), it->buf, n_threads_, it->data, &e)) return fail(e);
+            it->staged = false;
+            if (stage_) {
+                inq_span_t sp;
+                fill_span(*it, &sp);
+                it->staged = stage_(sp, it->slot);
+            }
             if (verbose_) {
                 const auto t3 = std::chrono::steady_clock::now();
                 auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-                std::fprintf(stderr, "[inq loader] plan %.2f ms, buffer %.2f ms (%s), read+tables %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
-                             ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), nbytes / 1e6, it->plan.segs.size(),
-                             it->data.anchors.size());
+                std::fprintf(stderr, "[inq loader] plan %.2f ms, buffer %.2f ms (%s), read+tables%s %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
+                             ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", it->staged ? "+upload" : "", ms(t2, t3), nbytes / 1e6,
+                             it->plan.segs.size(), it->data.anchors.size());
             }
             std::lock_guard<std::mutex> g(mu_);
             ready_.push_back(it);
@@ -379,6 +407,7 @@ private:
     SpanPlanner planner_;
     int n_threads_;
     bool pinned_;
+    StageFn stage_;
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[3];
     std::vector<Item *> free_;
@@ -501,7 +530,9 @@ struct AsyncCtx {
     void start(int device) {
         th = std::thread([this, device] { hrc = inq_ctx_create(device, &ctx); });
     }
-    bool wait() {
+    std::mutex mu;
+    bool wait() {  // any thread
+        std::lock_guard<std::mutex> g(mu);
         if (th.joinable()) th.join();
         return hrc == INQ_OK;
     }
@@ -552,7 +583,10 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
             ~PipeHolder() {
                 if (!leak) delete p;
             }
-        } holder{new SpanPipeline(args->bam, *F->P.bam, F->P.targets, span_bytes_from_env(), n_io, pin_env ? pin_env[0] == '1' : false),
+        } holder{new SpanPipeline(args->bam, *F->P.bam, F->P.targets, span_bytes_from_env(), n_io, pin_env ? pin_env[0] == '1' : false,
+                                  // the loader uploads every span it has read (waiting for the context the first time), so
+                                  // that the upload of span k+1 overlaps the inflate of span k
+                                  [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; }),
                  leak_all};
         SpanPipeline &pipe = *holder.p;
         bool joined = false;
@@ -577,18 +611,7 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
                 return INQ_EXIT_ERROR;
             }
             inq_span_t sp;
-            std::memset(&sp, 0, sizeof sp);
-            sp.comp = it->buf;
-            sp.comp_bytes = it->data.comp_bytes;
-            sp.blocks = it->data.blocks.data();
-            sp.n_blocks = it->data.blocks.size();
-            sp.anchors = it->data.anchors.data();
-            sp.anchor_stop = it->data.anchor_stop.data();
-            sp.n_anchors = it->data.anchors.size();
-            sp.locus_tid = it->plan.locus_tid.data();
-            sp.locus_start = it->plan.locus_start.data();
-            sp.locus_end = it->plan.locus_end.data();
-            sp.n_loci = it->plan.locus_start.size();
+            SpanPipeline::fill_span(*it, &sp);
             sp.minlen = F->minlen;
             sp.support = F->support;
             sp.unphased = F->unphased ? 1u : 0u;
@@ -599,7 +622,7 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
             res.phase1 = b1.data();
             res.phase2 = b2.data();
             inq_span_stats_t stt;
-            int rc2 = inq_call_span(ctx, &sp, &res, &stt);
+            int rc2 = it->staged ? inq_call_span_staged(ctx, &sp, it->slot, &res, &stt) : inq_call_span(ctx, &sp, &res, &stt);
             *t_dev += secs(tb, clk::now());
             if (timing == 2)
                 std::fprintf(stderr,
@@ -991,18 +1014,7 @@ static int inq_spans_next_impl(inq_spans_t *S, inq_span_t *sp, const uint32_t **
     }
     if (rc == 0) return 0;
     SpanPipeline::Item *it = S->cur;
-    std::memset(sp, 0, sizeof *sp);
-    sp->comp = it->buf;
-    sp->comp_bytes = it->data.comp_bytes;
-    sp->blocks = it->data.blocks.data();
-    sp->n_blocks = it->data.blocks.size();
-    sp->anchors = it->data.anchors.data();
-    sp->anchor_stop = it->data.anchor_stop.data();
-    sp->n_anchors = it->data.anchors.size();
-    sp->locus_tid = it->plan.locus_tid.data();
-    sp->locus_start = it->plan.locus_start.data();
-    sp->locus_end = it->plan.locus_end.data();
-    sp->n_loci = it->plan.locus_start.size();
+    SpanPipeline::fill_span(*it, sp);
     sp->minlen = S->minlen;
     sp->support = S->support;
     sp->unphased = S->unphased ? 1u : 0u;

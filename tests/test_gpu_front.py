@@ -173,9 +173,11 @@ def test_call_span_matches_oracle_and_host_emulation(ctx, tmp_path, monkeypatch,
     sp = call.Spans(bam, region_file=bed, minlen=minlen, support=support, threads=2, unphased=unphased, max_comp_bytes=span_bytes)
     got1 = np.full(len(loci), np.nan)
     got2 = np.full(len(loci), np.nan)
-    for span in sp.spans():
+    for k, span in enumerate(sp.spans()):
+        # odd seeds go through inq_span_stage + inq_call_span_staged, rotating through the three device slots
         rc, p1, p2, ties, stats = ctx.call_span(span["comp"], span["blocks"], span["anchors"], span["anchor_stop"], span["locus_tid"],
-                                                span["locus_start"], span["locus_end"], minlen, support, unphased)
+                                                span["locus_start"], span["locus_end"], minlen, support, unphased,
+                                                stage_slot=(k % 3) if seed % 2 else None)
         assert rc == 0
         idx = span["locus_index"]
         got1[idx], got2[idx] = p1, p2
@@ -348,6 +350,12 @@ def test_call_span_rejects_malformed_spans(ctx, tmp_path):
     comp[int(span["blocks"]["comp_off"][0]) + 30] ^= 0x10
     assert run(comp=comp) == hipcall.INQ_ERR_INFLATE
     assert run() == 0  # the ctx is usable after every error
+    # a staged slot only serves the span that was staged into it
+    a = dict(zip(("comp", "blocks", "anchors", "anchor_stop", "locus_tid", "locus_start", "locus_end"), args))
+    assert ctx.call_span(*[a[k] for k in ("comp", "blocks", "anchors", "anchor_stop", "locus_tid", "locus_start", "locus_end")],
+                         5, 3, False, check=False, stage_slot=1)[0] == 0
+    other = hipcall.SpanC()
+    assert ctx._L.inq_call_span_staged(ctx._h, other, 2, None, None) == hipcall.INQ_ERR_ARG
 
 
 def test_inflate_fuzz_agrees_with_zlib_on_mutated_streams(ctx):
