@@ -31,9 +31,10 @@
 
 using namespace inqhost;
 
-// auto front-end choice: the device front end inflates a BGZF block per GPU lane, which takes tens of
-// milliseconds however few blocks there are; below this many compressed bytes the CPU sweep is quicker
-static constexpr uint64_t kDeviceFrontMinBytes = 48ull << 20;
+// auto front-end choice: the device front end inflates a BGZF block per GPU lane, which takes ~40 ms however
+// few blocks there are; the CPU sweep inflates ~70 MB/s of BAM per thread.  Below this many compressed bytes
+// per host thread the sweep is quicker (48 MiB at -t 16, 3 MiB at -t 1).
+static constexpr uint64_t kDeviceFrontMinBytesPerThread = 3ull << 20;
 
 namespace {
 
@@ -556,7 +557,7 @@ static bool use_device_front(const inq_call_args_t *args, const Prepared &P) {
     uint64_t bytes = 0;
     while (planner.next(plan))
         for (const Segment &g : plan.segs) bytes += (g.vo_limit >> 16) - (g.vo_begin >> 16) + 32768;
-    return bytes >= kDeviceFrontMinBytes;
+    return bytes >= kDeviceFrontMinBytesPerThread * std::max<uint64_t>(1, std::min<uint64_t>(args->threads, 16));
 }
 
 // fills p1 / p2 through the device front end; returns an exit status
