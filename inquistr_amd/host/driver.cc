@@ -570,7 +570,10 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
     bool &leak_all = actx.leak;
     inq_ctx_t *&ctx = actx.ctx;
     int &hrc = actx.hrc;
-    const int n_io = (int)std::max<uint64_t>(1, std::min<uint64_t>(args->threads, 32));
+    // -t counts the reference's calling workers; here the host only copies file bytes, which a few pread
+    // streams do best whatever -t says (bounded by the machine)
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int n_io = (int)std::min<uint64_t>(std::max<uint64_t>(args->threads, 8), std::min<uint64_t>(hw, 32));
     std::vector<double> b1, b2;
     {
         const char *pin_env = std::getenv("INQ_SPAN_PINNED");
