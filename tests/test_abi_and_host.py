@@ -113,3 +113,17 @@ def test_committed_fixture_matches_oracle(orc):
         assert np.array_equal(res.pair_call, z[f"c{i}_pair_call"])
         assert np.array_equal(res.pair_bits, z[f"c{i}_pair_bits"])
         assert res.n_tie_loci == int(z[f"c{i}_params"][3])
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+@pytest.mark.parametrize("frontend", ["host", "device", None])
+def test_whole_command_fails_loudly_without_gpu(tmp_path, frontend):
+    """Neither front end has a CPU path for the calling: without a gfx950 device the command ends with status 1."""
+    from inquistr_amd import call
+    from tests.test_host_frontend import _make_case
+
+    bam, bed, loci, recs = _make_case(tmp_path, 3, n_loci=10)
+    with pytest.raises(call.CallError) as e, open(tmp_path / "o.inq", "w") as f:
+        call.genotype_repeats(bam, None, bed, 5, 3, 2, False, None, None, out=f, frontend=frontend)
+    assert e.value.status == 1 and "no CPU fallback" in e.value.message
+    assert (tmp_path / "o.inq").read_text() == ""
