@@ -34,14 +34,21 @@ constexpr int kLanes = 64;
 #define INQ_LITERAL_RUN 4
 #endif
 constexpr int kLiteralRun = INQ_LITERAL_RUN;
-constexpr int kLitSyms = 288, kDistSyms = 32;
+constexpr int kLitSyms = 286, kDistSyms = 30;  // HLIT <= 286, HDIST <= 30 (larger headers are rejected like zlib does)
 
+// 32 KB per wave, so that five waves share a CU's 160 KB.  All tables are lane-interleaved ([entry][lane]).
+//   sym : the symbols of both codes sorted by (length, value), ONE BYTE each: value & 0xff.  Within a length
+//         the literals (< 256) come before the length codes (>= 256), so one threshold per length (thr, the
+//         sorted index of the first length code of that length) recovers the ninth bit.
+//   cnt : construction scratch (per-length counts, then insertion slots), rows = length - 1 (+15: distances)
+//   base: low half = base[len] of Code (signed), high half = thr[len]; one read serves both
 struct InflateLds {
-    uint16_t sym[kLitSyms + kDistSyms][kLanes];  // sorted symbols: [0,288) literal/length, [288,320) distance
-    uint16_t cnt[32][kLanes];                    // construction scratch: [0,16) literal/length, [16,32) distance
-    int16_t base[32][kLanes];                    // base[len] of the two codes (see Code)
-    uint4 stage[kLanes];                         // the next 16 compressed bytes of every lane, written by an LDS-DMA load
+    uint8_t sym[kLitSyms + kDistSyms][kLanes];
+    uint16_t cnt[30][kLanes];
+    uint32_t base[30][kLanes];
+    uint4 stage[kLanes];  // the next 16 compressed bytes of every lane, written by an LDS-DMA load
 };
+static_assert(sizeof(InflateLds) <= 32768, "five waves per CU need 32 KB per wave");
 
 __device__ __forceinline__ uint32_t load_u32(const uint8_t *p) {
     uint32_t w;
@@ -211,9 +218,11 @@ __device__ __forceinline__ int decode_sym(BitReader &b, const Code &c, const Inf
     }
     const uint32_t len = 1u - (uint32_t)(int)(acc.x + acc.y);
     if (len > 15u) return -1;
-    const int idx = (int)L.base[tbl * 16 + (int)len][lane] + (int)(v >> (15u - len));
+    const uint32_t e = L.base[tbl * 15 + (int)len - 1][lane];
+    const int idx = (int)(short)(e & 0xffffu) + (int)(v >> (15u - len));
     b.drop(len);
-    return (int)L.sym[(tbl ? kLitSyms : 0) + idx][lane];
+    const int s8 = (int)L.sym[(tbl ? kLitSyms : 0) + idx][lane];
+    return s8 + ((uint32_t)idx >= (e >> 16) ? 256 : 0);  // thr = 0xffff for distance codes
 }
 
 // the code-length code: 19 symbols of <= 7 bits, everything in registers
@@ -262,35 +271,50 @@ __device__ __forceinline__ bool build_code(Code &c, InflateLds &L, int tbl, int 
     c.lim[0] = 0x7fffu;  // length 0 never counts
 #pragma unroll
     for (int len = 1; len <= 15; ++len) {
-        const uint32_t n = L.cnt[tbl * 16 + len][lane];
+        const uint32_t n = L.cnt[tbl * 15 + len - 1][lane];
         left = (left << 1) - (int)n;
         ok &= left >= 0;
         if (n) maxlen = len;
         const uint32_t lim = ok ? (first + n) << (15 - len) : 0u;  // <= 1 << 15 while not over-subscribed
         c.lim[len >> 1] |= ((lim - 1u) & 0xffffu) << ((len & 1) * 16);  // limit 0 -> -1: every v has reached it
-        L.base[tbl * 16 + len][lane] = (int16_t)((int)off - (int)first);
-        L.cnt[tbl * 16 + len][lane] = (uint16_t)off;
+        // thr starts at "no length code of this length"; place_symbol() lowers it when symbol 256 comes by
+        L.base[tbl * 15 + len - 1][lane] = (((uint32_t)((int)off - (int)first)) & 0xffffu) | 0xffff0000u;
+        L.cnt[tbl * 15 + len - 1][lane] = (uint16_t)off;
         off += n;
         first = (first + n) << 1;
     }
     return ok && (left == 0 || maxlen <= 1);
 }
 
+// Symbols arrive in ascending order (first the literal/length code, then the distance code).  Right before
+// symbol 256 is placed, every length's insertion slot is the sorted index of its first length code.
+__device__ __forceinline__ void place_symbol(InflateLds &L, int tbl, int sym, int len, int lane) {
+    if (tbl == 0 && sym == 256) {
+        for (int l = 0; l < 15; ++l) L.base[l][lane] = (L.base[l][lane] & 0xffffu) | ((uint32_t)L.cnt[l][lane] << 16);
+    }
+    const uint32_t at = L.cnt[tbl * 15 + len - 1][lane];
+    L.cnt[tbl * 15 + len - 1][lane] = (uint16_t)(at + 1);
+    L.sym[(tbl ? kLitSyms : 0) + at][lane] = (uint8_t)sym;
+}
+
 __device__ void build_fixed(InflateLds &L, Code &lit, Code &dist, int lane) {
-    // RFC 1951 3.2.6: literal/length lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287)
-    int k = 0;
-    for (int s = 256; s < 280; ++s) L.sym[k++][lane] = (uint16_t)s;
-    for (int s = 0; s < 144; ++s) L.sym[k++][lane] = (uint16_t)s;
-    for (int s = 280; s < 288; ++s) L.sym[k++][lane] = (uint16_t)s;
-    for (int s = 144; s < 256; ++s) L.sym[k++][lane] = (uint16_t)s;
-    for (int s = 0; s < 30; ++s) L.sym[kLitSyms + s][lane] = (uint16_t)s;  // codes 30, 31 never decode
-    for (int i = 0; i < 32; ++i) L.cnt[i][lane] = 0;
-    L.cnt[7][lane] = 24;
-    L.cnt[8][lane] = 152;
-    L.cnt[9][lane] = 112;
-    L.cnt[16 + 5][lane] = 30;
+    // RFC 1951 3.2.6: literal/length lengths 8 (0..143), 9 (144..255), 7 (256..279), 8 (280..287).  The codes
+    // of 286 and 287 take part in the code construction (152 codes of length 8) but never appear in valid data
+    // and have no room in the 286-entry table: the length-9 region is moved two slots down over their slots.
+    // A stream that uses them reads the first two length-9 literals there, above thr[8], i.e. as 400 and 401:
+    // not a length code, reported like any other invalid symbol.  Distance codes 30, 31 are left out (5 bits,
+    // 30 codes): they decode as "not a code".
+    for (int i = 0; i < 30; ++i) L.cnt[i][lane] = 0;
+    L.cnt[7 - 1][lane] = 24;
+    L.cnt[8 - 1][lane] = 152;
+    L.cnt[9 - 1][lane] = 112;
+    L.cnt[15 + 5 - 1][lane] = 30;
     (void)build_code(lit, L, 0, lane);
     (void)build_code(dist, L, 1, lane);
+    L.base[9 - 1][lane] = (L.base[9 - 1][lane] & 0xffff0000u) | ((L.base[9 - 1][lane] - 2u) & 0xffffu);
+    L.cnt[9 - 1][lane] = (uint16_t)(L.cnt[9 - 1][lane] - 2);
+    for (int sidx = 0; sidx < 286; ++sidx) place_symbol(L, 0, sidx, sidx < 144 ? 8 : sidx < 256 ? 9 : sidx < 280 ? 7 : 8, lane);
+    for (int sidx = 0; sidx < 30; ++sidx) place_symbol(L, 1, sidx, 5, lane);
 }
 
 // status bits per block
@@ -334,7 +358,7 @@ __device__ uint32_t read_dynamic_header(BitReader &b, InflateLds &L, Code &lit, 
         if (left != 0) return kBadHeader;  // zlib: an incomplete code-length code is an error
     }
     const BitReader mark = b;  // pass 2 starts here again (the staged 16 bytes are re-fetched on restore)
-    for (int i = 0; i < 32; ++i) L.cnt[i][lane] = 0;
+    for (int i = 0; i < 30; ++i) L.cnt[i][lane] = 0;
     const int total = hlit + hdist;
     bool has_eob = false;
     for (int pass = 0; pass < 2; ++pass) {
@@ -358,15 +382,12 @@ __device__ uint32_t read_dynamic_header(BitReader &b, InflateLds &L, Code &lit, 
             }
             for (int r = 0; r < rep; ++r, ++idx) {
                 const bool is_dist = idx >= hlit;
-                const int slot = (is_dist ? 16 : 0) + len;
                 if (pass == 0) {
+                    const int slot = (is_dist ? 15 : 0) + len - 1;
                     L.cnt[slot][lane] = (uint16_t)(L.cnt[slot][lane] + 1);
                     has_eob |= idx == 256;
-                } else {
-                    const uint32_t at = L.cnt[slot][lane];
-                    L.cnt[slot][lane] = (uint16_t)(at + 1);
-                    L.sym[(is_dist ? kLitSyms : 0) + at][lane] = (uint16_t)(is_dist ? idx - hlit : idx);
-                }
+                } else
+                    place_symbol(L, is_dist ? 1 : 0, is_dist ? idx - hlit : idx, len, lane);
             }
         }
         if (pass == 0) {

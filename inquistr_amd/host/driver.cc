@@ -423,7 +423,7 @@ private:
 static uint64_t span_bytes_from_env() {
     const char *e = std::getenv("INQ_SPAN_MB");
     const long v = e ? std::atol(e) : 0;
-    return v > 0 ? (uint64_t)v << 20 : (2048ull << 20);  // 30k..80k BGZF blocks: one to two rounds of the chip's 49 152 inflate lanes
+    return v > 0 ? (uint64_t)v << 20 : (2048ull << 20);  // 30k..80k BGZF blocks against the chip's 81 920 inflate lanes (5 waves x 64 lanes x 256 CUs)
 }
 
 struct inq_spans {
