@@ -261,6 +261,23 @@ int inq_call_span_staged(inq_ctx_t *ctx, const inq_span_t *span, int slot, inq_r
  * locus_pair_off[n_loci + 1].  Any pointer may be NULL. */
 int inq_span_fetch_batch(inq_ctx_t *ctx, uint32_t *cigar, inq_read_t *reads, uint32_t *pair_read, uint64_t *locus_pair_off);
 
+/* ==== `inquiSTR outlier` (src/outlier.rs): outlying samples per locus of a combined .inq ====
+ * values: HOST, row-major [n_rows][stride] f32, row i holding row_len[i] <= stride parsed numbers (NaN allowed:
+ * get_repeat_lengths maps it to 0, src/outlier.rs:80-83).  method: z-score (std_deviation_and_mean + z_score_outliers,
+ * :18-31, 97-110; f32 with the reference's sequential summation order) or DBSCAN (dbscan_outliers + mode, :112-145;
+ * eps = max(2 * mode, 10), min points = mincluster, at most 8192 values per row).  flags[i][k] = 1 where
+ * samples[k] is reported for row i; keep[i] tells what became of the row. */
+#define INQ_OUTLIER_ZSCORE 0
+#define INQ_OUTLIER_DBSCAN 1
+#define INQ_OUTLIER_ROW_SKIP 0     /* max < minsize: get_repeat_lengths returns None, the row is not looked at      */
+#define INQ_OUTLIER_ROW_KEEP 1
+#define INQ_OUTLIER_ROW_EMPTY 2    /* no values: the reference panics (unwrap on None, src/outlier.rs:90)            */
+#define INQ_OUTLIER_ROW_NO_MODE 3  /* DBSCAN, no value > 0: the reference panics ("No mode found for repeat", :144) */
+#define INQ_OUTLIER_ROW_TOO_WIDE 4 /* DBSCAN row with more than 8192 values: not supported                           */
+int inq_outlier_rows(inq_ctx_t *ctx, const float *values, const uint32_t *row_len, uint64_t n_rows, uint32_t stride,
+                     int method, uint32_t minsize, float zscore_cutoff, uint32_t mincluster, uint8_t *flags,
+                     uint8_t *keep);
+
 const char *inq_strerror(int code);
 const char *inq_backend_name(const inq_ctx_t *ctx); /* "hip:gfx950:<device name>" */
 const char *inq_last_error(const inq_ctx_t *ctx);   /* detail of the last INQ_ERR_HIP */

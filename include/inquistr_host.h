@@ -81,6 +81,22 @@ void inq_spans_close(inq_spans_t *s);
  * file, a later file with fewer lines than the first). */
 int inq_combine(const char *const *files, size_t n_files, int out_fd, char *errbuf, size_t errcap);
 
+/* `inquiSTR outlier` (src/outlier.rs:33-73; arguments src/main.rs:75-99): loci of a combined .inq (plain or gzip)
+ * with outlying samples, one line `chrom begin end s1,s2,...` each, after the header `chrom begin end outliers`.
+ * The arithmetic (z-score / DBSCAN per locus) runs on the GPU (inq_outlier_rows).  Returns 0, 1 (no GPU) or 101
+ * where the reference panics (missing file, -s with -S, a number that does not parse, ...). */
+typedef struct inq_outlier_args {
+    const char *combined;    /* positional                                   */
+    uint32_t minsize;        /* --minsize, default 10                        */
+    float zscore;            /* -z / --zscore, default 3.0                   */
+    int32_t method;          /* --method: INQ_OUTLIER_ZSCORE (default) / INQ_OUTLIER_DBSCAN */
+    const char *sample;      /* -s / --sample, NULL if absent                */
+    const char *subset_file; /* -S / --subset, NULL if absent                */
+    int32_t device;          /* HIP device ordinal (not a reference argument) */
+    int32_t reserved;
+} inq_outlier_args_t;
+int inq_outlier(const inq_outlier_args_t *args, int out_fd, char *errbuf, size_t errcap);
+
 /* ---- text side (src/call.rs:27-65, 91-101) ---- */
 size_t inq_host_format_f64(double v, char *buf, size_t cap);
 size_t inq_host_format_row(const char *chrom, uint32_t start, uint32_t end, double p1, double p2, char *buf, size_t cap);

@@ -43,6 +43,7 @@ HOST_ABI_SYMBOLS = (
     "inq_spans_n_targets",
     "inq_spans_next",
     "inq_spans_close",
+    "inq_outlier",
 )
 
 
@@ -57,6 +58,19 @@ class CallArgsC(C.Structure):
         ("unphased", C.c_int32),
         ("sample_name", C.c_char_p),
         ("reference", C.c_char_p),
+        ("device", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class OutlierArgsC(C.Structure):
+    _fields_ = [
+        ("combined", C.c_char_p),
+        ("minsize", C.c_uint32),
+        ("zscore", C.c_float),
+        ("method", C.c_int32),
+        ("sample", C.c_char_p),
+        ("subset_file", C.c_char_p),
         ("device", C.c_int32),
         ("reserved", C.c_int32),
     ]
@@ -127,6 +141,8 @@ def load():
         L.inq_spans_next.argtypes = [vp, C.POINTER(SpanC), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         L.inq_spans_close.restype = None
         L.inq_spans_close.argtypes = [vp]
+        L.inq_outlier.restype = C.c_int
+        L.inq_outlier.argtypes = [C.POINTER(OutlierArgsC), C.c_int, C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -174,6 +190,26 @@ def combine(calls, out=None) -> None:
     arr = (C.c_char_p * len(calls))(*[os.fspath(c).encode() for c in calls])
     err = C.create_string_buffer(2048)
     rc = L.inq_combine(arr, len(calls), out.fileno(), err, len(err))
+    if rc != 0:
+        raise CallError(rc, err.value.decode(errors="replace"))
+
+
+def outlier(combined, minsize: int = 10, zscore: float = 3.0, method: str = "zscore", sample: Optional[str] = None,
+            subset: Optional[str] = None, out=None, device: int = 0) -> None:
+    """src/outlier.rs:33 `outlier(combined, minsize, zscore_cutoff, method, subset)` with the CLI's -s / -S (src/main.rs:
+    213-227): loci of a combined .inq with outlying samples.  Raises CallError (101 where the reference panics)."""
+    L = load()
+    a = OutlierArgsC()
+    a.combined = os.fspath(combined).encode()
+    a.minsize, a.zscore = int(minsize), float(zscore)
+    a.method = {"zscore": 0, "dbscan": 1}[method]
+    a.sample = sample.encode() if sample is not None else None
+    a.subset_file = os.fspath(subset).encode() if subset is not None else None
+    a.device = device
+    err = C.create_string_buffer(2048)
+    out = sys.stdout if out is None else out
+    out.flush()
+    rc = L.inq_outlier(C.byref(a), out.fileno(), err, len(err))
     if rc != 0:
         raise CallError(rc, err.value.decode(errors="replace"))
 

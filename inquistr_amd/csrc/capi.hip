@@ -13,6 +13,7 @@
 #include "../../include/inquistr_hip.h"
 #include "cigar_walk.h"
 #include "ctx.h"
+#include "front_kernels.h"
 #include "kernels.h"
 
 using namespace inq;
@@ -110,7 +111,7 @@ void inq_ctx_destroy(inq_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->span) span_state_destroy(c->span);
     for (DevBuf *b : {&c->worklist, &c->sval, &c->smeta, &c->cigar, &c->reads, &c->pair_read, &c->off, &c->lstart,
-                      &c->lend, &c->p1, &c->p2, &c->pcall, &c->pbits})
+                      &c->lend, &c->p1, &c->p2, &c->pcall, &c->pbits, &c->ovalues, &c->olen, &c->oflags, &c->okeep, &c->otrans})
         if (b->p) (void)hipFree(b->p);
     for (auto &e : c->ev_pool) {
         (void)hipEventDestroy(e.e0);
@@ -299,6 +300,71 @@ static int call_batch_impl(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) 
 int inq_call_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) {
     try {
         return call_batch_impl(c, b, r);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
+static int outlier_rows_impl(inq_ctx_t *c, const float *values, const uint32_t *row_len, uint64_t n_rows, uint32_t stride,
+                             int method, uint32_t minsize, float cutoff, uint32_t mincluster, uint8_t *flags, uint8_t *keep) {
+    if (!c || (method != INQ_OUTLIER_ZSCORE && method != INQ_OUTLIER_DBSCAN)) return INQ_ERR_ARG;
+    if (n_rows && (!row_len || !keep || (stride && (!values || !flags)))) return INQ_ERR_ARG;
+    if (n_rows >= 0x7fffffffull) return INQ_ERR_ARG;
+    for (uint64_t i = 0; i < n_rows; ++i)
+        if (row_len[i] > stride) return INQ_ERR_ARG;
+    if (!n_rows) return INQ_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t cells = (size_t)n_rows * stride;
+    int rc;
+    if ((rc = ensure(c, c->ovalues, cells * 4)) != INQ_OK) return rc;
+    if ((rc = ensure(c, c->olen, n_rows * 4)) != INQ_OK) return rc;
+    if ((rc = ensure(c, c->oflags, cells)) != INQ_OK) return rc;
+    if ((rc = ensure(c, c->okeep, n_rows)) != INQ_OK) return rc;
+    if (method == INQ_OUTLIER_ZSCORE && (rc = ensure(c, c->otrans, outlier_rows_padded(n_rows) * stride * 4)) != INQ_OK) return rc;
+    if (cells) HIP_TRY(c, hipMemcpyAsync(c->ovalues.p, values, cells * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->olen.p, row_len, n_rows * 4, hipMemcpyHostToDevice, s));
+    if (cells) HIP_TRY(c, hipMemsetAsync(c->oflags.p, 0, cells, s));
+    OutlierArgs a;
+    a.values = (const float *)c->ovalues.p;
+    a.row_len = (const uint32_t *)c->olen.p;
+    a.n_rows = n_rows;
+    a.stride = stride;
+    a.minsize = minsize;
+    a.zscore_cutoff = cutoff;
+    a.mincluster = mincluster;
+    a.flags = (uint8_t *)c->oflags.p;
+    a.keep = (uint8_t *)c->okeep.p;
+    EvTriple *ev = nullptr;
+    if (c->timing) {
+        if (c->ev_used == c->ev_pool.size()) {
+            EvTriple t;
+            HIP_TRY(c, hipEventCreate(&t.e0));
+            HIP_TRY(c, hipEventCreate(&t.e1));
+            HIP_TRY(c, hipEventCreate(&t.e2));
+            c->ev_pool.push_back(t);
+        }
+        ev = &c->ev_pool[c->ev_used++];
+        HIP_TRY(c, hipEventRecord(ev->e0, s));
+    }
+    launch_outlier(a, method, (float *)c->otrans.p, s);
+    HIP_TRY(c, hipGetLastError());
+    if (ev) {
+        HIP_TRY(c, hipEventRecord(ev->e1, s));
+        HIP_TRY(c, hipEventRecord(ev->e2, s));
+    }
+    if (cells) HIP_TRY(c, hipMemcpyAsync(flags, c->oflags.p, cells, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(keep, c->okeep.p, n_rows, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return INQ_OK;
+}
+
+int inq_outlier_rows(inq_ctx_t *c, const float *values, const uint32_t *row_len, uint64_t n_rows, uint32_t stride, int method,
+                     uint32_t minsize, float zscore_cutoff, uint32_t mincluster, uint8_t *flags, uint8_t *keep) {
+    try {
+        return outlier_rows_impl(c, values, row_len, n_rows, stride, method, minsize, zscore_cutoff, mincluster, flags, keep);
     } catch (const std::bad_alloc &) {
         return INQ_ERR_NOMEM;
     } catch (...) {

@@ -32,6 +32,7 @@ struct inq_ctx {
     inq::DevBuf worklist, sval, smeta;
     // staging for the host-buffer entry
     inq::DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
+    inq::DevBuf ovalues, olen, oflags, okeep, otrans;  // inq_outlier_rows
     uint32_t grid_big = 1024;
     uint32_t grid_medium = 8192;
     uint32_t max_reads_hint = 0;  // 0 = unknown; else the caller's bound on reads per locus

@@ -91,4 +91,20 @@ void launch_scan_cigar_units(const inq_read_t *reads, const unsigned long long *
 void launch_scan_max_i64(const int64_t *in, int64_t *out, uint64_t n, uint64_t *tmp, hipStream_t s);
 inline uint64_t scan_tmp_words(uint64_t n) { return (n + 4095) / 4096 + 2; }
 
+// outlier.hip
+struct OutlierArgs {
+    const float *values;      // [n_rows][stride], row i holds row_len[i] values
+    const uint32_t *row_len;  // [n_rows]
+    uint64_t n_rows;
+    uint32_t stride;
+    uint32_t minsize;
+    float zscore_cutoff;
+    uint32_t mincluster;
+    uint8_t *flags;  // [n_rows][stride]: 1 = outlier
+    uint8_t *keep;   // [n_rows]: INQ_OUTLIER_ROW_*
+};
+// z-score works on a transposed copy ([stride][rows_padded] floats, caller's scratch); flags must be zero-filled
+inline uint64_t outlier_rows_padded(uint64_t n_rows) { return (n_rows + 63) / 64 * 64; }
+void launch_outlier(const OutlierArgs &a, int method, float *transposed, hipStream_t s);
+
 }  // namespace inq

@@ -50,6 +50,7 @@ ABI_SYMBOLS = (
     "inq_span_stage",
     "inq_call_span_staged",
     "inq_span_fetch_batch",
+    "inq_outlier_rows",
 )
 
 
@@ -205,6 +206,8 @@ def load(path: Optional[str] = None):
     L.inq_span_stage.argtypes = [vp, C.POINTER(SpanC), C.c_int]
     L.inq_call_span_staged.restype = C.c_int
     L.inq_call_span_staged.argtypes = [vp, C.POINTER(SpanC), C.c_int, C.POINTER(InqResultC), C.POINTER(SpanStatsC)]
+    L.inq_outlier_rows.restype = C.c_int
+    L.inq_outlier_rows.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32, vp, vp]
     L.inq_span_fetch_batch.restype = C.c_int
     L.inq_span_fetch_batch.argtypes = [vp, vp, vp, vp, vp]
     if path is None:
@@ -323,6 +326,21 @@ class Context:
         if rc != INQ_OK:
             self._raise(rc)
         return cigar, reads, pair_read, off
+
+    def outlier_rows(self, values: np.ndarray, row_len: np.ndarray, method: str = "zscore", minsize: int = 10,
+                     zscore_cutoff: float = 3.0, mincluster: int = 1, check: bool = True):
+        """inq_outlier_rows: values f32 [n_rows, stride]; returns (code, flags u8 [n_rows, stride], keep u8 [n_rows])."""
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        row_len = np.ascontiguousarray(row_len, dtype=np.uint32)
+        n_rows, stride = values.shape if values.ndim == 2 else (len(row_len), 0)
+        flags = np.zeros((n_rows, stride), dtype=np.uint8)
+        keep = np.zeros(n_rows, dtype=np.uint8)
+        rc = self._L.inq_outlier_rows(self._h, values.ctypes.data, row_len.ctypes.data, n_rows, stride,
+                                      {"zscore": 0, "dbscan": 1}[method], minsize, zscore_cutoff, mincluster,
+                                      flags.ctypes.data, keep.ctypes.data)
+        if rc != INQ_OK and check:
+            self._raise(rc)
+        return rc, flags, keep
 
     def status(self) -> Tuple[int, int]:
         ties = C.c_uint64(0)

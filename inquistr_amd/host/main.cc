@@ -34,12 +34,64 @@ int main(int argc, char **argv) {
         if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
         return rc;
     }
+    if (argc >= 2 && std::strcmp(argv[1], "outlier") == 0) {  // src/main.rs:75-99
+        inq_outlier_args_t o;
+        std::memset(&o, 0, sizeof o);
+        o.minsize = 10;
+        o.zscore = 3.0f;
+        o.method = INQ_OUTLIER_ZSCORE;
+        const char *combined = nullptr;
+        for (int i = 2; i < argc; ++i) {
+            std::string s = argv[i];
+            auto eq = s.find('=');
+            std::string key = (s.size() > 2 && s[0] == '-' && s[1] == '-' && eq != std::string::npos) ? s.substr(0, eq) : s;
+            const char *inl = (key.size() != s.size()) ? argv[i] + eq + 1 : nullptr;
+            auto val = [&]() -> const char * {
+                if (inl) return inl;
+                if (i + 1 >= argc) {
+                    std::fprintf(stderr, "error: a value is required for '%s' but none was supplied\n", argv[i]);
+                    std::exit(2);
+                }
+                return argv[++i];
+            };
+            if (key == "--minsize") o.minsize = (uint32_t)std::strtoul(val(), nullptr, 10);
+            else if (key == "-z" || key == "--zscore") o.zscore = std::strtof(val(), nullptr);
+            else if (key == "--method") {
+                const std::string m = val();
+                if (m == "zscore") o.method = INQ_OUTLIER_ZSCORE;
+                else if (m == "dbscan") o.method = INQ_OUTLIER_DBSCAN;
+                else {
+                    std::fprintf(stderr, "error: invalid value '%s' for '--method <METHOD>'\n  [possible values: zscore, dbscan]\n", m.c_str());
+                    return 2;
+                }
+            } else if (key == "-s" || key == "--sample") o.sample = val();
+            else if (key == "-S" || key == "--subset") o.subset_file = val();
+            else if (key == "--device") o.device = (int32_t)std::strtol(val(), nullptr, 10);
+            else if (!s.empty() && s[0] == '-' && s.size() > 1) {
+                std::fprintf(stderr, "error: unexpected argument '%s' found\n", s.c_str());
+                return 2;
+            } else if (!combined) combined = argv[i];
+            else {
+                std::fprintf(stderr, "error: unexpected argument '%s' found\n", s.c_str());
+                return 2;
+            }
+        }
+        if (!combined) {
+            std::fputs("error: the following required arguments were not provided:\n  <COMBINED>\n\nUsage: inquistr outlier [OPTIONS] <COMBINED>\n", stderr);
+            return 2;
+        }
+        o.combined = combined;
+        char err[1024] = {0};
+        int rc = inq_outlier(&o, 1, err, sizeof err);
+        if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
+        return rc;
+    }
     if (argc < 2 || std::strcmp(argv[1], "call") != 0) {
         if (argc >= 2 && (!std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help"))) {
             std::puts("Tool to genotype STRs from long reads (MI355X build: `call` only)\n\nUsage: inquistr call [OPTIONS] <BAM>");
             return 0;
         }
-        std::fputs("error: this build provides the `call` and `combine` subcommands only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
+        std::fputs("error: this build provides the `call`, `combine` and `outlier` subcommands only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
         return 2;
     }
     if (argc == 2) {  // arg_required_else_help

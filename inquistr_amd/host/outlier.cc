@@ -1,0 +1,291 @@
+// outlier.cc — `inquiSTR outlier` (src/outlier.rs:33-73, src/main.rs:75-99,202-229): reads a combined .inq,
+// hands the numbers of all loci to the GPU in one matrix (inq_outlier_rows) and prints the loci with
+// outlying samples.  Text in, text out; the arithmetic is not here.
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "../../include/inquistr_host.h"
+
+namespace {
+
+void set_err(char *buf, size_t cap, const std::string &m) {
+    if (buf && cap) std::snprintf(buf, cap, "%s", m.c_str());
+}
+
+// utils::reader (src/utils.rs:7-13): niffler sniffs the compression from the first bytes; zlib's gz layer does
+// the same for gzip / plain text (bzip2, xz and zstd inputs are not supported here)
+struct Lines {
+    gzFile gz = nullptr;
+    bool open(const char *path) {
+        gz = gzopen(path, "rb");
+        if (gz) gzbuffer(gz, 1 << 20);
+        return gz != nullptr;
+    }
+    bool next(std::string &line) {  // BufRead::lines(): split on '\n', a trailing '\r' goes too
+        line.clear();
+        char buf[1 << 16];
+        bool got = false;
+        for (;;) {
+            if (!gzgets(gz, buf, sizeof buf)) break;
+            got = true;
+            const size_t n = std::strlen(buf);
+            line.append(buf, n);
+            if (n && buf[n - 1] == '\n') break;
+        }
+        if (!got) return false;
+        if (!line.empty() && line.back() == '\n') line.pop_back();
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        return true;
+    }
+    ~Lines() {
+        if (gz) gzclose(gz);
+    }
+};
+
+void split_tabs(const std::string &s, std::vector<std::pair<size_t, size_t>> &out) {
+    out.clear();
+    size_t p = 0;
+    for (;;) {
+        const size_t t = s.find('\t', p);
+        if (t == std::string::npos) {
+            out.emplace_back(p, s.size() - p);
+            return;
+        }
+        out.emplace_back(p, t - p);
+        p = t + 1;
+    }
+}
+
+// Rust's `str::parse::<f32>`: [+-]? ( inf | infinity | nan | digits [. digits] [e [+-] digits] ), nothing around it
+bool parse_f32(const char *s, size_t n, float *out) {
+    size_t i = 0;
+    if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+    auto word = [&](const char *w) {
+        const size_t m = std::strlen(w);
+        if (n - i != m) return false;
+        for (size_t k = 0; k < m; ++k)
+            if ((s[i + k] | 0x20) != w[k]) return false;
+        return true;
+    };
+    bool ok = word("inf") || word("infinity") || word("nan");
+    if (!ok) {
+        size_t j = i, digits = 0;
+        while (j < n && s[j] >= '0' && s[j] <= '9') ++j, ++digits;
+        if (j < n && s[j] == '.') {
+            ++j;
+            while (j < n && s[j] >= '0' && s[j] <= '9') ++j, ++digits;
+        }
+        if (!digits) return false;
+        if (j < n && (s[j] == 'e' || s[j] == 'E')) {
+            ++j;
+            if (j < n && (s[j] == '+' || s[j] == '-')) ++j;
+            size_t ed = 0;
+            while (j < n && s[j] >= '0' && s[j] <= '9') ++j, ++ed;
+            if (!ed) return false;
+        }
+        if (j != n) return false;
+    }
+    char tmp[128];
+    if (n >= sizeof tmp) {  // absurdly long literal: strtof on a heap copy
+        std::string t(s, n);
+        *out = std::strtof(t.c_str(), nullptr);
+        return true;
+    }
+    std::memcpy(tmp, s, n);
+    tmp[n] = 0;
+    *out = std::strtof(tmp, nullptr);  // correctly rounded, like Rust
+    return true;
+}
+
+std::string strip_hap(std::string s) {  // .replace("_H1", "").replace("_H2", ""), src/outlier.rs:108,128
+    for (const char *pat : {"_H1", "_H2"}) {
+        size_t p = 0;
+        while ((p = s.find(pat, p)) != std::string::npos) s.erase(p, 3);
+    }
+    return s;
+}
+
+bool write_all(int fd, const std::string &s) {
+    size_t off = 0;
+    while (off < s.size()) {
+        ssize_t w = ::write(fd, s.data() + off, s.size() - off);
+        if (w <= 0) return false;
+        off += (size_t)w;
+    }
+    return true;
+}
+
+int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t errcap) {
+    if (!a || !a->combined) {
+        set_err(errbuf, errcap, "no combined file given");
+        return INQ_EXIT_ERROR;
+    }
+    struct stat st;
+    if (::stat(a->combined, &st) != 0) {  // src/main.rs:210-212
+        set_err(errbuf, errcap, "Combined file does not exist!");
+        return INQ_EXIT_PANIC;
+    }
+    if (a->sample && a->subset_file) {  // src/main.rs:214-216
+        set_err(errbuf, errcap, "Cannot use both -s and -S arguments");
+        return INQ_EXIT_PANIC;
+    }
+    if (a->method != INQ_OUTLIER_ZSCORE && a->method != INQ_OUTLIER_DBSCAN) {
+        set_err(errbuf, errcap, "unknown method");
+        return INQ_EXIT_ERROR;
+    }
+    bool have_subset = false;
+    std::vector<std::string> subset;
+    if (a->sample) have_subset = true, subset.emplace_back(a->sample);
+    if (a->subset_file) {  // one name per line, src/main.rs:220-223
+        Lines sf;
+        if (!sf.open(a->subset_file)) {
+            set_err(errbuf, errcap, "Problem opening file");
+            return INQ_EXIT_PANIC;
+        }
+        have_subset = true;
+        std::string l;
+        while (sf.next(l)) subset.push_back(l);
+    }
+    Lines in;
+    if (!in.open(a->combined)) {
+        set_err(errbuf, errcap, "Problem opening file");
+        return INQ_EXIT_PANIC;
+    }
+    std::string line;
+    if (!in.next(line)) {  // lines.next().unwrap(), src/outlier.rs:36
+        set_err(errbuf, errcap, "called `Option::unwrap()` on a `None` value (empty combined file)");
+        return INQ_EXIT_PANIC;
+    }
+    std::vector<std::pair<size_t, size_t>> fld;
+    split_tabs(line, fld);
+    std::vector<std::string> samples;
+    for (size_t k = 3; k < fld.size(); ++k) samples.push_back(line.substr(fld[k].first, fld[k].second));
+    if (samples.empty()) {  // samples.len().ilog2(), :39; the header went out one line earlier (:37)
+        write_all(out_fd, "chrom\tbegin\tend\toutliers\n");
+        set_err(errbuf, errcap, "argument of integer logarithm must be positive (no sample columns)");
+        return INQ_EXIT_PANIC;
+    }
+    uint32_t mincluster = 0;
+    for (size_t n = samples.size(); n > 1; n >>= 1) ++mincluster;
+    for (auto &s : samples) s = strip_hap(s);
+
+    // every locus: coordinates as text + its numbers; rows may be ragged, the matrix takes the widest
+    std::vector<std::string> coords;
+    std::vector<uint32_t> row_len;
+    std::vector<std::vector<float>> rows;
+    size_t stride = 0;
+    // the reference works line by line: what it printed before a panic stays printed.  A line that makes it
+    // panic ends the reading here; the lines in front of it are still computed and printed.
+    std::string late_panic;
+    while (late_panic.empty() && in.next(line)) {
+        split_tabs(line, fld);
+        if (fld.size() < 3) {  // splitline[2], :43
+            late_panic = "index out of bounds: a line with fewer than three fields";
+            break;
+        }
+        std::vector<float> v(fld.size() - 3);
+        for (size_t k = 3; k < fld.size() && late_panic.empty(); ++k)
+            if (!parse_f32(line.data() + fld[k].first, fld[k].second, &v[k - 3]))  // :78
+                late_panic = "Failed to parse number: " + line.substr(fld[k].first, fld[k].second);
+        if (!late_panic.empty()) break;
+        coords.push_back(line.substr(0, fld[2].first + fld[2].second));
+        row_len.push_back((uint32_t)v.size());
+        stride = std::max(stride, v.size());
+        rows.push_back(std::move(v));
+    }
+    const size_t n_rows = rows.size();
+    std::vector<float> mat(n_rows * stride, 0.0f);
+    for (size_t i = 0; i < n_rows; ++i) std::memcpy(mat.data() + i * stride, rows[i].data(), rows[i].size() * sizeof(float));
+    std::vector<std::vector<float>>().swap(rows);
+    std::vector<uint8_t> flags(n_rows * stride, 0), keep(n_rows, 0);
+
+    inq_ctx_t *ctx = nullptr;
+    int hrc = inq_ctx_create(a->device, &ctx);
+    if (hrc != INQ_OK) {
+        set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
+        return INQ_EXIT_ERROR;
+    }
+    hrc = inq_outlier_rows(ctx, mat.data(), row_len.data(), n_rows, (uint32_t)stride, a->method, a->minsize, a->zscore,
+                           mincluster, flags.data(), keep.data());
+    std::string detail = hrc == INQ_ERR_HIP ? inq_last_error(ctx) : "";
+    inq_ctx_destroy(ctx);
+    if (hrc != INQ_OK) {
+        set_err(errbuf, errcap, std::string("device call failed: ") + inq_strerror(hrc) + (detail.empty() ? "" : " [" + detail + "]"));
+        return INQ_EXIT_ERROR;
+    }
+
+    std::string out = "chrom\tbegin\tend\toutliers\n";  // :37
+    for (size_t i = 0; i < n_rows; ++i) {
+        switch (keep[i]) {
+        case INQ_OUTLIER_ROW_SKIP: continue;
+        case INQ_OUTLIER_ROW_EMPTY:
+            write_all(out_fd, out);
+            set_err(errbuf, errcap, "called `Option::unwrap()` on a `None` value (a locus without values)");
+            return INQ_EXIT_PANIC;
+        case INQ_OUTLIER_ROW_NO_MODE:
+            write_all(out_fd, out);
+            set_err(errbuf, errcap, "No mode found for repeat");
+            return INQ_EXIT_PANIC;
+        case INQ_OUTLIER_ROW_TOO_WIDE:
+            set_err(errbuf, errcap, "DBSCAN on more than 8192 values per locus is not supported");
+            return INQ_EXIT_ERROR;
+        default: break;
+        }
+        std::string names;
+        bool any = false, in_subset = !have_subset;
+        for (uint32_t k = 0; k < row_len[i]; ++k) {
+            if (!flags[i * stride + k]) continue;
+            if (k >= samples.size()) {  // samples[index], :108
+                write_all(out_fd, out);
+                set_err(errbuf, errcap, "index out of bounds: more values than samples in the header");
+                return INQ_EXIT_PANIC;
+            }
+            if (any) names += ',';
+            names += samples[k];
+            any = true;
+            if (have_subset && !in_subset)
+                for (const auto &s : subset)
+                    if (s == samples[k]) in_subset = true;
+        }
+        if (any && in_subset) {  // :47-66
+            out += coords[i];
+            out += '\t';
+            out += names;
+            out += '\n';
+        }
+        if (out.size() > (1u << 20)) {
+            if (!write_all(out_fd, out)) return INQ_EXIT_PANIC;
+            out.clear();
+        }
+    }
+    if (!write_all(out_fd, out)) return INQ_EXIT_PANIC;
+    if (!late_panic.empty()) {
+        set_err(errbuf, errcap, late_panic);
+        return INQ_EXIT_PANIC;
+    }
+    return INQ_EXIT_OK;
+}
+
+}  // namespace
+
+extern "C" int inq_outlier(const inq_outlier_args_t *args, int out_fd, char *errbuf, size_t errcap) {
+    try {
+        return outlier_impl(args, out_fd, errbuf, errcap);
+    } catch (const std::exception &e) {
+        set_err(errbuf, errcap, std::string("internal error: ") + e.what());
+        return INQ_EXIT_ERROR;
+    } catch (...) {
+        set_err(errbuf, errcap, "internal error");
+        return INQ_EXIT_ERROR;
+    }
+}

@@ -1,0 +1,47 @@
+"""`inquiSTR outlier` restatement (oracle/outlier_oracle.py) against the reference's own unit-test vectors and
+hand-derived ones; host-side text rules that need no GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import outlier_oracle as oo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "kat_outlier.json")))["vectors"]
+
+
+def test_oracle_reproduces_the_reference_unit_tests(kat):
+    assert sum(1 for v in kat if v["name"].startswith("reference")) == 2
+    for v in kat:
+        vals = [np.float32(x) for x in v["values"]]
+        if v["method"] == "zscore":
+            got = oo.z_score_outliers(vals, v["samples"], v["cutoff"])
+        else:
+            got = oo.dbscan_outliers(vals, v["samples"], v["mincluster"])
+        assert got == v["expect"], v["name"]
+
+
+def test_parse_f32_follows_rust():
+    for ok in ["1", "-1.5", "+2", ".5", "5.", "1e3", "1E-2", "NaN", "nan", "inf", "-Infinity"]:
+        oo.parse_f32(ok)
+    for bad in ["", " 1", "1 ", "e5", ".", "0x10", "1_0", "1,5", "--1"]:
+        with pytest.raises(oo.ReferencePanic):
+            oo.parse_f32(bad)
+
+
+def test_outlier_text_rules():
+    head = "chromosome\tbegin\tend\tA_H1\tA_H2\tB_H1\tB_H2\tC_H1\tC_H2\tD_H1\tD_H2"
+    rows = ["chr1\t10\t20\t1\t2\t2\t3\t1\tNaN\t3\t500", "chr1\t30\t40\t1\t2\t2\t3\t1\t5\t3\t2", "chr2\t5\t9\t400\t2\t2\t3\t1\t5\t3\t2"]
+    assert oo.outlier_text([head] + rows, 10, 2.0) == "chrom\tbegin\tend\toutliers\nchr1\t10\t20\tD\nchr2\t5\t9\tA\n"
+    assert oo.outlier_text([head] + rows, 10, 2.0, subset=["A"]) == "chrom\tbegin\tend\toutliers\nchr2\t5\t9\tA\n"
+    assert oo.outlier_text([head] + rows, 1000, 2.0) == "chrom\tbegin\tend\toutliers\n"  # nothing reaches minsize
+    with pytest.raises(oo.ReferencePanic):
+        oo.outlier_text([head, "chr1\t1\t2\tx"], 10, 2.0)
+    with pytest.raises(oo.ReferencePanic):
+        oo.outlier_text(["chromosome\tbegin\tend"], 10, 2.0)
