@@ -1,5 +1,5 @@
-"""`python -m inquistr_amd call|combine ...` — forwards to the native CLI (inquistr_amd/lib/inquistr), which is
-the program a user of the reference would run in place of `inquiSTR call` / `inquiSTR combine`."""
+"""`python -m inquistr_amd call|combine|outlier ...` — forwards to the native CLI (inquistr_amd/lib/inquistr), which is
+the program a user of the reference would run in place of `inquiSTR call` / `inquiSTR combine` / `inquiSTR outlier`."""
 import os
 import subprocess
 import sys
