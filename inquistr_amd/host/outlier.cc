@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/stat.h>
@@ -156,16 +158,50 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
         std::string l;
         while (sf.next(l)) subset.push_back(l);
     }
-    Lines in;
-    if (!in.open(a->combined)) {
-        set_err(errbuf, errcap, "Problem opening file");
-        return INQ_EXIT_PANIC;
+    // the HIP runtime starts (0.1 - 0.3 s) while the text is read and parsed
+    inq_ctx_t *ctx = nullptr;
+    int hrc = INQ_OK;
+    std::thread ctx_thread([&] { hrc = inq_ctx_create(a->device, &ctx); });
+    struct CtxGuard {
+        inq_ctx_t *&c;
+        std::thread &t;
+        ~CtxGuard() {
+            if (t.joinable()) t.join();
+            inq_ctx_destroy(c);
+        }
+    } ctx_guard{ctx, ctx_thread};
+    // the whole text in memory, then lines parsed by several threads: the numbers are what the command spends its
+    // time on (40 million of them in a 200 000 x 200 cohort), the GPU part is milliseconds
+    std::string text;
+    {
+        Lines in;
+        if (!in.open(a->combined)) {
+            set_err(errbuf, errcap, "Problem opening file");
+            return INQ_EXIT_PANIC;
+        }
+        char buf[1 << 16];
+        int got;
+        while ((got = gzread(in.gz, buf, sizeof buf)) > 0) text.append(buf, (size_t)got);
+        if (got < 0) {
+            set_err(errbuf, errcap, "Problem reading file");
+            return INQ_EXIT_PANIC;
+        }
     }
-    std::string line;
-    if (!in.next(line)) {  // lines.next().unwrap(), src/outlier.rs:36
+    // BufRead::lines(): split on '\n' (a trailing '\r' goes too); no line after a final newline
+    std::vector<std::pair<size_t, size_t>> lines;  // (offset, length)
+    for (size_t p = 0; p < text.size();) {
+        const char *nl = (const char *)std::memchr(text.data() + p, '\n', text.size() - p);
+        size_t e = nl ? (size_t)(nl - text.data()) : text.size();
+        size_t len = e - p;
+        if (len && text[p + len - 1] == '\r') --len;
+        lines.emplace_back(p, len);
+        p = e + 1;
+    }
+    if (lines.empty()) {  // lines.next().unwrap(), src/outlier.rs:36
         set_err(errbuf, errcap, "called `Option::unwrap()` on a `None` value (empty combined file)");
         return INQ_EXIT_PANIC;
     }
+    std::string line = text.substr(lines[0].first, lines[0].second);
     std::vector<std::pair<size_t, size_t>> fld;
     split_tabs(line, fld);
     std::vector<std::string> samples;
@@ -179,38 +215,76 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
     for (size_t n = samples.size(); n > 1; n >>= 1) ++mincluster;
     for (auto &s : samples) s = strip_hap(s);
 
-    // every locus: coordinates as text + its numbers; rows may be ragged, the matrix takes the widest
-    std::vector<std::string> coords;
-    std::vector<uint32_t> row_len;
-    std::vector<std::vector<float>> rows;
-    size_t stride = 0;
-    // the reference works line by line: what it printed before a panic stays printed.  A line that makes it
-    // panic ends the reading here; the lines in front of it are still computed and printed.
-    std::string late_panic;
-    while (late_panic.empty() && in.next(line)) {
-        split_tabs(line, fld);
-        if (fld.size() < 3) {  // splitline[2], :43
-            late_panic = "index out of bounds: a line with fewer than three fields";
-            break;
+    // The reference works line by line: what it printed before a panic stays printed.  The first line that makes
+    // it panic (fewer than three fields, a number that does not parse) ends the input here; the lines in front
+    // of it are still computed and printed.
+    const size_t n_lines = lines.size() - 1;
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t n_thr = std::max<size_t>(1, std::min<size_t>(hw, n_lines / 2048 + 1));
+    std::vector<uint32_t> row_len(n_lines, 0);
+    std::vector<size_t> bad_a(n_thr, (size_t)-1);
+    auto chunk = [&](size_t t) { return std::make_pair(n_lines * t / n_thr, n_lines * (t + 1) / n_thr); };
+    auto parallel = [&](const std::function<void(size_t)> &fn) {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < n_thr; ++t) th.emplace_back(fn, t);
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    parallel([&](size_t t) {  // pass A: fields per line
+        auto [lo, hi] = chunk(t);
+        for (size_t i = lo; i < hi; ++i) {
+            const char *p = text.data() + lines[i + 1].first;
+            size_t tabs = 0;
+            for (size_t k = 0; k < lines[i + 1].second; ++k) tabs += p[k] == '\t';
+            if (tabs < 2) {  // splitline[2], :43
+                bad_a[t] = i;
+                return;
+            }
+            row_len[i] = (uint32_t)(tabs - 2);
         }
-        std::vector<float> v(fld.size() - 3);
-        for (size_t k = 3; k < fld.size() && late_panic.empty(); ++k)
-            if (!parse_f32(line.data() + fld[k].first, fld[k].second, &v[k - 3]))  // :78
-                late_panic = "Failed to parse number: " + line.substr(fld[k].first, fld[k].second);
-        if (!late_panic.empty()) break;
-        coords.push_back(line.substr(0, fld[2].first + fld[2].second));
-        row_len.push_back((uint32_t)v.size());
-        stride = std::max(stride, v.size());
-        rows.push_back(std::move(v));
-    }
-    const size_t n_rows = rows.size();
-    std::vector<float> mat(n_rows * stride, 0.0f);
-    for (size_t i = 0; i < n_rows; ++i) std::memcpy(mat.data() + i * stride, rows[i].data(), rows[i].size() * sizeof(float));
-    std::vector<std::vector<float>>().swap(rows);
+    });
+    size_t first_bad = n_lines;
+    std::string late_panic;
+    for (size_t t = 0; t < n_thr; ++t)
+        if (bad_a[t] < first_bad) first_bad = bad_a[t], late_panic = "index out of bounds: a line with fewer than three fields";
+    size_t stride = 0;
+    for (size_t i = 0; i < first_bad; ++i) stride = std::max<size_t>(stride, row_len[i]);
+    std::vector<float> mat(first_bad * stride, 0.0f);
+    std::vector<size_t> bad_b(n_thr, (size_t)-1);
+    parallel([&](size_t t) {  // pass B: the numbers
+        auto [lo, hi] = chunk(t);
+        hi = std::min(hi, first_bad);
+        for (size_t i = lo; i < hi; ++i) {
+            const char *p = text.data() + lines[i + 1].first, *end = p + lines[i + 1].second;
+            int field = 0;
+            const char *f0 = p;
+            for (const char *q = p;; ++q) {
+                if (q == end || *q == '\t') {
+                    if (field >= 3 && !parse_f32(f0, (size_t)(q - f0), &mat[i * stride + (size_t)(field - 3)])) {  // :78
+                        bad_b[t] = i;
+                        return;
+                    }
+                    ++field;
+                    f0 = q + 1;
+                    if (q == end) break;
+                }
+            }
+        }
+    });
+    for (size_t t = 0; t < n_thr; ++t)
+        if (bad_b[t] < first_bad) first_bad = bad_b[t], late_panic = "Failed to parse number";
+    row_len.resize(first_bad);
+    auto coords_of = [&](size_t i) {  // chrom, begin, end as they stand in the file
+        const char *p = text.data() + lines[i + 1].first;
+        size_t k = 0, tabs = 0;
+        for (; k < lines[i + 1].second; ++k)
+            if (p[k] == '\t' && ++tabs == 3) break;
+        return std::string(p, k);
+    };
+    const size_t n_rows = first_bad;
     std::vector<uint8_t> flags(n_rows * stride, 0), keep(n_rows, 0);
 
-    inq_ctx_t *ctx = nullptr;
-    int hrc = inq_ctx_create(a->device, &ctx);
+    ctx_thread.join();
     if (hrc != INQ_OK) {
         set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
         return INQ_EXIT_ERROR;
@@ -218,7 +292,6 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
     hrc = inq_outlier_rows(ctx, mat.data(), row_len.data(), n_rows, (uint32_t)stride, a->method, a->minsize, a->zscore,
                            mincluster, flags.data(), keep.data());
     std::string detail = hrc == INQ_ERR_HIP ? inq_last_error(ctx) : "";
-    inq_ctx_destroy(ctx);
     if (hrc != INQ_OK) {
         set_err(errbuf, errcap, std::string("device call failed: ") + inq_strerror(hrc) + (detail.empty() ? "" : " [" + detail + "]"));
         return INQ_EXIT_ERROR;
@@ -258,7 +331,7 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
                     if (s == samples[k]) in_subset = true;
         }
         if (any && in_subset) {  // :47-66
-            out += coords[i];
+            out += coords_of(i);
             out += '\t';
             out += names;
             out += '\n';
