@@ -45,3 +45,25 @@ def test_outlier_text_rules():
         oo.outlier_text([head, "chr1\t1\t2\tx"], 10, 2.0)
     with pytest.raises(oo.ReferencePanic):
         oo.outlier_text(["chromosome\tbegin\tend"], 10, 2.0)
+
+
+def test_outlier_command_without_gpu(tmp_path):
+    """No CPU path for the arithmetic: without a gfx950 device the command ends with status 1; the reference's
+    argument panics come first."""
+    import torch
+
+    from inquistr_amd import call
+
+    p = tmp_path / "c.tsv"
+    p.write_text("chromosome\tbegin\tend\tA_H1\tA_H2\nchr1\t1\t9\t12\t99\n")
+    with pytest.raises(call.CallError) as e:
+        call.outlier(tmp_path / "missing.tsv")
+    assert e.value.status == 101 and "does not exist" in e.value.message
+    (tmp_path / "s.txt").write_text("A\n")
+    with pytest.raises(call.CallError) as e:
+        call.outlier(p, sample="A", subset=tmp_path / "s.txt")
+    assert e.value.status == 101
+    if not torch.cuda.is_available():
+        with pytest.raises(call.CallError) as e, open(tmp_path / "o.txt", "w") as f:
+            call.outlier(p, out=f)
+        assert e.value.status == 1 and "no CPU fallback" in e.value.message
