@@ -200,7 +200,8 @@ typedef struct inq_bgzf_block {
 
 /* Inflates n_blocks BGZF payloads; every pointer is HOST memory (the call uploads, runs one lane per
  * block, downloads, synchronises).  block_status may be NULL.  Returns INQ_ERR_INFLATE if any block
- * failed.  CRC32 is not verified. */
+ * failed.  `comp` holds whole BGZF blocks: the 8 bytes behind every payload are its CRC32 / ISIZE trailer,
+ * and the inflated bytes are checked against that CRC32 as htslib does (ctx option "verify_crc", default 1). */
 int inq_bgzf_inflate(inq_ctx_t *ctx, const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks,
                      uint64_t n_blocks, uint8_t *out, uint64_t out_bytes, uint32_t *block_status);
 
@@ -209,7 +210,8 @@ int inq_bgzf_inflate(inq_ctx_t *ctx, const uint8_t *comp, uint64_t comp_bytes, c
  * segments.  Segments let one call serve loci that are far apart without inflating what lies between. */
 #define INQ_ANCHOR_SEGMENT_END (1ull << 63)
 typedef struct inq_span {
-    const uint8_t *comp;             /* HOST (ideally pinned): the compressed bytes of the blocks        */
+    const uint8_t *comp;             /* HOST (pageable is fine): the compressed bytes of the blocks,
+                                        segment after segment, each payload followed by its trailer      */
     uint64_t comp_bytes;
     const inq_bgzf_block_t *blocks;  /* file order; out_off dense and ascending from 0                   */
     uint64_t n_blocks;
