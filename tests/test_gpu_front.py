@@ -449,3 +449,55 @@ def test_device_aux_walk_skips_long_strings_of_every_length(tmp_path):
             call.genotype_repeats(bam, "chr1:5000-5050", None, 5, 3, 1, False, "S", None, out=f, frontend=fe)
         texts[fe] = out.read_text()
     assert texts["device"] == texts["host"] == "chromosome\tbegin\tend\tS_H1\tS_H2\nchr1\t5000\t5050\t12\t30\n"
+
+
+def test_edge_loci_through_both_front_ends(tmp_path):
+    """Loci at the lowest legal start (10), at the end of a contig, duplicated, zero-length, nested and abutting;
+    reads starting at position 0 and ending on the last base: device front end = host front end = the Python
+    restatement over every record."""
+    from inquistr_amd import call
+    from oracle import pyoracle as py
+    from tests import gen
+    from tools import bamio
+
+    rng = random.Random(31)
+    LN = 60_000
+    loci = [("chrA", 10, 40), ("chrA", 10, 40), ("chrA", 25, 25), ("chrA", 20, 300), ("chrA", 300, 320), ("chrA", 320, 340),
+            ("chrA", LN - 200, LN - 1), ("chrA", LN - 11, LN - 1), ("chrB", 10, 10), ("chrB", 5000, 5050)]
+    recs = {0: [], 1: []}
+    for t, (lo, hi) in ((0, (0, 400)), (0, (LN - 900, LN - 1)), (1, (0, 60)), (1, (4700, 5300))):
+        for k in range(40):
+            pos = rng.randint(lo, max(lo, hi - 50)) if k % 5 else lo  # some reads start on the first base of the range
+            cig = gen.random_cigar(rng, rng.choice([1, 3, 9, 30]))
+            ref = sum(n for o, n in cig if o in "MDN=X")
+            room = (LN if t == 0 else 20_000) - pos
+            if ref > room:
+                cig = [("M", max(room, 1))]
+            recs[t].append(py.Record(pos=pos, cigar=cig, mapq=rng.choice([5, 20, 60]), flag=rng.choice([0, 16]), hp=("C", rng.choice([1, 2])), tid=t))
+    recs[0].append(py.Record(pos=LN - 700, cigar=[("M", 350), ("I", 9), ("M", 350)], mapq=60, hp=("C", 1), tid=0))  # ends on the last base
+    bam = str(tmp_path / "edge.bam")
+    w = bamio.BamWriter(bam, [("chrA", LN), ("chrB", 20_000)], block=3000)
+    k = 0
+    for t in (0, 1):
+        recs[t].sort(key=lambda r: r.pos)
+        for r in recs[t]:
+            w.add(f"r{k}", r.flag, t, r.pos, r.mapq, r.cigar, [("HP", r.hp[0], r.hp[1])], l_seq=k % 4)
+            k += 1
+    w.close()
+    bed = tmp_path / "edge.bed"
+    bed.write_text("".join(f"{c}\t{s}\t{e}\n" for c, s, e in loci))
+    for unphased in (False, True):
+        rows = [py.format_header("S")]
+        for c, s, e in loci:
+            t = 0 if c == "chrA" else 1
+            if unphased:
+                a, b, _ = py.genotype_repeat_unphased(recs[t], t, s, e, 5, 2)
+            else:
+                a, b = py.genotype_repeat_phased(recs[t], t, s, e, 5, 2)
+            rows.append(py.format_row(c, s, e, a, b))
+        want = "\n".join(rows) + "\n"
+        for fe in ("host", "device"):
+            out = tmp_path / f"{fe}.inq"
+            with open(out, "w") as f:
+                call.genotype_repeats(bam, None, str(bed), 5, 2, 1, unphased, "S", None, out=f, frontend=fe)
+            assert out.read_text() == want, (fe, unphased)
