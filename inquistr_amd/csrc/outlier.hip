@@ -5,8 +5,8 @@
 //   mode :132-145, dbscan_outliers :112-130 + [3P] dbscan 0.3.1  1-D DBSCAN, eps = max(2 * mode, 10), f64 distances
 // Rows (loci) are independent.  z-score: one LANE per row, so that every f32 addition happens in the
 // reference's order (no FMA contraction: explicit round-to-nearest intrinsics); the kernel is a stream over the
-// matrix, three passes per row.  DBSCAN: one WAVE per row with the row in LDS; neighbour counts are O(n^2)
-// broadcast reads of LDS.  Noise = neither a core point nor within eps of one (order-independent).
+// matrix, three passes per row.  DBSCAN: one workgroup per row, the row sorted in LDS, neighbour counts by binary
+// search (O(n log n)).  Noise = neither a core point nor within eps of one (order-independent).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -71,46 +71,92 @@ __global__ __launch_bounds__(256) void outlier_zscore_kernel(OutlierArgs a, cons
 
 constexpr uint32_t kDbscanMaxCols = 8192;
 
-__global__ __launch_bounds__(64) void outlier_dbscan_kernel(OutlierArgs a) {
-    __shared__ float v[kDbscanMaxCols];
-    __shared__ uint8_t core[kDbscanMaxCols];
+// 1-D DBSCAN of one row per workgroup, O(n log n): the row is sorted in LDS (bitonic, value + original index),
+// after which (a) equal `value as usize` keys are contiguous, so the mode is a matter of run lengths, and
+// (b) the neighbours of a point - |x - y| < eps, evaluated in f64 exactly as the crate does - are a contiguous
+// range found by two binary searches on that same predicate (rounding is monotone, so it has one switch point
+// on either side of the point).  A prefix count of the core points then answers "is a core point within eps".
+template <int CAP>
+struct DbscanLds {
+    float v[CAP];
+    uint16_t idx[CAP];
+    uint16_t pc[CAP + 1];  // pc[i] = core points among sorted positions [0, i)
+    unsigned long long wkey[4];  // per-wave partial results of the workgroup's four waves
+    uint32_t wcnt[4];
+    float wmax[4];
+};
+
+__device__ __forceinline__ unsigned long long as_usize(float x) {  // `value as usize`: saturating, for x > 0
+    return x >= 18446744073709551616.0f ? ~0ull : (unsigned long long)x;
+}
+
+template <int CAP>
+__global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
+    __shared__ DbscanLds<CAP> L;
     const uint64_t row = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t t = threadIdx.x;
     const uint32_t n = a.row_len[row];
     const float *p = a.values + row * (uint64_t)a.stride;
     uint8_t *f = a.flags + row * (uint64_t)a.stride;
-    if (n == 0 || n > kDbscanMaxCols) {
-        if (lane == 0) a.keep[row] = n == 0 ? INQ_OUTLIER_ROW_EMPTY : INQ_OUTLIER_ROW_TOO_WIDE;
+    if (n == 0 || n > (uint32_t)CAP) {
+        if (t == 0) a.keep[row] = n == 0 ? INQ_OUTLIER_ROW_EMPTY : INQ_OUTLIER_ROW_TOO_WIDE;
         return;
     }
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
     float mx = -INFINITY;
-    for (uint32_t k = lane; k < n; k += 64u) {
-        const float x = clean(p[k]);
-        v[k] = x;
-        mx = x > mx ? x : mx;
+    for (uint32_t k = t; k < np2; k += 256u) {
+        const float x = k < n ? clean(p[k]) : INFINITY;  // padding sorts behind everything
+        L.v[k] = x;
+        L.idx[k] = (uint16_t)k;
+        if (k < n) mx = x > mx ? x : mx;
     }
     for (int off = 32; off; off >>= 1) {
         const float o = __shfl_xor(mx, off);
         mx = o > mx ? o : mx;
     }
+    if ((t & 63u) == 0) L.wmax[t >> 6] = mx;
     __syncthreads();
-    if (mx < (float)a.minsize) {
-        if (lane == 0) a.keep[row] = INQ_OUTLIER_ROW_SKIP;
+    mx = fmaxf(fmaxf(L.wmax[0], L.wmax[1]), fmaxf(L.wmax[2], L.wmax[3]));
+    if (mx < (float)a.minsize) {  // :86-92
+        if (t == 0) a.keep[row] = INQ_OUTLIER_ROW_SKIP;
         return;
     }
-    // mode of `value as usize` over the positive values (:136-139); ties -> the smallest value (the reference
-    // leaves them to HashMap order)
+    // bitonic sort ascending by (value, original index)
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < np2; i += 256u) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const float x = L.v[i], y = L.v[l];
+                    const uint16_t xi = L.idx[i], yi = L.idx[l];
+                    const bool up = (i & k) == 0;
+                    const bool gt = x > y || (x == y && xi > yi);
+                    if (gt == up) {
+                        L.v[i] = y, L.v[l] = x;
+                        L.idx[i] = yi, L.idx[l] = xi;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // mode of `value as usize` over the positive values (:136-139): longest run of equal keys; ties -> the
+    // smallest key (the reference leaves them to HashMap order)
     uint32_t best_cnt = 0;
     unsigned long long best_key = ~0ull;
-    for (uint32_t i = lane; i < n; i += 64u) {
-        const float x = v[i];
+    for (uint32_t i = t; i < n; i += 256u) {
+        const float x = L.v[i];
         if (!(x > 0.0f)) continue;
-        const unsigned long long key = x >= 18446744073709551616.0f ? ~0ull : (unsigned long long)x;
-        uint32_t cnt = 0;
-        for (uint32_t j = 0; j < n; ++j) {
-            const float y = v[j];
-            if (y > 0.0f && (y >= 18446744073709551616.0f ? ~0ull : (unsigned long long)y) == key) ++cnt;
+        const unsigned long long key = as_usize(x);
+        if (i > 0 && L.v[i - 1] > 0.0f && as_usize(L.v[i - 1]) == key) continue;  // not the start of its run
+        uint32_t lo = i + 1, hi = n;  // first position behind the run
+        while (lo < hi) {
+            const uint32_t m = (lo + hi) >> 1;
+            if (as_usize(L.v[m]) == key) lo = m + 1;
+            else hi = m;
         }
+        const uint32_t cnt = lo - i;
         if (cnt > best_cnt || (cnt == best_cnt && key < best_key)) best_cnt = cnt, best_key = key;
     }
     for (int off = 32; off; off >>= 1) {
@@ -118,27 +164,63 @@ __global__ __launch_bounds__(64) void outlier_dbscan_kernel(OutlierArgs a) {
         const unsigned long long ok = __shfl_xor(best_key, off);
         if (oc > best_cnt || (oc == best_cnt && ok < best_key)) best_cnt = oc, best_key = ok;
     }
+    if ((t & 63u) == 0) L.wcnt[t >> 6] = best_cnt, L.wkey[t >> 6] = best_key;
+    __syncthreads();
+    best_cnt = 0, best_key = ~0ull;
+    for (int w = 0; w < 4; ++w)
+        if (L.wcnt[w] > best_cnt || (L.wcnt[w] == best_cnt && L.wkey[w] < best_key)) best_cnt = L.wcnt[w], best_key = L.wkey[w];
     if (best_cnt == 0) {  // "No mode found for repeat"
-        if (lane == 0) a.keep[row] = INQ_OUTLIER_ROW_NO_MODE;
+        if (t == 0) a.keep[row] = INQ_OUTLIER_ROW_NO_MODE;
         return;
     }
-    if (lane == 0) a.keep[row] = INQ_OUTLIER_ROW_KEEP;
+    if (t == 0) a.keep[row] = INQ_OUTLIER_ROW_KEEP;
     const unsigned long long twice = best_key * 2ull;  // usize arithmetic of the reference (wraps in release builds)
     const double eps = (double)(twice > 10ull ? twice : 10ull);  // :115
-    for (uint32_t i = lane; i < n; i += 64u) {
-        const double x = (double)v[i];
-        uint32_t cnt = 0;
-        for (uint32_t j = 0; j < n; ++j) cnt += fabs(x - (double)v[j]) < eps ? 1u : 0u;  // [3P] range_query: distance < eps
-        core[i] = cnt >= a.mincluster ? 1 : 0;                                            // [3P] neighbors.len() >= mpt
+    auto near = [&](double x, uint32_t j) { return fabs(x - (double)L.v[j]) < eps; };  // [3P] range_query: distance < eps
+    auto range_of = [&](uint32_t i, uint32_t &first, uint32_t &behind) {
+        const double x = (double)L.v[i];
+        uint32_t lo = 0, hi = i;  // first position <= i that is near
+        while (lo < hi) {
+            const uint32_t m = (lo + hi) >> 1;
+            if (near(x, m)) hi = m;
+            else lo = m + 1;
+        }
+        first = lo;
+        lo = i + 1, hi = n;  // first position > i that is not near
+        while (lo < hi) {
+            const uint32_t m = (lo + hi) >> 1;
+            if (near(x, m)) lo = m + 1;
+            else hi = m;
+        }
+        behind = lo;
+    };
+    for (uint32_t i = t; i < n; i += 256u) {
+        uint32_t first, behind;
+        range_of(i, first, behind);
+        L.pc[i + 1] = (behind - first) >= a.mincluster ? 1 : 0;  // [3P] neighbors.len() >= mpt (the point itself counts)
+    }
+    if (t == 0) L.pc[0] = 0;
+    __syncthreads();
+    if (t < 64u) {  // one wave turns the core flags into prefix counts
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + t;
+            uint32_t x = i < n ? L.pc[i + 1] : 0u;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off);
+                if ((int)t >= off) x += y;
+            }
+            if (i < n) L.pc[i + 1] = (uint16_t)(carry + x);
+            carry += __shfl(x, 63);
+        }
     }
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64u) {
-        bool noise = !core[i];
-        if (noise) {
-            const double x = (double)v[i];
-            for (uint32_t j = 0; j < n && noise; ++j) noise = !(core[j] && fabs(x - (double)v[j]) < eps);
-        }
-        if (noise) f[i] = 1;  // :126 Classification::Noise (flags are zero-filled by the caller)
+    for (uint32_t i = t; i < n; i += 256u) {
+        const bool core = L.pc[i + 1] != L.pc[i];
+        if (core) continue;
+        uint32_t first, behind;
+        range_of(i, first, behind);
+        if (L.pc[behind] == L.pc[first]) f[L.idx[i]] = 1;  // no core point within eps: Classification::Noise (:126)
     }
 }
 
@@ -152,8 +234,12 @@ void launch_outlier(const OutlierArgs &a, int method, float *transposed, hipStre
             hipLaunchKernelGGL(outlier_transpose_kernel, dim3((uint32_t)((a.n_rows + 63) / 64), (a.stride + 63) / 64), dim3(256), 0, s,
                                a.values, transposed, a.n_rows, a.stride, rows_padded);
         hipLaunchKernelGGL(outlier_zscore_kernel, dim3((uint32_t)((a.n_rows + 255) / 256)), dim3(256), 0, s, a, transposed, rows_padded);
-    } else
-        hipLaunchKernelGGL(outlier_dbscan_kernel, dim3((uint32_t)a.n_rows), dim3(64), 0, s, a);
+    } else if (a.stride <= 256u)
+        hipLaunchKernelGGL((outlier_dbscan_kernel<256>), dim3((uint32_t)a.n_rows), dim3(256), 0, s, a);
+    else if (a.stride <= 2048u)
+        hipLaunchKernelGGL((outlier_dbscan_kernel<2048>), dim3((uint32_t)a.n_rows), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((outlier_dbscan_kernel<kDbscanMaxCols>), dim3((uint32_t)a.n_rows), dim3(256), 0, s, a);
 }
 
 }  // namespace inq
