@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
     auto near = [&](double x, uint32_t j) { return fabs(x - (double)L.v[j]) < eps; };  // [3P] range_query: distance < eps
     auto range_of = [&](uint32_t i, uint32_t &first, uint32_t &behind) {
         const double x = (double)L.v[i];
+        if (!isfinite(x)) {  // inf - inf is NaN, and NaN < eps is false: an infinite value is not even its own neighbour
+            first = behind = i;
+            return;
+        }
         uint32_t lo = 0, hi = i;  // first position <= i that is near
         while (lo < hi) {
             const uint32_t m = (lo + hi) >> 1;

@@ -40,17 +40,18 @@ def parse_f32(s: str) -> np.float32:
 
 def std_deviation_and_mean(data: Sequence[np.float32]):
     """src/outlier.rs:18-31: sequential f32 sums."""
-    s = F(0)
-    for v in data:
-        s = F(s + v)
-    count = F(len(data))
-    mean = F(s / count)
-    var = F(0)
-    for v in data:
-        d = F(mean - v)
-        var = F(var + F(d * d))
-    var = F(var / count)
-    return mean, F(np.sqrt(var))
+    with np.errstate(all="ignore"):  # inf - inf and friends are part of the semantics, not accidents
+        s = F(0)
+        for v in data:
+            s = F(s + v)
+        count = F(len(data))
+        mean = F(s / count)
+        var = F(0)
+        for v in data:
+            d = F(mean - v)
+            var = F(var + F(d * d))
+        var = F(var / count)
+        return mean, F(np.sqrt(var))
 
 
 def get_repeat_lengths(fields: Sequence[str], minsize: int) -> Optional[List[np.float32]]:

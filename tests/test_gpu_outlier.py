@@ -50,6 +50,8 @@ def _random_matrix(rng, n_rows, n_cols):
         else:
             r = [float(rng.choice([7, 7, 7, 40])) for _ in range(n)]
         r = [float("nan") if rng.random() < 0.08 else x for x in r]
+        if rng.random() < 0.05 and n:  # "inf" parses as an f32 too
+            r[rng.randrange(n)] = rng.choice([float("inf"), float("-inf")])
         lens.append(n)
         rows.append(r + [0.0] * (n_cols - n))
     return np.array(rows, dtype=np.float32).reshape(n_rows, n_cols), np.array(lens, dtype=np.uint32)
