@@ -805,6 +805,10 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
         int wrc = write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
         if (wrc != INQ_EXIT_OK) return wrc;
     }
+    {  // the CLI is about to leave the process: the device context is left to the operating system (see run_device_front)
+        const char *fast_env = std::getenv("INQ_FAST_EXIT");
+        actx.leak = fast_env && fast_env[0] == '1';
+    }
     if (timing)
         std::fprintf(stderr, "[inq timing] open+targets %.3fs  hip ctx %.3fs  front end %.3fs  device calls %.3fs  total %.3fs\n",
                      secs(t_start, t_prep), secs(t_prep, t_ctx), t_front, t_dev, secs(t_start, clk::now()));
