@@ -90,8 +90,9 @@ __device__ __forceinline__ unsigned long long as_usize(float x) {  // `value as 
     return x >= 18446744073709551616.0f ? ~0ull : (unsigned long long)x;
 }
 
-template <int CAP>
-__global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
+template <int CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void outlier_dbscan_kernel(OutlierArgs a) {
+    constexpr int kWaves = THREADS / 64;
     __shared__ DbscanLds<CAP> L;
     const uint64_t row = blockIdx.x;
     const uint32_t t = threadIdx.x;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
     float mx = -INFINITY;
-    for (uint32_t k = t; k < np2; k += 256u) {
+    for (uint32_t k = t; k < np2; k += (uint32_t)THREADS) {
         const float x = k < n ? clean(p[k]) : INFINITY;  // padding sorts behind everything
         L.v[k] = x;
         L.idx[k] = (uint16_t)k;
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
     }
     if ((t & 63u) == 0) L.wmax[t >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(L.wmax[0], L.wmax[1]), fmaxf(L.wmax[2], L.wmax[3]));
+    mx = L.wmax[0];
+    for (int w = 1; w < kWaves; ++w) mx = fmaxf(mx, L.wmax[w]);
     if (mx < (float)a.minsize) {  // :86-92
         if (t == 0) a.keep[row] = INQ_OUTLIER_ROW_SKIP;
         return;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
     // bitonic sort ascending by (value, original index)
     for (uint32_t k = 2; k <= np2; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = t; i < np2; i += 256u) {
+            for (uint32_t i = t; i < np2; i += (uint32_t)THREADS) {
                 const uint32_t l = i ^ j;
                 if (l > i) {
                     const float x = L.v[i], y = L.v[l];
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
     // smallest key (the reference leaves them to HashMap order)
     uint32_t best_cnt = 0;
     unsigned long long best_key = ~0ull;
-    for (uint32_t i = t; i < n; i += 256u) {
+    for (uint32_t i = t; i < n; i += (uint32_t)THREADS) {
         const float x = L.v[i];
         if (!(x > 0.0f)) continue;
         const unsigned long long key = as_usize(x);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
     if ((t & 63u) == 0) L.wcnt[t >> 6] = best_cnt, L.wkey[t >> 6] = best_key;
     __syncthreads();
     best_cnt = 0, best_key = ~0ull;
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < kWaves; ++w)
         if (L.wcnt[w] > best_cnt || (L.wcnt[w] == best_cnt && L.wkey[w] < best_key)) best_cnt = L.wcnt[w], best_key = L.wkey[w];
     if (best_cnt == 0) {  // "No mode found for repeat"
         if (t == 0) a.keep[row] = INQ_OUTLIER_ROW_NO_MODE;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
         }
         behind = lo;
     };
-    for (uint32_t i = t; i < n; i += 256u) {
+    for (uint32_t i = t; i < n; i += (uint32_t)THREADS) {
         uint32_t first, behind;
         range_of(i, first, behind);
         L.pc[i + 1] = (behind - first) >= a.mincluster ? 1 : 0;  // [3P] neighbors.len() >= mpt (the point itself counts)
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void outlier_dbscan_kernel(OutlierArgs a) {
         }
     }
     __syncthreads();
-    for (uint32_t i = t; i < n; i += 256u) {
+    for (uint32_t i = t; i < n; i += (uint32_t)THREADS) {
         const bool core = L.pc[i + 1] != L.pc[i];
         if (core) continue;
         uint32_t first, behind;
@@ -238,12 +240,12 @@ void launch_outlier(const OutlierArgs &a, int method, float *transposed, hipStre
             hipLaunchKernelGGL(outlier_transpose_kernel, dim3((uint32_t)((a.n_rows + 63) / 64), (a.stride + 63) / 64), dim3(256), 0, s,
                                a.values, transposed, a.n_rows, a.stride, rows_padded);
         hipLaunchKernelGGL(outlier_zscore_kernel, dim3((uint32_t)((a.n_rows + 255) / 256)), dim3(256), 0, s, a, transposed, rows_padded);
-    } else if (a.stride <= 256u)
-        hipLaunchKernelGGL((outlier_dbscan_kernel<256>), dim3((uint32_t)a.n_rows), dim3(256), 0, s, a);
+    } else if (a.stride <= 256u)  // a row of <= 256 values keeps one wave busy, not four
+        hipLaunchKernelGGL((outlier_dbscan_kernel<256, 64>), dim3((uint32_t)a.n_rows), dim3(64), 0, s, a);
     else if (a.stride <= 2048u)
-        hipLaunchKernelGGL((outlier_dbscan_kernel<2048>), dim3((uint32_t)a.n_rows), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((outlier_dbscan_kernel<2048, 256>), dim3((uint32_t)a.n_rows), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((outlier_dbscan_kernel<kDbscanMaxCols>), dim3((uint32_t)a.n_rows), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((outlier_dbscan_kernel<kDbscanMaxCols, 256>), dim3((uint32_t)a.n_rows), dim3(256), 0, s, a);
 }
 
 }  // namespace inq
