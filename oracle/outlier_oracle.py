@@ -131,3 +131,28 @@ def outlier_text(lines: Sequence[str], minsize: int = 10, zscore_cutoff: float =
         if names and (subset is None or any(n in subset for n in names)):
             out.append(f"{f[0]}\t{f[1]}\t{f[2]}\t{','.join(names)}")
     return "\n".join(out) + "\n"
+
+
+def c_outlier_rows(values: np.ndarray, row_len: np.ndarray, method: str = "zscore", minsize: int = 10, cutoff: float = 3.0,
+                   mincluster: int = 1, threads: int = 1):
+    """The C restatement (oracle/outlier_oracle.c, OpenMP over rows): (flags, keep).  CPU baseline + cross-check."""
+    import ctypes as C
+    import os
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "liborcoutlier.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(here, "outlier_oracle.c")):
+        subprocess.check_call(["make", "-C", here, "-B", "liborcoutlier.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(lib)
+    values = np.ascontiguousarray(values, dtype=np.float32)
+    row_len = np.ascontiguousarray(row_len, dtype=np.uint32)
+    n_rows, stride = values.shape
+    flags = np.zeros((n_rows, stride), dtype=np.uint8)
+    keep = np.zeros(n_rows, dtype=np.uint8)
+    L.orc_outlier_rows.restype = None
+    L.orc_outlier_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32,
+                                   C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_outlier_rows(values.ctypes.data, row_len.ctypes.data, n_rows, stride, {"zscore": 0, "dbscan": 1}[method], minsize,
+                       cutoff, mincluster, flags.ctypes.data, keep.ctypes.data, threads)
+    return flags, keep

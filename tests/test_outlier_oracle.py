@@ -67,3 +67,36 @@ def test_outlier_command_without_gpu(tmp_path):
         with pytest.raises(call.CallError) as e, open(tmp_path / "o.txt", "w") as f:
             call.outlier(p, out=f)
         assert e.value.status == 1 and "no CPU fallback" in e.value.message
+
+
+@pytest.mark.parametrize("method", ["zscore", "dbscan"])
+def test_c_restatement_agrees_with_the_python_one(method):
+    import random
+
+    rng = random.Random(5)
+    n_rows, n_cols = 200, 37
+    vals = np.zeros((n_rows, n_cols), dtype=np.float32)
+    lens = np.zeros(n_rows, dtype=np.uint32)
+    for i in range(n_rows):
+        n = rng.choice([0, 1, 5, n_cols, n_cols])
+        base = rng.choice([3, 12, 40])
+        row = [base + rng.choice([-1, 0, 0, 1, 0.5]) for _ in range(n)]
+        for _ in range(rng.choice([0, 1, 3])):
+            if n:
+                row[rng.randrange(n)] = rng.choice([base * 7.0, float("nan"), float("inf"), -4.0])
+        vals[i, :n] = row
+        lens[i] = n
+    flags, keep = oo.c_outlier_rows(vals, lens, method, minsize=10, cutoff=2.0, mincluster=5, threads=2)
+    for i in range(n_rows):
+        row = [np.float32(0) if np.isnan(x) else x for x in vals[i, : lens[i]]]
+        if not row:
+            assert keep[i] == 2
+        elif max(row) < np.float32(10):
+            assert keep[i] == 0
+        else:
+            try:
+                want = oo.z_score_flags(row, 2.0) if method == "zscore" else oo.dbscan_flags(row, 5)
+            except oo.ReferencePanic:
+                assert keep[i] == 3
+                continue
+            assert keep[i] == 1 and list(flags[i, : lens[i]].astype(bool)) == want, i

@@ -32,6 +32,21 @@ def main():
         print(f"{method}: {n_rows} loci x {n_cols} values: kernel {ms:.3f} ms = {n_rows / ms / 1e3:.1f} M loci/s, "
               f"{cells * 5 / ms / 1e6:.1f} GB/s of matrix read + flags written once (call incl. PCIe {wall * 1e3:.0f} ms); "
               f"{int(keep.sum())} loci kept, {int(flags.sum())} outlying values", flush=True)
+    # CPU baseline: the C restatement (oracle/outlier_oracle.c, OpenMP over loci) on a sample of the same matrix, and
+    # a check that it reports the same values
+    from oracle import outlier_oracle as oo
+
+    threads = min(16, len(os.sched_getaffinity(0)))
+    sample = min(n_rows, max(1000, (200_000_000 if method == "zscore" else 4_000_000_000) // max(n_cols * (1 if method == "zscore" else n_cols), 1)))
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        cf, ck = oo.c_outlier_rows(vals[:sample], lens[:sample], method, 10, 3.0, max(1, n_cols.bit_length() - 1), threads)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    same = bool((cf == flags[:sample]).all() and (ck == keep[:sample]).all())
+    print(f"cpu baseline ({threads} threads, first {sample} loci, C restatement of src/outlier.rs, not the Rust binary): "
+          f"{best * 1e3:.1f} ms = {sample / best / 1e6:.2f} M loci/s; same flags as the GPU: {same}", flush=True)
 
 
 if __name__ == "__main__":
