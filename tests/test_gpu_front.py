@@ -501,3 +501,27 @@ def test_edge_loci_through_both_front_ends(tmp_path):
             with open(out, "w") as f:
                 call.genotype_repeats(bam, None, str(bed), 5, 2, 1, unphased, "S", None, out=f, frontend=fe)
             assert out.read_text() == want, (fe, unphased)
+
+
+def test_many_spans_with_staged_uploads_equal_the_host_front_end(tmp_path, monkeypatch):
+    """20 000 loci / 200 MB of BAM cut into 64 MB spans: the loader thread stages span k+1 on the device while span k
+    is being inflated.  Same bytes as the host front end, every row called, and the same again with one big span."""
+    from inquistr_amd import call
+    from tools import make_synth_bam
+
+    prefix = str(tmp_path / "w")
+    make_synth_bam.write("unphased100k", 20_000, prefix)
+    texts = {}
+    for name, env in (("host", {"INQ_FRONTEND": "host"}), ("device64", {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "64"}),
+                      ("device", {"INQ_FRONTEND": "device"}), ("auto", {})):
+        for k in ("INQ_FRONTEND", "INQ_SPAN_MB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = tmp_path / f"{name}.inq"
+        with open(out, "w") as f:
+            call.genotype_repeats(prefix + ".bam", None, prefix + ".bed", 5, 3, 8, True, "S", None, out=f)
+        texts[name] = out.read_text()
+    assert texts["host"] == texts["device64"] == texts["device"] == texts["auto"]
+    rows = texts["host"].splitlines()
+    assert len(rows) == 20_001 and not any(r.endswith("NaN\tNaN") for r in rows[1:])
