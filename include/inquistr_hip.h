@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define INQ_ABI_VERSION 2
+#define INQ_ABI_VERSION 3
 
 /* ---- error codes (0 = ok, negative = failure; never throws / aborts) ---- */
 enum {
@@ -47,9 +47,11 @@ enum {
                                   `r.expect("Error reading BAM file")` src/call.rs:295,346 panics)     */
     INQ_ERR_BAM = -12,         /* device front end: record chain / field lengths corrupt, or records of the
                                   contig not coordinate-sorted                                          */
-    INQ_ERR_AUX = -13          /* device front end: HP aux of a fetched read is neither `C` nor `i`
-                                  (src/call.rs:482-491), SA is not `Z` or cannot be parsed (:429-451):
-                                  the reference panics                                                  */
+    INQ_ERR_AUX = -13          /* an aux field the reference panics on: HP of a FETCHED read is neither `C`
+                                  nor `i` in phased mode (get_phase runs before the filter, src/call.rs:349,
+                                  482-491; device front end), or a KEPT read carries INQ_READ_SA_PANIC
+                                  (is_accidental_2d is only reached from call_from_cigar, i.e. for reads
+                                  that passed the filter: src/call.rs:303,357 -> :394 -> :429-451)        */
 };
 
 /* ---- read descriptor: one 16-byte record per decoded BAM record ---------
@@ -58,7 +60,8 @@ enum {
  *   mapq()            src/call.rs:299,352       -> mapq
  *   cigar()           src/call.rs:382           -> cigar_off4 / n_cigar into inq_batch_t.cigar
  *   aux(b"HP")        src/call.rs:482-491       -> bits&INQ_READ_HAS_HP, phase (value `as u8`)
- *   is_accidental_2d  src/call.rs:415-459       -> bits&INQ_READ_IS_2D (host evaluates the SA string)
+ *   is_accidental_2d  src/call.rs:415-459       -> bits&INQ_READ_IS_2D / INQ_READ_SA_PANIC (the SA string is evaluated
+ *                                                  by whoever builds the descriptors: host sweep or cigar_gather)
  *   flag 0x4          (bam_endpos rule)         -> bits&INQ_READ_UNMAPPED
  */
 typedef struct inq_read {
@@ -75,6 +78,10 @@ typedef struct inq_read {
 #define INQ_READ_REVERSE 0x02u  /* BAM flag 0x10  */
 #define INQ_READ_HAS_HP 0x04u   /* HP aux present */
 #define INQ_READ_IS_2D 0x08u    /* is_accidental_2d(record) == true */
+#define INQ_READ_SA_PANIC 0x10u /* the CIGAR has an S op AND is_accidental_2d(record) would panic (SA aux not `Z`,
+                                   no entry, < 4 fields, POS or CIGAR unparsable: src/call.rs:429-451,469).  The
+                                   reference only gets there for a read that passed the filter (:303,357), so the
+                                   device raises INQ_ERR_AUX iff such a read is KEPT; a filtered-out one is ignored */
 
 /* ---- one batch of loci ----------------------------------------------------
  * cigar   : BAM-native packed ops, `len << 4 | op`, op in 0..8 = MIDNSHP=X, all reads

@@ -36,6 +36,7 @@ INQ_READ_UNMAPPED = 0x01
 INQ_READ_REVERSE = 0x02
 INQ_READ_HAS_HP = 0x04
 INQ_READ_IS_2D = 0x08
+INQ_READ_SA_PANIC = 0x10  # has an S op and is_accidental_2d would panic: raised for kept reads only
 
 INQ_PAIR_CLIP = 0x01
 INQ_PAIR_FETCHED = 0x02
@@ -245,6 +246,7 @@ class BatchBuilder:
         reverse: bool = False,
         unmapped: bool = False,
         is_2d: bool = False,
+        sa_panic: bool = False,
     ) -> int:
         w = np.asarray(cigar_words, dtype=np.uint32)
         n = int(w.shape[0])
@@ -257,6 +259,7 @@ class BatchBuilder:
             | (INQ_READ_REVERSE if reverse else 0)
             | (INQ_READ_HAS_HP if phase is not None else 0)
             | (INQ_READ_IS_2D if is_2d else 0)
+            | (INQ_READ_SA_PANIC if sa_panic else 0)
         )
         self._reads.append((self._off4, n, pos, mapq, bits, (phase or 0) & 0xFF, 0))
         self._off4 += (n + pad) // 4

@@ -312,8 +312,10 @@ __global__ __launch_bounds__(256) void cigar_gather_kernel(ScanArgs a, uint64_t 
         // is_accidental_2d is only reached from a soft-clip op (src/call.rs:394)
         if (clip && ri.sa_off) {
             const uint32_t v = is_accidental_2d(a.u, ri, (rd.bits & INQ_READ_REVERSE) != 0, (int64_t)rd.pos, endpos);
+            // a panic of is_accidental_2d only happens for a read that passes the filter (src/call.rs:303,357 ->
+            // :394): carried as a bit of the descriptor, raised by the locus kernel's read epilogue if KEPT
             if (v == 1u) rd.bits |= INQ_READ_IS_2D;
-            else if (v > 1u) a.info[i].err = ri.err | (v >> 8);
+            else if (v > 1u) rd.bits |= INQ_READ_SA_PANIC;
         }
         a.reads[i] = rd;
     }

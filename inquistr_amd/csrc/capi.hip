@@ -44,6 +44,7 @@ int status_to_code(uint32_t st) {
     if (st & ST_CIGAR_OP) return INQ_ERR_CIGAR_OP;
     if (st & ST_RANGE) return INQ_ERR_RANGE;
     if (st & ST_PHASE) return INQ_ERR_PHASE;
+    if (st & ST_AUX) return INQ_ERR_AUX;
     return INQ_OK;
 }
 
@@ -67,7 +68,7 @@ const char *inq_strerror(int code) {
     case INQ_ERR_NOMEM: return "out of device memory";
     case INQ_ERR_INFLATE: return "a BGZF block does not inflate to its recorded size (corrupt or truncated BAM)";
     case INQ_ERR_BAM: return "corrupt BAM record chain, or records not coordinate-sorted";
-    case INQ_ERR_AUX: return "HP aux of a fetched read is neither C nor i, or its SA aux cannot be parsed (the reference panics)";
+    case INQ_ERR_AUX: return "HP aux of a fetched read is neither C nor i, or the SA aux of a kept read with a soft clip cannot be parsed (the reference panics)";
     case INQ_ERR_NO_DEVICE: return "no gfx950 (MI355X) device available; this library has no CPU fallback";
     default: return "unknown error";
     }

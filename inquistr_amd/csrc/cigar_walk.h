@@ -26,14 +26,14 @@ namespace inq {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // device status word bits (mapped to INQ_ERR_* by the host, same precedence as the oracle)
-constexpr uint32_t ST_INDEX = 1u, ST_CIGAR_OP = 2u, ST_RANGE = 4u, ST_PHASE = 8u, ST_LOCUS = 16u, ST_HINT = 32u;
+constexpr uint32_t ST_INDEX = 1u, ST_CIGAR_OP = 2u, ST_RANGE = 4u, ST_PHASE = 8u, ST_LOCUS = 16u, ST_HINT = 32u, ST_AUX = 64u;
 
 // per-pair meta byte: low 3 bits are the public INQ_PAIR_* bits
 constexpr uint32_t PM_CLIP = 1u, PM_FETCHED = 2u, PM_KEPT = 4u;
 constexpr int PM_GRP_SHIFT = 4;  // bits 4-5: haplotype group 0 (none) / 1 / 2
 constexpr uint32_t PM_CHOSEN = 64u;
 
-constexpr uint32_t RB_UNMAPPED = 1u, RB_REVERSE = 2u, RB_HAS_HP = 4u, RB_IS_2D = 8u;
+constexpr uint32_t RB_UNMAPPED = 1u, RB_REVERSE = 2u, RB_HAS_HP = 4u, RB_IS_2D = 8u, RB_SA_PANIC = 16u;
 
 constexpr int kQueueCap = 128;  // window-lane queue entries per wave
 
@@ -268,10 +268,7 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
         carry += readlane_u32(incl, 63);
         ++tc;
         if (tc >= t_nchunks) {
-            // lane tk <- carry: v_writelane takes the value from an SGPR and the lane select from M0
-            // (constant-bus limit: one SGPR).  M0 is a reserved register hipcc never keeps live on
-            // gfx950 (LDS needs no M0 init on GFX9+), so it is free to use inside one asm statement.
-            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(end_carry) : "s"(carry), "s"(tk));
+            end_carry = writelane_u32(end_carry, carry, tk);  // lane tk <- carry
             ++tk;
             tc = 0;
             tail_load();
@@ -320,6 +317,9 @@ __device__ __forceinline__ void walk_pairs(const BatchView &b, const PairMeta &m
                 grp = phase;
         }
         if (bad_phase) status |= ST_PHASE;
+        // is_accidental_2d panics on this read's SA, but the reference only calls it from call_from_cigar,
+        // i.e. for reads that passed the filter (src/call.rs:303,357 -> :394)
+        if (kept && (bits & RB_SA_PANIC)) status |= ST_AUX;
         val = (int64_t)L.acc[lane];
         meta = ((L.flags[lane] & 1u) ? PM_CLIP : 0u) | (fetched ? PM_FETCHED : 0u) | (kept ? PM_KEPT : 0u) |
                (grp << PM_GRP_SHIFT);

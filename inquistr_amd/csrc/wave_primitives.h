@@ -49,6 +49,12 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int l) {
     uint32_t hi = readlane_u32((uint32_t)((uint64_t)v >> 32), l);
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
+// v_writelane_b32 through the LLVM intrinsic (this clang has no __builtin_amdgcn_writelane): the value and the
+// lane select are wave-uniform, register allocation and M0 are the compiler's business
+extern "C" __device__ int inq_llvm_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t writelane_u32(uint32_t old, uint32_t value, int l) {
+    return (uint32_t)inq_llvm_writelane_i32((int)value, l, (int)old);
+}
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 }  // namespace inq

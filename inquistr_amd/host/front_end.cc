@@ -91,16 +91,13 @@ int FrontEnd::add_read(const BamRec &r, bool has_clip, std::string *err, bool *p
             return -1;
         }
     }
-    // is_accidental_2d is only reached from a soft-clip op (src/call.rs:394)
+    // is_accidental_2d is only reached from a soft-clip op (src/call.rs:394) of a read that passed the filter
+    // (call_from_cigar is called behind it, :303,357): a panic in there is carried as a bit of the descriptor
+    // and raised by the device for KEPT reads only
     if (has_clip && r.sa_type) {
-        std::string pm;
-        int v = is_accidental_2d(r, &pm);
-        if (v < 0) {
-            *err = pm;
-            *panic = true;
-            return -1;
-        }
-        if (v) bits |= INQ_READ_IS_2D;
+        int v = is_accidental_2d(r, nullptr);
+        if (v < 0) bits |= INQ_READ_SA_PANIC;
+        else if (v) bits |= INQ_READ_IS_2D;
     }
     inq_read_t rd;
     std::memset(&rd, 0, sizeof rd);

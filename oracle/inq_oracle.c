@@ -391,17 +391,21 @@ static int panic_to_inq(int panic) {
     case ORC_PANIC_PHASE_KEY: return INQ_ERR_PHASE;
     case ORC_PANIC_SUPPORT: return INQ_ERR_SUPPORT_ZERO;
     case ORC_PANIC_LOCUS: return INQ_ERR_LOCUS;
+    case ORC_PANIC_SA_TYPE:
+    case ORC_PANIC_SA_FORMAT:
+    case ORC_PANIC_HP_TYPE: return INQ_ERR_AUX;
     default: return INQ_ERR_ARG;
     }
 }
 
-/* error precedence shared with the HIP library: INDEX > CIGAR_OP > RANGE > PHASE */
+/* error precedence shared with the HIP library: INDEX > CIGAR_OP > RANGE > PHASE > AUX */
 static int err_rank(int code) {
     switch (code) {
-    case INQ_ERR_INDEX: return 4;
-    case INQ_ERR_CIGAR_OP: return 3;
-    case INQ_ERR_RANGE: return 2;
-    case INQ_ERR_PHASE: return 1;
+    case INQ_ERR_INDEX: return 5;
+    case INQ_ERR_CIGAR_OP: return 4;
+    case INQ_ERR_RANGE: return 3;
+    case INQ_ERR_PHASE: return 2;
+    case INQ_ERR_AUX: return 1;
     default: return 0;
     }
 }
@@ -459,6 +463,13 @@ int orc_call_batch(const inq_batch_t *b, inq_result_t *res, int n_threads) {
             r->sa_type = 0;
             r->sa = NULL;
             r->is2d_given = (rd->bits & INQ_READ_IS_2D) ? 1 : 0;
+            if (rd->bits & INQ_READ_SA_PANIC) {
+                /* "is_accidental_2d would panic on this record": stands in as an SA aux that is not a
+                 * string, so the panic fires where the reference's does - at the first soft-clip op of a
+                 * read that passed the filter (src/call.rs:303,357 -> :394 -> :429-432) - and nowhere else */
+                r->sa_type = 'i';
+                r->is2d_given = -1;
+            }
             /* domain checks the device also makes for every offered read */
             int64_t rlen = 0;
             int bad_op = 0;
@@ -493,7 +504,9 @@ int orc_call_batch(const inq_batch_t *b, inq_result_t *res, int n_threads) {
                 int64_t val = 0;
                 if (r->tid == 0) {
                     int pp = 0;
-                    orc_call_t c = orc_call_from_cigar(r, b->minlen, start_ext, end_ext, &pp);
+                    orc_record_t q = *r; /* debug value of a read flagged SA_PANIC: as if is_accidental_2d were false */
+                    if (q.is2d_given < 0) q.sa_type = 0, q.is2d_given = 0;
+                    orc_call_t c = orc_call_from_cigar(&q, b->minlen, start_ext, end_ext, &pp);
                     val = c.value;
                     if (c.clipped) bits |= INQ_PAIR_CLIP;
                     if (fetch_yields(r, 0, start_ext, end_ext)) {

@@ -218,7 +218,7 @@ def test_device_front_end_error_classes(tmp_path):
         bam = str(tmp_path / "e.bam")
         w = bamio.BamWriter(bam, [("chr1", 100000)])
         for i, r in enumerate(sorted(recs, key=lambda r: r.pos) if sort else recs):
-            w.add(f"r{i}", r.flag, 0, r.pos, 60, r.cigar, (tags or (lambda r: [("HP", r.hp[0], r.hp[1])] + ([("SA", r.sa[0], r.sa[1])] if r.sa else [])))(r))
+            w.add(f"r{i}", r.flag, 0, r.pos, r.mapq, r.cigar, (tags or (lambda r: [("HP", r.hp[0], r.hp[1])] + ([("SA", r.sa[0], r.sa[1])] if r.sa else [])))(r))
         w.close()
         with open(tmp_path / "e.inq", "w") as f:
             call.genotype_repeats(bam, "chr1:5000-5050", None, 5, 3, 1, unphased, None, None, out=f, frontend="device")
@@ -243,6 +243,9 @@ def test_device_front_end_error_classes(tmp_path):
     with pytest.raises(call.CallError) as e:
         run(bad_sa2)
     assert e.value.status == 101
+    # the same read filtered out (mapq <= 10) never reaches call_from_cigar, hence never is_accidental_2d
+    dropped = ok + [py.Record(pos=4990, cigar=[("S", 20), ("M", 400)], mapq=5, hp=("C", 1), sa=("Z", "chr1,notanumber,-,50M,60,0;"))]
+    assert run(dropped).splitlines()[1] == "chr1\t5000\t5050\t12\t12"
     # the same reads without a soft clip never reach is_accidental_2d
     fine = ok + [py.Record(pos=4990, cigar=[("M", 400)], hp=("C", 1), sa=("Z", "chr1,notanumber,-,50M,60,0;"))]
     assert run(fine).count("\n") == 2
@@ -250,6 +253,35 @@ def test_device_front_end_error_classes(tmp_path):
     with pytest.raises(call.CallError) as e:
         run([ok[0], py.Record(pos=4700, cigar=[("M", 500)], hp=("C", 1))] + ok[1:], sort=False)
     assert e.value.status == 101
+
+
+@pytest.mark.parametrize("frontend", ["host", "device"])
+def test_error_class_sweep(tmp_path, frontend):
+    """{mapq 5/60} x {HP absent/C/i/s} x {spanning/inside/partial} x {clip/no clip} x {10 SA shapes} x {phased, unphased}:
+    exit status AND row text against the Python restatement.  is_accidental_2d can only panic for a read that passed
+    the filter (src/call.rs:303,357 -> :394), get_phase for any fetched read in phased mode (:349)."""
+    from inquistr_amd import call
+    from tests import errclass
+
+    bam = str(tmp_path / "e.bam")
+    out = tmp_path / "e.inq"
+    region = "%s:%d-%d" % errclass.LOCUS
+    n_panic = n_rows = 0
+    for name, probe in errclass.cases():
+        recs = errclass.write_bam(bam, errclass.good_reads() + [probe])
+        for unphased in (False, True):
+            want = errclass.expected(recs, unphased)
+            try:
+                with open(out, "w") as f:
+                    call.genotype_repeats(bam, region, None, 5, 3, 1, unphased, None, None, out=f, frontend=frontend)
+                got = out.read_text().splitlines()[1]
+            except call.CallError as e:
+                assert e.status == 101, (name, unphased, e)
+                got = None
+            assert got == want, (name, unphased, frontend)
+            n_panic += want is None
+            n_rows += want is not None
+    assert n_panic == 4 * 6 + 2 * 3 * 2 * 10 + 2 * 2 * 6 and n_rows == 2 * 480 - n_panic
 
 
 def test_device_front_end_region_string_and_long_cigar_tag(tmp_path):

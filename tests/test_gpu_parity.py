@@ -276,6 +276,23 @@ def test_domain_errors(ctx, orc):
     b = one()
     b.locus_pair_off[1] = 2
     assert both(b) == B.INQ_ERR_ARG
+    # INQ_READ_SA_PANIC: raised for a KEPT read only (src/call.rs:303,357 -> :394); the read below has a soft clip
+    def sa(mapq, phase, unphased, pos=900, depth=1):
+        bb = B.BatchBuilder(unphased=unphased)
+        good = [bb.add_read(900, B.encode_cigar([("M", 300)]), phase=1) for _ in range(depth - 1)]
+        r = bb.add_read(pos, B.encode_cigar([("S", 20), ("M", 300)]), mapq=mapq, phase=phase, sa_panic=True)
+        bb.add_locus(1010, 1090, good + [r])
+        return bb.build()
+
+    for depth in (1, 70, 300, 3000):  # every locus kernel shares the read epilogue
+        assert both(sa(60, 1, False, depth=depth)) == B.INQ_ERR_AUX
+        assert both(sa(60, 1, True, depth=depth)) == B.INQ_ERR_AUX
+        assert both(sa(10, 1, False, depth=depth)) == B.INQ_OK      # mapq <= 10: filtered
+        assert both(sa(60, None, False, depth=depth)) == B.INQ_OK   # no HP in phased mode: filtered
+        assert both(sa(60, None, True, depth=depth)) == B.INQ_ERR_AUX
+        assert both(sa(60, 1, True, pos=1005, depth=depth)) == B.INQ_OK   # starts inside the window: unphased drops it
+        assert both(sa(60, 1, False, pos=1005, depth=depth)) == B.INQ_ERR_AUX  # phased keeps a partial overlap
+        assert both(sa(60, 1, False, pos=5000, depth=depth)) == B.INQ_OK  # not fetched at all
     # the ctx stays usable after an error
     assert both(one()) == B.INQ_OK
 

@@ -41,10 +41,16 @@ def emulate_span(sp):
         ends.append(py.reference_end(rec))
         hp = r["hp"]
         has_clip = any(o == "S" for o, _ in ops)
+        is_2d = sa_panic = False
+        if has_clip and r["sa"]:  # what cigar_gather / FrontEnd::add_read evaluate, panic carried as a bit
+            try:
+                is_2d = py.is_accidental_2d(rec)
+            except py.ReferencePanic:
+                sa_panic = True
         bb.add_read(r["pos"], np.array(r["cigar"], dtype=np.uint32), mapq=r["mapq"],
                     phase=(hp[1] & 0xFF) if hp and hp[0] in "Ci" else None,
                     reverse=bool(r["flag"] & 0x10), unmapped=bool(r["flag"] & 0x4),
-                    is_2d=bool(has_clip and r["sa"] and py.is_accidental_2d(rec)))
+                    is_2d=is_2d, sa_panic=sa_panic)
     for t, s, e in zip(sp["locus_tid"], sp["locus_start"], sp["locus_end"]):
         lo, hi = int(s) - 10, int(e) + 10
         bb.add_locus(int(s), int(e), [i for i, r in enumerate(reads) if r["tid"] == int(t) and r["pos"] < hi and ends[i] > lo])
