@@ -147,6 +147,63 @@ def write(workload: str, n_loci: int, prefix: str, level: int = 1, seq: bool = F
     return rid
 
 
+_NATIVE = None
+
+
+def native_lib():
+    """tools/libsynthbam.so (tools/synth_bam_writer.cc), built on first use."""
+    global _NATIVE
+    if _NATIVE is None:
+        import ctypes as C
+        import subprocess
+
+        here = os.path.dirname(os.path.abspath(__file__))
+        so, src = os.path.join(here, "libsynthbam.so"), os.path.join(here, "synth_bam_writer.cc")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, src, "-lz"])
+        L = C.CDLL(so)
+        L.inq_synth_write_bam.restype = C.c_int
+        L.inq_synth_write_bam.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        _NATIVE = L
+    return _NATIVE
+
+
+def write_native(workload: str, n_loci: int, prefix: str, level: int = 1, threads: int = 0, device=None):
+    """Same files as write() (byte for byte, tests/test_synth_bam_native.py), records assembled, deflated and indexed by
+    native threads.  device: a torch device to generate the workload on (bit-identical to the numpy generator)."""
+    import ctypes as C
+
+    wl = synth.WORKLOADS[workload]
+    if device is not None:
+        d = synth.DeviceBatch(wl, device, 0, n_loci)
+        cigar = d.cigar.cpu().numpy().view(np.uint32)
+        reads = d.reads.cpu().numpy().view(np.uint8).reshape(-1).view(synth.READ_DTYPE)
+        ls, le = d.locus_start.cpu().numpy(), d.locus_end.cpu().numpy()
+        del d
+    else:
+        b = synth.generate_numpy(wl, 0, n_loci)
+        cigar, reads, ls, le = b.cigar, b.reads, b.locus_start, b.locus_end
+    n = len(reads)
+    R = wl.reads_per_locus
+    tid = (np.arange(n, dtype=np.int64) // R // LOCI_PER_CONTIG).astype(np.int32)
+    key = tid.astype(np.int64) << 32 | reads["pos"].astype(np.int64)
+    order = np.argsort(key, kind="stable").astype(np.uint64)
+    name_id = np.arange(n, dtype=np.uint64)
+    n_contigs = (n_loci + LOCI_PER_CONTIG - 1) // LOCI_PER_CONTIG
+    with open(prefix + ".bed", "w") as bed:
+        bed.write("".join(f"chr{j // LOCI_PER_CONTIG + 1}\t{s}\t{e}\n" for j, (s, e) in enumerate(zip(ls.tolist(), le.tolist()))))
+    cigar = np.ascontiguousarray(cigar)
+    reads = np.ascontiguousarray(reads)
+    err = C.create_string_buffer(512)
+    rc = native_lib().inq_synth_write_bam((prefix + ".bam").encode(), n, reads.ctypes.data, cigar.ctypes.data, order.ctypes.data,
+                                          tid.ctypes.data, name_id.ctypes.data, n_contigs, CONTIG_LEN, level,
+                                          threads or len(os.sched_getaffinity(0)), err, len(err))
+    if rc != 0:
+        raise RuntimeError("synth_bam_writer: " + err.value.decode())
+    return n
+
+
 if __name__ == "__main__":
     n = write(sys.argv[1], int(sys.argv[2]), sys.argv[3], seq=len(sys.argv) > 4 and sys.argv[4] == "seq")
     print(f"wrote {sys.argv[3]}.bam/.bai/.bed: {n} reads, {os.path.getsize(sys.argv[3] + '.bam') / 1e6:.1f} MB")
