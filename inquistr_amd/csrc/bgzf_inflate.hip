@@ -617,7 +617,8 @@ __global__ __launch_bounds__(kLanes) void bgzf_crc32_kernel(InflateArgs a) {
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s) {
     if (!a.n_blocks) return;
     const uint64_t grid = (a.n_blocks + kLanes - 1) / kLanes;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
+    if (a.algo == 0u) launch_bgzf_inflate_wg(a, s);
+    else hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
     if (a.verify_crc) hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
 }
 

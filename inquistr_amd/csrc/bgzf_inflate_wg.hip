@@ -1,0 +1,747 @@
+// bgzf_inflate_wg.hip — DEFLATE (RFC 1951) of BGZF blocks, ONE WORKGROUP PER BLOCK, every lane decoding.
+//
+// Replaces, for the device front end, the zlib inflate htslib runs under bam.fetch()/rc_records()
+// (reference call sites src/call.rs:288,294,338,345; [3P] htslib bgzf.c).  The lane-per-block kernel
+// (bgzf_inflate.hip) is bound by the latency of one lane's serial decode (~36 ms per 64 KB block, whatever
+// the number of blocks), so a file of 20 000 blocks keeps a quarter of the chip busy for 36 ms.  Here a
+// workgroup of T lanes decodes ONE block together:
+//
+//   * Huffman decode is parallel INSIDE the deflate stream.  A round hands every lane a 32-byte segment of
+//     the compressed bits.  Lane 0 knows where its first symbol starts; the others guess (their segment's first
+//     bit) and decode anyway: a Huffman decoder started at a wrong bit re-synchronises with the true symbol
+//     chain after a few symbols.  Every lane reports where its chain left its segment; a lane whose left
+//     neighbour ended somewhere else than it started decodes again from there, until every start equals the
+//     neighbour's end (lane 0's is true by construction, so after k repeats lanes 0..k are: correctness never
+//     depends on the guess, only speed does; typically 2-3 repeats).  These passes only COUNT (bits, output
+//     bytes, matches).
+//   * A prefix sum of the byte counts gives every lane its place in the output; a COMMIT pass decodes once more,
+//     stores literals where they belong and, for every byte of a match, records its ROOT in LDS: the position the
+//     byte is ultimately copied from.  Inside a lane's own stretch of output the root is known at once
+//     (root[p] = root[p - distance], the lane walks its bytes in order); a source in an earlier lane's stretch
+//     is left as a pointer.  Pointer jumping (root[p] = root[root[p]], all bytes at once) then shortens every
+//     chain to a literal of this round or to bytes of earlier rounds in a few sweeps - the chains CIGAR-like
+//     data produces (3-byte matches at distance 4 or 8, each feeding the next) would take thousands of ordered
+//     copy sweeps otherwise - and ONE coalesced pass copies out[p] = out[root[p]] for the match bytes.
+//   * Symbols are decoded by table: 10 bits index a 1024-entry table in LDS (literal / length base + extra-bit
+//     count / end-of-block, and the code length), 8 bits a distance table; longer codes (rare by construction)
+//     take the canonical limits-and-base path.  Tables are built by the whole workgroup (count, rank by ballot,
+//     scatter, one canonical decode per table entry).
+//   * The output window is the output itself in global memory (L2-resident while the block is in flight), so a
+//     workgroup needs 20 KB of LDS and eight of them share a CU.
+// Every access is bounded (LDS indices masked or checked, output by ISIZE, distances by the bytes produced,
+// every loop by a bit count that strictly grows), so a corrupt stream ends in a per-block status, never in a
+// fault or a hang.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/inquistr_hip.h"
+#include "front_kernels.h"
+#include "wave_primitives.h"
+
+namespace inq {
+
+namespace {
+
+constexpr int kLitBits = 10, kDistBits = 8;
+constexpr uint32_t kSegBits = 256;  // compressed bits per lane and round
+constexpr int kMaxLit = 288, kMaxDist = 32;
+
+constexpr uint32_t E_LIT = 0u, E_LEN = 1u, E_EOB = 2u, E_LONG = 3u;
+constexpr uint32_t kLongEntry = E_LONG << 4;  // code longer than the table's index: canonical path
+// table entry: bits 0-3 code length (0 = not a code), 4-5 type, 8-11 extra bits, 16-31 literal / base value
+__device__ __forceinline__ uint32_t mk_entry(uint32_t n, uint32_t type, uint32_t xb, uint32_t val) {
+    return n | (type << 4) | (xb << 8) | (val << 16);
+}
+// RFC 1951 3.2.5: literal/length symbol -> entry
+__device__ __forceinline__ uint32_t ll_entry(uint32_t sym, uint32_t n) {
+    if (sym < 256u) return mk_entry(n, E_LIT, 0u, sym);
+    if (sym == 256u) return mk_entry(n, E_EOB, 0u, 0u);
+    const uint32_t s = sym - 257u;
+    if (s >= 29u) return 0u;  // 286, 287 take part in the fixed code but never appear in valid data
+    if (s < 8u) return mk_entry(n, E_LEN, 0u, 3u + s);
+    if (s == 28u) return mk_entry(n, E_LEN, 0u, 258u);
+    const uint32_t xb = (s - 4u) >> 2;
+    return mk_entry(n, E_LEN, xb, 3u + ((4u + (s & 3u)) << xb));
+}
+__device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t n) {
+    if (sym >= 30u) return 0u;
+    if (sym < 4u) return mk_entry(n, E_LEN, 0u, 1u + sym);
+    const uint32_t xb = (sym - 2u) >> 1;
+    return mk_entry(n, E_LEN, xb, 1u + ((2u + (sym & 1u)) << xb));
+}
+
+template <int T>
+struct WgLds {
+    static constexpr int kStage = 8 * T + 8;        // dwords: T segments of 32 bytes + look-ahead
+#ifndef INQ_WG_CAP
+#define INQ_WG_CAP 8192
+#endif
+    static constexpr int kRoundCap = INQ_WG_CAP;    // output bytes per round (rounds are cut at the lane that would exceed it)
+    uint32_t lut_ll[1 << kLitBits];
+    uint32_t lut_d[1 << kDistBits];
+    uint32_t stage[kStage];
+    // root of every output byte of the round, as position - (round start - 32768): >= 32768 = a byte of this round
+    // (a literal points at itself), < 32768 = a byte of an earlier round (deflate distances are <= 32768)
+    uint16_t root[kRoundCap];
+    uint32_t end_bit[T];   // per lane: where its chain left its segment, | kFlagBit if it stopped (EOB / not a code)
+    uint16_t sorted[kMaxLit + kMaxDist];  // symbols by (code length, value): literal/length, then distance
+    uint32_t limit[2][16], base[2][16], cnt[2][16], run[2][16];
+    uint8_t lens[kMaxLit + kMaxDist];
+    uint8_t cl_lut[128];  // 7 bits of the stream -> code-length symbol | code length << 5 (0 = not a code)
+    uint8_t cl_len[20];
+    // block-uniform state
+    uint32_t P, out, status, last, type, eob, hlit, hdist, flag;
+    uint32_t red[8], red2[8];
+};
+
+constexpr uint32_t kStopped = 0x80000000u;  // in end_bit: the chain met EOB or a pattern that is no code
+constexpr uint32_t kStopEob = 0x40000000u;  // ... and it was EOB
+
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
+    uint32_t w;
+    __builtin_memcpy(&w, p, 4);
+    return w;
+}
+__device__ __forceinline__ void st_u32(uint8_t *p, uint32_t w) { __builtin_memcpy(p, &w, 4); }
+
+// ---- LZ77 copy in global memory (the window is the output): <= 16 bytes per load/store group, loads first
+struct Quad {
+    uint32_t w0, w1, w2, w3;
+};
+__device__ __forceinline__ Quad load_quad(const uint8_t *src) { return Quad{ld_u32(src), ld_u32(src + 4), ld_u32(src + 8), ld_u32(src + 12)}; }
+__device__ __forceinline__ void store_quad(uint8_t *dst, const Quad &q, uint32_t n) {
+    if (n == 16u) {
+        st_u32(dst, q.w0);
+        st_u32(dst + 4, q.w1);
+        st_u32(dst + 8, q.w2);
+        st_u32(dst + 12, q.w3);
+        return;
+    }
+    uint32_t k = 0;
+    if (n >= 4u) st_u32(dst, q.w0), k = 4u;
+    if (n >= 8u) st_u32(dst + 4, q.w1), k = 8u;
+    if (n >= 12u) st_u32(dst + 8, q.w2), k = 12u;
+    uint32_t t = k == 0u ? q.w0 : k == 4u ? q.w1 : k == 8u ? q.w2 : q.w3;
+    for (; k < n; ++k, t >>= 8) dst[k] = (uint8_t)t;
+}
+__device__ __forceinline__ void copy_match(uint8_t *dst, uint32_t dd, uint32_t len) {
+    const uint8_t *src = dst - dd;
+    if (dd >= 16u || dd >= len) {  // a 16-byte group never reads what it writes
+        for (uint32_t k = 0; k < len; k += 16u) {
+            const Quad q = load_quad(src + k);
+            store_quad(dst + k, q, len - k < 16u ? len - k : 16u);
+        }
+        return;
+    }
+    // short period (dd < 16, dd < len): the output is the last dd bytes repeated
+    const uint64_t lo = (uint64_t)ld_u32(src) | ((uint64_t)ld_u32(src + 4) << 32);
+    const uint64_t hi = (uint64_t)ld_u32(src + 8) | ((uint64_t)ld_u32(src + 12) << 32);
+    if (dd == 1u) {
+        const uint32_t w = ((uint32_t)lo & 0xffu) * 0x01010101u;
+        uint32_t k = 0;
+        for (; k + 4u <= len; k += 4u) st_u32(dst + k, w);
+        for (; k < len; ++k) dst[k] = (uint8_t)w;
+        return;
+    }
+    uint32_t idx = 0;
+    for (uint32_t k = 0; k < len; ++k) {
+        dst[k] = (uint8_t)(idx < 8u ? lo >> (8u * idx) : hi >> (8u * (idx - 8u)));
+        if (++idx == dd) idx = 0;
+    }
+}
+
+// ---- bit cursor over the staged compressed dwords (LDS); positions are relative to stage bit 0
+struct SegBits {
+    const uint32_t *st;
+    uint32_t lo, hi, nxt, wi, pos;
+    __device__ __forceinline__ void init(const uint32_t *stage, uint32_t p) {
+        st = stage;
+        pos = p;
+        wi = p >> 5;
+        lo = st[wi];
+        hi = st[wi + 1];
+        nxt = st[wi + 2];
+    }
+    __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, pos & 31u); }  // >= 33 valid bits behind pos
+    __device__ __forceinline__ void consume(uint32_t n) {  // n < 32
+        const uint32_t np = pos + n;
+        if ((np ^ pos) & ~31u) {
+            lo = hi;
+            hi = nxt;
+            ++wi;
+            nxt = st[wi + 2];  // consumed two refills later
+        }
+        pos = np;
+    }
+};
+
+// canonical decode of the code at the cursor (first stream bit = top of v15): {length, sorted index} or 0 length
+template <int T>
+__device__ __forceinline__ uint32_t canon_entry(const WgLds<T> &L, int tbl, uint32_t v15, uint32_t from_len) {
+    uint32_t len = from_len;
+    for (; len <= 15u; ++len)
+        if (v15 < L.limit[tbl][len]) break;
+    if (len > 15u) return 0u;
+    const uint32_t idx = L.base[tbl][len] + (v15 >> (15u - len));
+    if (tbl == 0) return idx < (uint32_t)kMaxLit ? ll_entry(L.sorted[idx], len) : 0u;
+    return idx < (uint32_t)kMaxDist ? dist_entry(L.sorted[kMaxLit + idx], len) : 0u;
+}
+
+// Decodes the symbols that START in [start, seg_end) of one lane's segment.  MODE 0: counts only.  MODE 1 (commit):
+// literals go to out[o...] and every byte gets its root (r0 = first output byte of the round).  MODE 2 (a lone lane
+// whose output exceeds the round's root array): literals and matches go straight to the output, in order.
+// Returns the position behind the last decoded symbol (| kStopped / kStopEob).  `bad` collects INQ_INFLATE_* bits.
+template <int T, int MODE>
+__device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, uint32_t seg_end, uint32_t &nbytes, uint8_t *out, uint32_t o,
+                                                   uint32_t r0, uint32_t &bad) {
+    SegBits b;
+    b.init(L.stage, start);
+    uint32_t nb = 0, stop = 0;
+    while (b.pos < seg_end) {
+        const uint32_t bits = b.peek();
+        uint32_t e = L.lut_ll[bits & ((1u << kLitBits) - 1u)];
+        if (e == kLongEntry) e = canon_entry<T>(L, 0, __brev(bits) >> 17, kLitBits + 1);
+        const uint32_t n = e & 15u;
+        if (n == 0u) {
+            stop = kStopped;
+            break;
+        }
+        const uint32_t type = (e >> 4) & 3u;
+        if (type == E_LIT) {
+            b.consume(n);
+            if (MODE) out[o + nb] = (uint8_t)(e >> 16);
+            if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(o + nb - r0 + 32768u);
+            ++nb;
+            continue;
+        }
+        if (type == E_EOB) {
+            b.consume(n);
+            stop = kStopped | kStopEob;
+            break;
+        }
+        const uint32_t xb = (e >> 8) & 15u;
+        const uint32_t len = (e >> 16) + ((bits >> n) & ((1u << xb) - 1u));
+        b.consume(n + xb);
+        const uint32_t dbits = b.peek();
+        uint32_t d = L.lut_d[dbits & ((1u << kDistBits) - 1u)];
+        if (d == kLongEntry) d = canon_entry<T>(L, 1, __brev(dbits) >> 17, kDistBits + 1);
+        const uint32_t dn = d & 15u;
+        if (dn == 0u) {
+            stop = kStopped;
+            break;
+        }
+        const uint32_t dxb = (d >> 8) & 15u;
+        const uint32_t dist = (d >> 16) + ((dbits >> dn) & ((1u << dxb) - 1u));
+        b.consume(dn + dxb);
+        if (MODE) {
+            if (dist > o + nb) {
+                bad |= INQ_INFLATE_BAD_DISTANCE;
+                stop = kStopped;
+                break;
+            }
+            if (MODE == 1) {
+                // the lane's own bytes are rooted already (it walks them in order; LDS operations of a wave execute in
+                // order); a source in front of the lane's stretch stays a pointer for the jumping sweeps
+                uint32_t p = o + nb - r0;               // relative to the round
+                const uint32_t own = o - r0;
+                uint32_t k = 0;
+                const int32_t sp0 = (int32_t)(p - dist);  // may lie in front of the round (negative)
+                if (sp0 + (int32_t)len <= (int32_t)own) {
+                    // the whole source lies in front of this lane's stretch: the roots are consecutive pointers
+                    const uint32_t v = (uint32_t)(sp0 + 32768);
+                    for (; k + 4u <= len; k += 4u) {
+                        const uint32_t a = (v + k) | ((v + k + 1u) << 16), b2 = (v + k + 2u) | ((v + k + 3u) << 16);
+                        const uint64_t w = (uint64_t)a | ((uint64_t)b2 << 32);
+                        __builtin_memcpy(&L.root[p + k], &w, 8);
+                    }
+                    for (; k < len; ++k) L.root[p + k] = (uint16_t)(v + k);
+                } else if (sp0 >= (int32_t)own && dist >= 4u) {
+                    // the whole source lies in the lane's own stretch, already rooted: copy roots four at a time
+                    // (a group never reads what it writes; later groups may read what earlier ones wrote: LDS is in order)
+                    for (; k + 4u <= len; k += 4u) {
+                        uint64_t w;
+                        __builtin_memcpy(&w, &L.root[(uint32_t)sp0 + k], 8);
+                        __builtin_memcpy(&L.root[p + k], &w, 8);
+                    }
+                    for (; k < len; ++k) L.root[p + k] = L.root[(uint32_t)sp0 + k];
+                } else {
+                    for (; k < len; ++k) {
+                        const int32_t sp = sp0 + (int32_t)k;
+                        L.root[p + k] = sp >= (int32_t)own ? L.root[(uint32_t)sp] : (uint16_t)(sp + 32768);
+                    }
+                }
+            } else {
+                copy_match(out + o + nb, dist, len);
+            }
+        }
+        nb += len;
+    }
+    nbytes = nb;
+    return b.pos | stop;
+}
+
+// ---- workgroup-wide helpers (T lanes, T / 64 waves); every lane must call them
+template <int T>
+__device__ __forceinline__ uint32_t wg_min(uint32_t v, uint32_t *red) {
+    for (int off = 32; off; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off);
+        v = o < v ? o : v;
+    }
+    if (T == 64) return v;
+    __syncthreads();  // red[] free again
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t r = red[0];
+    for (int w = 1; w < T / 64; ++w) r = red[w] < r ? red[w] : r;
+    return r;
+}
+// exclusive prefix sums of two values at once; totals through tot_a / tot_b
+template <int T>
+__device__ __forceinline__ void wg_scan2(uint32_t a, uint32_t b, uint32_t &ex_a, uint32_t &ex_b, uint32_t &tot_a, uint32_t &tot_b,
+                                         uint32_t *red, uint32_t *red2) {
+    const uint32_t ia = wave_inclusive_scan_u32(a), ib = wave_inclusive_scan_u32(b);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 63u) red[threadIdx.x >> 6] = ia, red2[threadIdx.x >> 6] = ib;
+    __syncthreads();
+    uint32_t ca = 0, cb = 0, ta = 0, tb = 0;
+    for (int w = 0; w < T / 64; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) ca += red[w], cb += red2[w];
+        ta += red[w];
+        tb += red2[w];
+    }
+    ex_a = ca + ia - a;
+    ex_b = cb + ib - b;
+    tot_a = ta;
+    tot_b = tb;
+}
+
+// ---- header of a dynamic block (RFC 1951 3.2.7) from the staged bits, in three steps: lane 0 reads the counts and the
+// code-length code's lengths; lanes 0..18 build that code's 7-bit decode table (one symbol each); lane 0 decodes the
+// literal/length and distance code lengths through it into L.lens.
+template <int T>
+__device__ uint32_t header_counts(WgLds<T> &L, SegBits &b) {  // lane 0
+    const uint32_t bits = b.peek();
+    const uint32_t hlit = (bits & 31u) + 257u, hdist = ((bits >> 5) & 31u) + 1u, hclen = ((bits >> 10) & 15u) + 4u;
+    b.consume(14u);
+    if (hlit > 286u || hdist > 30u) return INQ_INFLATE_BAD_HEADER;  // zlib: "too many length or distance symbols"
+    const uint64_t order = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
+                           5ull << 45 | 11ull << 50 | 4ull << 55;
+    const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+    for (int i = 0; i < 19; ++i) L.cl_len[i] = 0;
+    for (uint32_t i = 0; i < hclen; ++i) {
+        const uint32_t sy = i < 12u ? (uint32_t)(order >> (5u * i)) & 31u : (uint32_t)(order_hi >> (5u * (i - 12u))) & 31u;
+        L.cl_len[sy] = (uint8_t)(b.peek() & 7u);
+        b.consume(3u);
+    }
+    L.hlit = hlit;
+    L.hdist = hdist;
+    return 0u;
+}
+
+template <int T>
+__device__ void header_cl_table(WgLds<T> &L, int tid) {  // lanes 0..18; cl_lut zero-filled by the caller
+    const uint32_t n = L.cl_len[tid];
+    uint64_t cnt = 0;  // 5 bits per length
+    uint32_t rank = 0;
+    for (int t = 0; t < 19; ++t) {
+        const uint32_t l = L.cl_len[t];
+        cnt += 1ull << (5u * l);
+        rank += (l == n && t < tid) ? 1u : 0u;
+    }
+    if (tid == 0) {  // zlib: an over-subscribed or incomplete code-length code is an error
+        int left = 1;
+        for (int len = 1; len <= 7; ++len) {
+            left = (left << 1) - (int)((cnt >> (5 * len)) & 31u);
+            if (left < 0) break;
+        }
+        if (left != 0) atomicOr(&L.status, (uint32_t)INQ_INFLATE_BAD_HEADER);
+    }
+    if (n == 0u) return;
+    uint32_t code = 0;
+    for (uint32_t len = 1; len < n; ++len) code = (code + (uint32_t)((cnt >> (5u * len)) & 31u)) << 1;
+    code += rank;
+    if (code >> n) return;  // over-subscribed: reported by lane 0
+    const uint32_t rev = __brev(code) >> (32u - n);
+    for (uint32_t k = 0; k < (1u << (7u - n)); ++k) L.cl_lut[rev | (k << n)] = (uint8_t)((uint32_t)tid | (n << 5));
+}
+
+template <int T>
+__device__ uint32_t header_lengths(WgLds<T> &L, SegBits &b, uint32_t limit_bits) {  // lane 0
+    const uint32_t hlit = L.hlit, total = L.hlit + L.hdist;
+    uint32_t idx = 0, prev = 0;
+    while (idx < total) {
+        if (b.pos > limit_bits) return INQ_INFLATE_INPUT_OVERRUN;
+        const uint32_t bits = b.peek();
+        const uint32_t e = L.cl_lut[bits & 127u];
+        const uint32_t n = e >> 5, sy = e & 31u;
+        if (n == 0u) return INQ_INFLATE_BAD_CODE;
+        uint32_t len, rep;
+        if (sy < 16u) {
+            len = sy, rep = 1u;
+            b.consume(n);
+        } else if (sy == 16u) {
+            if (idx == 0u) return INQ_INFLATE_BAD_HEADER;
+            len = prev, rep = 3u + ((bits >> n) & 3u);
+            b.consume(n + 2u);
+        } else if (sy == 17u) {
+            len = 0u, rep = 3u + ((bits >> n) & 7u);
+            b.consume(n + 3u);
+        } else {
+            len = 0u, rep = 11u + ((bits >> n) & 127u);
+            b.consume(n + 7u);
+        }
+        if (idx + rep > total) return INQ_INFLATE_BAD_HEADER;
+        prev = len;
+        if (len)  // literal/length lengths at lens[0 .. hlit), distance lengths at lens[kMaxLit .. kMaxLit + hdist); zero-filled before
+            for (uint32_t r = 0; r < rep; ++r) L.lens[idx + r < hlit ? idx + r : kMaxLit + (idx + r - hlit)] = (uint8_t)len;
+        idx += rep;
+    }
+    if (L.lens[256] == 0) return INQ_INFLATE_BAD_HEADER;  // zlib: "missing end-of-block"
+    return 0u;
+}
+
+// ---- code construction by the whole workgroup from L.lens (zeroed beyond hlit / hdist)
+template <int T>
+__device__ void build_tables(WgLds<T> &L, int tid) {
+    if (tid < 32) L.cnt[tid >> 4][tid & 15] = 0u;
+    __syncthreads();
+    for (int s = tid; s < kMaxLit + kMaxDist; s += T) {
+        const uint32_t n = L.lens[s];
+        if (n) atomicAdd(&L.cnt[s >= kMaxLit][n], 1u);
+    }
+    __syncthreads();
+    if (tid < 2) {  // limits, bases, insertion slots; zlib's inflate_table rejects over-subscribed sets and
+        const int tbl = tid;  // incomplete ones with any code longer than one bit
+        int left = 1, maxlen = 0;
+        uint32_t off = 0, first = 0;
+        bool ok = true;
+        L.limit[tbl][0] = 0u;
+        for (int len = 1; len <= 15; ++len) {
+            const uint32_t n = L.cnt[tbl][len];
+            left = (left << 1) - (int)n;
+            ok &= left >= 0;
+            if (n) maxlen = len;
+            L.limit[tbl][len] = ok ? (first + n) << (15 - len) : 0u;
+            L.base[tbl][len] = off - first;
+            L.run[tbl][len] = off;
+            off += n;
+            first = (first + n) << 1;
+        }
+        if (!(ok && (left == 0 || maxlen <= 1))) atomicOr(&L.status, (uint32_t)INQ_INFLATE_BAD_HEADER);
+        if (!ok)
+            for (int len = 1; len <= 15; ++len) L.limit[tbl][len] = 0u;  // nothing decodes
+    }
+    __syncthreads();
+    // rank inside a length by ballot, 64 symbols at a time: wave 0 sorts the literal/length symbols, the last wave
+    // the distance symbols (the same wave when T == 64)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int tbl = 0; tbl < 2; ++tbl) {
+        if (wave != (tbl ? T / 64 - 1 : 0)) continue;
+        const int nsym = tbl ? kMaxDist : kMaxLit, sbase = tbl ? kMaxLit : 0;
+        for (int c0 = 0; c0 < nsym; c0 += 64) {
+            const int s = c0 + lane;
+            const uint32_t n = s < nsym ? L.lens[sbase + s] : 0u;
+            for (uint32_t len = 1; len <= 15u; ++len) {
+                const uint64_t m = ballot64(n == len);
+                if (m == 0ull) continue;
+                const uint32_t r0 = L.run[tbl][len];
+                if (n == len) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    L.sorted[sbase + r0 + rank] = (uint16_t)s;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) L.run[tbl][len] = r0 + (uint32_t)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < (1 << kLitBits); e += T) {
+        const uint32_t v15 = __brev((uint32_t)e) >> 17;
+        L.lut_ll[e] = v15 < L.limit[0][kLitBits] ? canon_entry<T>(L, 0, v15, 1u) : (v15 < L.limit[0][15] ? kLongEntry : 0u);
+    }
+    for (int e = tid; e < (1 << kDistBits); e += T) {
+        const uint32_t v15 = __brev((uint32_t)e) >> 17;
+        L.lut_d[e] = v15 < L.limit[1][kDistBits] ? canon_entry<T>(L, 1, v15, 1u) : (v15 < L.limit[1][15] ? kLongEntry : 0u);
+    }
+    __syncthreads();
+}
+
+template <int T>
+__device__ __forceinline__ void stage_load(WgLds<T> &L, const uint8_t *payload, const uint8_t *hard, uint32_t base_dw, int tid) {
+    for (int k = tid; k < WgLds<T>::kStage; k += T) {
+        const uint8_t *p = payload + 4ull * ((uint64_t)base_dw + (uint64_t)k);
+        L.stage[k] = ld_u32(p < hard ? p : hard);  // behind the payload: only a corrupt stream consumes it
+    }
+}
+
+}  // namespace
+
+template <int T>
+__global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
+    __shared__ WgLds<T> L;
+    const int tid = (int)threadIdx.x;
+    const uint64_t bi = blockIdx.x;
+    const inq_bgzf_block_t blk = a.blocks[bi];
+    // host-checked, re-checked: the block's extents lie inside the buffers
+    const bool extents_ok = !(blk.comp_off > a.comp_bytes || (uint64_t)blk.comp_len > a.comp_bytes - blk.comp_off || blk.out_off > a.out_bytes ||
+                              (uint64_t)blk.isize > a.out_bytes - blk.out_off || blk.isize > 65536u);
+    const uint8_t *payload = a.comp + blk.comp_off;
+    const uint8_t *hard = a.comp + a.comp_bytes + 60;  // the buffer carries 64 bytes of padding
+    uint8_t *out = a.out + blk.out_off;
+    const uint32_t isize = blk.isize;
+    const uint32_t payload_bits = blk.comp_len * 8u;
+    if (tid == 0) {
+        L.P = 0u;
+        L.out = 0u;
+        L.status = extents_ok ? 0u : (uint32_t)INQ_INFLATE_BAD_HEADER;
+        L.last = 0u;
+    }
+#ifdef INQ_INFLATE_DEBUG_ENV
+    // dev-time probe (debug_flags & 8): per block {deflate blocks, rounds, count passes, match sweeps, kilo-cycles in
+    // header+tables, counting, commit, matches} into block_status[8 * bi ..] for bi < n_blocks / 8
+    uint32_t dbg_n[4] = {0, 0, 0, 0};
+    uint64_t dbg_c[4] = {0, 0, 0, 0}, dbg_t = clock64();
+#define DBG_N(i) ++dbg_n[i]
+#define DBG_LAP(i) { const uint64_t now_ = clock64(); dbg_c[i] += now_ - dbg_t; dbg_t = now_; }
+#else
+#define DBG_N(i)
+#define DBG_LAP(i)
+#endif
+    __syncthreads();
+    while (L.status == 0u) {
+        // ================= block header
+        const uint32_t P0 = L.P;
+        __syncthreads();  // everyone has read P (and the loop condition) before lane 0 moves on
+        stage_load<T>(L, payload, hard, P0 >> 5, tid);
+        for (int s = tid; s < kMaxLit + kMaxDist; s += T) L.lens[s] = 0;
+        __syncthreads();
+        SegBits hb;
+        if (tid == 0) {
+            hb.init(L.stage, P0 & 31u);
+            uint32_t st = 0;
+            if (P0 + 3u > payload_bits) st = INQ_INFLATE_INPUT_OVERRUN;
+            else {
+                const uint32_t bits = hb.peek();
+                hb.consume(3u);
+                L.last = bits & 1u;
+                const uint32_t type = (bits >> 1) & 3u;
+                L.type = type;
+                if (type == 3u) st = INQ_INFLATE_BAD_HEADER;
+                else if (type == 2u) st = header_counts<T>(L, hb);
+                else if (type == 1u) {
+                    L.hlit = 288u;
+                    L.hdist = 32u;
+                }
+            }
+            L.P = (P0 & ~31u) + hb.pos;
+            if (st) L.status = st;
+        }
+        for (int i = tid; i < 128; i += T) L.cl_lut[i] = 0;
+        __syncthreads();
+        if (L.status) break;
+        if (L.type == 2u) {
+            if (tid < 19) header_cl_table<T>(L, tid);
+            __syncthreads();
+            if (tid == 0 && L.status == 0u) {
+                const uint32_t st = header_lengths<T>(L, hb, (uint32_t)(WgLds<T>::kStage - 4) * 32u);
+                L.P = (P0 & ~31u) + hb.pos;
+                if (st) L.status = st;
+            }
+            __syncthreads();
+            if (L.status) break;
+        }
+        const uint32_t type = L.type;
+        if (type == 0u) {  // stored: byte-align, LEN, NLEN, bytes
+            const uint32_t q = (L.P + 7u) >> 3;  // byte offset of LEN
+            const uint32_t o0 = L.out;
+            uint32_t st = 0, len = 0;
+            if ((uint64_t)q + 4u > blk.comp_len) st = INQ_INFLATE_INPUT_OVERRUN;
+            else {
+                const uint32_t w = ld_u32(payload + q);
+                len = w & 0xffffu;
+                if ((len ^ (w >> 16)) != 0xffffu) st = INQ_INFLATE_BAD_STORED;
+                else if ((uint64_t)q + 4u + len > blk.comp_len) st = INQ_INFLATE_INPUT_OVERRUN;
+                else if (len > isize - o0) st = INQ_INFLATE_OUTPUT_SIZE;
+            }
+            __syncthreads();
+            if (st == 0u) {
+                for (uint32_t k = (uint32_t)tid; k < len; k += T) out[o0 + k] = payload[q + 4u + k];
+            }
+            if (tid == 0) {
+                if (st) L.status = st;
+                L.P = (q + 4u + len) * 8u;
+                L.out = o0 + len;
+            }
+            __syncthreads();
+            if (L.status || L.last) break;
+            continue;
+        }
+        if (type == 1u) {  // RFC 1951 3.2.6
+            for (int s = tid; s < kMaxLit; s += T) L.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+            // 32 five-bit distance codes make the set complete; 30 and 31 never appear in valid data (dist_entry: not a code)
+            for (int s = tid; s < 32; s += T) L.lens[kMaxLit + s] = 5;
+            __syncthreads();
+        }
+        build_tables<T>(L, tid);
+        DBG_N(0);
+        DBG_LAP(0);
+        if (L.status) break;
+
+        // ================= rounds: T segments of 256 compressed bits each
+        for (;;) {
+            const uint32_t P = L.P, out0 = L.out;
+            const uint32_t base_dw = P >> 5;
+            __syncthreads();
+            stage_load<T>(L, payload, hard, base_dw, tid);
+            __syncthreads();
+            const uint32_t seg_end = ((uint32_t)tid + 1u) * kSegBits;
+            uint32_t start = tid == 0 ? (P & 31u) : (uint32_t)tid * kSegBits;
+            uint32_t nbytes = 0, bad = 0;
+            uint32_t end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad);
+            DBG_N(1);
+            DBG_N(2);
+            // ---- until every chain starts where its left neighbour's ended (lanes behind the first stop do not matter)
+            uint32_t ncommit = T;
+            for (int it = 0; it <= T; ++it) {
+                L.end_bit[tid] = end;
+                __syncthreads();
+                const uint32_t left = tid == 0 ? start : L.end_bit[tid - 1];
+                const bool left_stopped = tid != 0 && (left & kStopped);
+                const bool mismatch = !left_stopped && (left & 0x3fffffffu) != start;
+                // first lane that has to decode again, first lane that stopped
+                const uint32_t first_bad = wg_min<T>(mismatch ? (uint32_t)tid : 0xffffu, L.red);
+                const uint32_t first_stop = wg_min<T>((end & kStopped) ? (uint32_t)tid : 0xffffu, L.red2);
+                if (first_bad == 0xffffu || first_stop < first_bad) {
+                    ncommit = first_stop == 0xffffu ? (uint32_t)T : first_stop + 1u;
+                    break;
+                }
+                if (mismatch) {
+                    start = left & 0x3fffffffu;
+                    end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad);
+                }
+                DBG_N(2);
+                __syncthreads();  // end_bit[] read by everyone before it is rewritten
+            }
+            // ---- places in the output; the round is cut at the first lane whose bytes would leave the root array
+            if ((uint32_t)tid >= ncommit) nbytes = 0u;
+            uint32_t off_b, tot_b, dummy0, dummy1;
+            wg_scan2<T>(nbytes, 0u, off_b, dummy0, tot_b, dummy1, L.red, L.red2);
+            bool lone = false;  // lane 0 alone exceeds the array: it writes its literals and matches in order by itself
+            if (tot_b > (uint32_t)WgLds<T>::kRoundCap) {
+                const uint32_t keep = wg_min<T>(off_b + nbytes > (uint32_t)WgLds<T>::kRoundCap ? (uint32_t)tid : 0xffffu, L.red);
+                lone = keep == 0u;
+                ncommit = lone ? 1u : (keep < ncommit ? keep : ncommit);
+                if ((uint32_t)tid >= ncommit) nbytes = 0u;
+                wg_scan2<T>(nbytes, 0u, off_b, dummy0, tot_b, dummy1, L.red, L.red2);
+            }
+            const bool committed = (uint32_t)tid < ncommit;
+            DBG_LAP(1);
+            if (tot_b > isize - out0) bad |= INQ_INFLATE_OUTPUT_SIZE;  // uniform
+            // ---- commit: literals to the output, roots of all bytes to LDS
+            if (committed && bad == 0u) {
+                uint32_t nb2;
+                if (lone) (void)decode_segment<T, 2>(L, start, seg_end, nb2, out, out0 + off_b, out0, bad);
+                else (void)decode_segment<T, 1>(L, start, seg_end, nb2, out, out0 + off_b, out0, bad);
+            }
+            if (committed && tid == (int)ncommit - 1) {  // the last committed chain: where the next round starts, and why this one ended
+                const uint32_t stop = end & (kStopped | kStopEob);
+                if (stop == kStopped) bad |= INQ_INFLATE_BAD_CODE;
+                L.P = (base_dw << 5) + (end & 0x3fffffffu);
+                L.eob = stop == (kStopped | kStopEob);
+                L.out = out0 + tot_b;
+            }
+            if (bad) atomicOr(&L.status, bad);
+            __syncthreads();  // literals (global) and roots (LDS) are visible to the workgroup
+            DBG_LAP(2);
+            if (L.status) break;
+            // ---- matches: shorten every chain to its root by pointer jumping, then one gather
+            if (!lone) {
+                // four consecutive bytes per lane and step (one 8-byte LDS access for their roots)
+                const uint32_t n4 = (tot_b + 3u) >> 2;
+                for (int sweep = 0; sweep < 16; ++sweep) {  // chains hop to an earlier lane's stretch each time: <= log2(T) + 1 sweeps
+                    if (tid == 0) L.flag = 0u;
+                    __syncthreads();
+                    bool changed = false;
+                    for (uint32_t g = (uint32_t)tid; g < n4; g += T) {
+                        uint64_t w;
+                        __builtin_memcpy(&w, &L.root[4u * g], 8);  // the array is a multiple of 4 long
+                        const uint32_t r0_ = (uint32_t)w & 0xffffu, r1_ = (uint32_t)(w >> 16) & 0xffffu, r2_ = (uint32_t)(w >> 32) & 0xffffu,
+                                       r3_ = (uint32_t)(w >> 48);
+                        // a literal's root is itself, so following it changes nothing; bytes behind tot_b hold stale roots of
+                        // an earlier round: following them is harmless (bounded index), and nobody reads them
+                        const uint32_t a0 = r0_ >= 32768u ? L.root[(r0_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r0_;
+                        const uint32_t a1 = r1_ >= 32768u ? L.root[(r1_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r1_;
+                        const uint32_t a2 = r2_ >= 32768u ? L.root[(r2_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r2_;
+                        const uint32_t a3 = r3_ >= 32768u ? L.root[(r3_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r3_;
+                        const uint64_t nw = (uint64_t)a0 | ((uint64_t)a1 << 16) | ((uint64_t)a2 << 32) | ((uint64_t)a3 << 48);
+                        if (nw != w) {
+                            __builtin_memcpy(&L.root[4u * g], &nw, 8);
+                            changed = true;
+                        }
+                    }
+                    if (changed) L.flag = 1u;
+                    DBG_N(3);
+                    __syncthreads();
+                    if (L.flag == 0u) break;
+                    __syncthreads();
+                }
+                const uint8_t *from = out + out0 - 32768;  // root r lives at from[r]; never dereferenced in front of the block (distance check)
+                uint8_t *dstb = out + out0;
+                for (uint32_t g = (uint32_t)tid; g < n4; g += T) {
+                    const uint32_t q = 4u * g;
+                    uint64_t w;
+                    __builtin_memcpy(&w, &L.root[q], 8);
+                    const uint32_t r0_ = (uint32_t)w & 0xffffu, r1_ = (uint32_t)(w >> 16) & 0xffffu, r2_ = (uint32_t)(w >> 32) & 0xffffu,
+                                   r3_ = (uint32_t)(w >> 48);
+                    const uint32_t self = q + 32768u;
+                    if (q + 4u <= tot_b && r1_ == r0_ + 1u && r2_ == r0_ + 2u && r3_ == r0_ + 3u) {
+                        if (r0_ != self) st_u32(dstb + q, ld_u32(from + r0_));  // four bytes of one match, or four literals (nothing to do)
+                    } else {
+                        if (q < tot_b && r0_ != self) dstb[q] = from[r0_];
+                        if (q + 1u < tot_b && r1_ != self + 1u) dstb[q + 1u] = from[r1_];
+                        if (q + 2u < tot_b && r2_ != self + 2u) dstb[q + 2u] = from[r2_];
+                        if (q + 3u < tot_b && r3_ != self + 3u) dstb[q + 3u] = from[r3_];
+                    }
+                }
+            }
+            __syncthreads();
+            DBG_LAP(3);
+            if (L.eob) break;
+            if (L.P > payload_bits) {  // a round that ran off the payload without meeting end-of-block
+                if (tid == 0) L.status = INQ_INFLATE_INPUT_OVERRUN;
+                __syncthreads();
+                break;
+            }
+        }
+        if (L.status || L.last) break;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t st = L.status;
+        if (st == 0u) {
+            if (L.out != isize) st = INQ_INFLATE_OUTPUT_SIZE;
+            else if (L.P > payload_bits) st = INQ_INFLATE_INPUT_OVERRUN;
+        }
+        if (a.block_status) a.block_status[bi] = st;
+        if (st) atomicOr(a.err, st);
+    }
+#ifdef INQ_INFLATE_DEBUG_ENV
+    if ((a.debug_flags & 8u) && a.block_status) {
+        __syncthreads();
+        if (tid == 0 && bi < a.n_blocks / 8)
+            for (int k = 0; k < 4; ++k) a.block_status[8 * bi + k] = dbg_n[k], a.block_status[8 * bi + 4 + k] = (uint32_t)(dbg_c[k] >> 10);
+    }
+#endif
+}
+
+void launch_bgzf_inflate_wg(const InflateArgs &a, hipStream_t s) {
+    if (!a.n_blocks) return;
+#ifndef INQ_WG_T
+#define INQ_WG_T 128
+#endif
+    constexpr int T = INQ_WG_T;
+    hipLaunchKernelGGL((bgzf_inflate_wg_kernel<T>), dim3((uint32_t)a.n_blocks), dim3(T), 0, s, a);
+}
+
+}  // namespace inq

@@ -431,6 +431,11 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
         c->verify_crc = value != 0;
         return INQ_OK;
     }
+    if (std::strcmp(key, "inflate_algo") == 0) {
+        if (value < 0 || value > 1) return INQ_ERR_ARG;
+        c->inflate_algo = (uint32_t)value;
+        return INQ_OK;
+    }
     if (std::strcmp(key, "nt_loads") == 0) {
         c->nt_loads = value < 0 ? -1 : (value != 0);
         return INQ_OK;

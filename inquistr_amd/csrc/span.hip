@@ -139,10 +139,11 @@ int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t c
     ia.block_status = want_block_status ? (uint32_t *)S->block_status.p : nullptr;
     ia.err = &S->d_st->inflate;
     ia.verify_crc = c->verify_crc ? 1u : 0u;
-    {
-        const char *dbg = std::getenv("INQ_INFLATE_DEBUG");
-        ia.debug_flags = dbg ? (uint32_t)std::atoi(dbg) : 0u;
-    }
+    ia.debug_flags = 0u;
+#ifdef INQ_INFLATE_DEBUG_ENV  // timing experiments only (drops stores: wrong bytes), never in the shipped library
+    if (const char *dbg = std::getenv("INQ_INFLATE_DEBUG")) ia.debug_flags = (uint32_t)std::atoi(dbg);
+#endif
+    ia.algo = c->inflate_algo;
     launch_bgzf_inflate(ia, s);
     HIP_TRY(c, hipGetLastError());
     return INQ_OK;

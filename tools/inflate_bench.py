@@ -43,6 +43,10 @@ def main():
     alt = os.environ.get("INQ_LIB")  # another build of libinquistr_hip.so (A/B)
     ctx = hipcall.Context(0, lib=hipcall.load(alt)) if alt else hipcall.Context(0)
     out_bytes = int(blocks["isize"].sum())
+    if os.environ.get("ALGO"):
+        ctx.set_option("inflate_algo", int(os.environ["ALGO"]))
+    if os.environ.get("NOCRC"):
+        ctx.set_option("verify_crc", 0)
     for rep in range(3):
         t = time.perf_counter()
         rc, out, st = ctx.bgzf_inflate(comp, blocks, check=False)
@@ -53,6 +57,11 @@ def main():
     import os
 
     if os.environ.get("INQ_INFLATE_DEBUG"):
+        if int(os.environ["INQ_INFLATE_DEBUG"]) & 8:
+            v = st[: len(st) // 8 * 8].reshape(-1, 8).astype(np.float64)
+            names = ["deflate blocks", "rounds", "count passes", "match sweeps", "kcyc header+tables", "kcyc counting", "kcyc commit", "kcyc matches"]
+            for k, nm in enumerate(names):
+                print(f"  {nm}: mean {v[:, k].mean():.1f} median {np.median(v[:, k]):.1f} max {v[:, k].max():.0f}")
         if int(os.environ["INQ_INFLATE_DEBUG"]) & 4:
             kc = st.astype(np.float64)
             print(f"shader kilo-cycles per lane: median {np.median(kc):.0f}, max {kc.max():.0f}; with the kernel time above that is "
