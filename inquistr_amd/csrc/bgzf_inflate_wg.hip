@@ -74,7 +74,7 @@ template <int T>
 struct WgLds {
     static constexpr int kStage = 8 * T + 8;        // dwords: T segments of 32 bytes + look-ahead
 #ifndef INQ_WG_CAP
-#define INQ_WG_CAP 8192
+#define INQ_WG_CAP 4096
 #endif
     static constexpr int kRoundCap = INQ_WG_CAP;    // output bytes per round (rounds are cut at the lane that would exceed it)
     uint32_t lut_ll[1 << kLitBits];

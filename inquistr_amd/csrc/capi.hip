@@ -432,7 +432,7 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
         return INQ_OK;
     }
     if (std::strcmp(key, "inflate_algo") == 0) {
-        if (value < 0 || value > 1) return INQ_ERR_ARG;
+        if (value < 0 || value > 2) return INQ_ERR_ARG;
         c->inflate_algo = (uint32_t)value;
         return INQ_OK;
     }

@@ -19,7 +19,7 @@ struct InflateArgs {
     unsigned int *err;       // OR of the INQ_INFLATE_* bits of all blocks
     uint32_t debug_flags;    // timing experiments only: 1 = drop literal stores, 2 = drop match copies, 4 = block_status receives shader kilo-cycles
     uint32_t verify_crc;     // also check every block against the CRC32 of its trailer (comp holds whole blocks)
-    uint32_t algo;           // 0 = one workgroup per block (bgzf_inflate_wg.hip), 1 = one lane per block (bgzf_inflate.hip)
+    uint32_t algo;           // 0 = one workgroup per block (bgzf_inflate_wg.hip), 1 = one lane per block (bgzf_inflate.hip), 2 = by block count
 };
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s);
 void launch_bgzf_inflate_wg(const InflateArgs &a, hipStream_t s);  // the inflate alone, no CRC pass

@@ -12,9 +12,11 @@ from inquistr_amd import hipcall
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[0, 1], ids=["inflate_wg", "inflate_lane"])
+def ctx(request):
+    """Both inflate kernels (workgroup per block / lane per block) go through every test of this file."""
     c = hipcall.Context(0)
+    c.set_option("inflate_algo", request.param)
     yield c
     c.close()
 

@@ -9,7 +9,10 @@ ctx = hipcall.Context(0)
 ctx.set_option("inflate_algo", int(os.environ.get("ALGO", "0")))
 rng = random.Random(5)
 n_bad = 0
+only = os.environ.get("ONLY")
 for pi, data in enumerate(_payloads(rng)):
+    if only is not None and pi != int(only):
+        continue
     for level, strategy in [(0, 0), (1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (9, zlib.Z_FILTERED)]:
         d = data[:65000] if level == 0 and len(data) > 65000 else data
         try:

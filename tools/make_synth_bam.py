@@ -205,5 +205,10 @@ def write_native(workload: str, n_loci: int, prefix: str, level: int = 1, thread
 
 
 if __name__ == "__main__":
-    n = write(sys.argv[1], int(sys.argv[2]), sys.argv[3], seq=len(sys.argv) > 4 and sys.argv[4] == "seq")
+    if len(sys.argv) > 4 and sys.argv[4] == "native":  # native writer, workload generated on the GPU when there is one
+        import torch
+
+        n = write_native(sys.argv[1], int(sys.argv[2]), sys.argv[3], device=torch.device("cuda:0") if torch.cuda.is_available() else None)
+    else:
+        n = write(sys.argv[1], int(sys.argv[2]), sys.argv[3], seq=len(sys.argv) > 4 and sys.argv[4] == "seq")
     print(f"wrote {sys.argv[3]}.bam/.bai/.bed: {n} reads, {os.path.getsize(sys.argv[3] + '.bam') / 1e6:.1f} MB")

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/tools/make_synth_bam.py unphased100k $LOCI /tmp/front_prof > $OUT/gen.log 2>&1 || { tail $OUT/gen.log; exit 1; }
+python3 $ROOT/tools/make_synth_bam.py unphased100k $LOCI /tmp/front_prof native > $OUT/gen.log 2>&1 || { tail $OUT/gen.log; exit 1; }
 export INQ_FRONTEND=device
 export INQ_FAST_EXIT=0  # the CLI normally leaves through _Exit, which would skip the profiler's output
 CLI="$ROOT/inquistr_amd/lib/inquistr call /tmp/front_prof.bam -R /tmp/front_prof.bed -t 16 -u --sample-name S"
@@ -23,7 +23,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 for f in $(find $OUT/trace -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats.csv; done
 for d in pmc_fetch pmc_write pmc_sq; do
   f=$(find $OUT/$d -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && (head -1 $f; grep -E 'bgzf_|chain_kernel|record_parse|cigar_gather|join_kernel|scan_' $f) > $OUT/$d.csv
+  [ -n "$f" ] && (head -1 $f; grep -E 'bgzf_|inflate|chain_kernel|record_parse|cigar_gather|join_kernel|scan_' $f) > $OUT/$d.csv
 done
 ls -l /tmp/front_prof.bam > $OUT/bam_size.txt
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/device.inq $OUT/host.inq

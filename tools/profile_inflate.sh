@@ -12,7 +12,7 @@ run() {  # name, counters...
 import csv, sys, collections
 agg = collections.defaultdict(float); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
-    if "bgzf_inflate_kernel" in r["Kernel_Name"]:
+    if "bgzf_inflate" in r["Kernel_Name"]:
         agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 for k in sorted(agg): print(f"{k:28s} {agg[k] / max(n[k], 1):16.0f}  (mean of {n[k]} dispatches)")
 PY
