@@ -48,6 +48,18 @@ typedef struct inq_call_args {
  * for non-zero statuses is copied to errbuf (and printed to stderr by the CLI). */
 int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap);
 
+/* One process per GPU (inquistr_amd/call_dist.py; the reference's counterpart is the rayon loop over loci, src/call.rs:115-136,
+ * whose workers share nothing but the output Vec): the same command restricted to the targets target_index[0 .. n_index)
+ * (positions in the target list -r / -R give, in list order), rows as numbers instead of text: phase1[k], phase2[k] = the row
+ * of target target_index[k] (NaN where the reference prints NaN).  Nothing is written anywhere.  Same exit statuses. */
+int inq_genotype_repeats_rows(const inq_call_args_t *args, const uint32_t *target_index, uint64_t n_index, double *phase1, double *phase2,
+                              char *errbuf, size_t errcap);
+/* The work split for `world` such processes: order[0 .. *n_targets) = the targets in file order (contig of the BAM header,
+ * start, end), cuts[0 .. world] = cut points into order[] chosen so that every part needs about the same number of
+ * compressed BAM bytes (.bai linear index).  Part r = order[cuts[r] .. cuts[r + 1]).  No GPU involved. */
+int inq_host_partition(const inq_call_args_t *args, uint64_t world, uint32_t *order, uint64_t order_cap, uint64_t *cuts, uint64_t *n_targets,
+                       char *errbuf, size_t errcap);
+
 /* ---- BAM -> batch front end (no GPU involved) ---- */
 typedef struct inq_frontend inq_frontend_t;
 int inq_frontend_open(const inq_call_args_t *args, inq_frontend_t **out, char *errbuf, size_t errcap);

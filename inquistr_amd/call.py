@@ -22,6 +22,8 @@ CLI_PATH = os.path.join(_PKG, "lib", "inquistr")
 
 HOST_ABI_SYMBOLS = (
     "inq_genotype_repeats",
+    "inq_genotype_repeats_rows",
+    "inq_host_partition",
     "inq_combine",
     "inq_frontend_open",
     "inq_frontend_n_targets",
@@ -97,6 +99,10 @@ def load():
         vp = C.c_void_p
         L.inq_genotype_repeats.restype = C.c_int
         L.inq_genotype_repeats.argtypes = [C.POINTER(CallArgsC), C.c_int, C.c_char_p, C.c_size_t]
+        L.inq_genotype_repeats_rows.restype = C.c_int
+        L.inq_genotype_repeats_rows.argtypes = [C.POINTER(CallArgsC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.inq_host_partition.restype = C.c_int
+        L.inq_host_partition.argtypes = [C.POINTER(CallArgsC), C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         L.inq_combine.restype = C.c_int
         L.inq_combine.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
         L.inq_frontend_open.restype = C.c_int
@@ -180,6 +186,40 @@ def genotype_repeats(bamp: str, region: Optional[str], region_file: Optional[str
     rc = L.inq_genotype_repeats(C.byref(a), fd, err, len(err))
     if rc != 0:
         raise CallError(rc, err.value.decode(errors="replace"))
+
+
+def genotype_repeats_rows(bamp: str, region: Optional[str], region_file: Optional[str], target_index, minlen: int = 5, support: int = 3,
+                          threads: int = 1, unphased: bool = False, device: int = 0, frontend: Optional[str] = None):
+    """inq_genotype_repeats_rows: the rows (phase1, phase2 as f64 arrays) of the targets `target_index` points at."""
+    L = load()
+    idx = np.ascontiguousarray(target_index, dtype=np.uint32)
+    a = _args(bamp, region, region_file, minlen, support, threads, unphased, None, None, device, frontend)
+    p1 = np.full(len(idx), np.nan)
+    p2 = np.full(len(idx), np.nan)
+    err = C.create_string_buffer(2048)
+    rc = L.inq_genotype_repeats_rows(C.byref(a), idx.ctypes.data, len(idx), p1.ctypes.data, p2.ctypes.data, err, len(err))
+    if rc != 0:
+        raise CallError(rc, err.value.decode(errors="replace"))
+    return p1, p2
+
+
+def partition(bamp: str, region: Optional[str], region_file: Optional[str], world: int):
+    """inq_host_partition: (order, cuts) - the targets in file order and world + 1 cut points balanced by BAM bytes."""
+    L = load()
+    a = _args(bamp, region, region_file, 5, 3, 1, False, None, None)
+    err = C.create_string_buffer(2048)
+    n = C.c_uint64(0)
+    cuts = np.zeros(world + 1, dtype=np.uint64)
+    cap = 1 << 16
+    while True:
+        order = np.zeros(cap, dtype=np.uint32)
+        rc = L.inq_host_partition(C.byref(a), world, order.ctypes.data, cap, cuts.ctypes.data, C.byref(n), err, len(err))
+        if rc != 0 and n.value > cap:
+            cap = int(n.value)
+            continue
+        if rc != 0:
+            raise CallError(rc, err.value.decode(errors="replace"))
+        return order[: n.value].copy(), cuts.astype(np.int64)
 
 
 def combine(calls, out=None) -> None:

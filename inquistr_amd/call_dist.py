@@ -24,33 +24,20 @@ import numpy as np
 from . import call as hostcall
 
 
-def _cuts_by_file_bytes(bamp: str, sorted_targets, world: int) -> List[int]:
-    """world + 1 cut points into the sorted target list.  Cost of a target = compressed bytes between its
-    scan start and the next target's (same contig), capped so that one far-away locus does not own a whole
-    chromosome; falls back to equal counts when the index gives nothing."""
-    n = len(sorted_targets)
-    L = hostcall.load()
-    bai = bamp + ".bai" if os.path.exists(bamp + ".bai") else os.path.splitext(bamp)[0] + ".bai"
-    tid_of = {}
-    offs = np.zeros(n, dtype=np.float64)
-    for k, (chrom, start, _end) in enumerate(sorted_targets):
-        if chrom not in tid_of:
-            tid_of[chrom] = L.inq_host_bam_tid(os.fspath(bamp).encode(), chrom.encode())
-        offs[k] = L.inq_host_bai_file_offset(bai.encode(), tid_of[chrom], max(0, start - 10))
-    cost = np.ones(n, dtype=np.float64)
-    if n > 1 and offs.max() > 0:
-        d = np.diff(offs)
-        ok = d > 0
-        if ok.any():
-            cap = np.percentile(d[ok], 99) * 4 + 1
-            cost[:-1] += np.clip(np.where(ok, d, 0), 0, cap)
-            cost[-1] += np.median(d[ok])
-    csum = np.concatenate([[0.0], np.cumsum(cost)])
-    cuts = [0]
-    for r in range(1, world):
-        cuts.append(int(min(max(np.searchsorted(csum, csum[-1] * r / world, side="left"), cuts[-1]), n)))
-    cuts.append(n)
-    return cuts
+def _exchange_status(status: int, message: str, rank: int, world: int, group=None):
+    """Every rank learns whether any rank failed (and rank 0 the failing rank's message) BEFORE the row gather, so that a
+    data-dependent failure on one rank (a record the reference panics on, a HIP error, out of memory) ends the run on all
+    ranks with the same exit status instead of leaving the others waiting in the gather."""
+    import torch.distributed as dist
+
+    if world == 1:
+        return status, message, rank
+    got = [None] * world
+    dist.all_gather_object(got, (int(status), str(message)), group=group)
+    for r, (st, msg) in enumerate(got):
+        if st != 0:
+            return st, msg, r
+    return 0, "", -1
 
 
 def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: Optional[str], minlen: int = 5,
@@ -58,63 +45,68 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
                                  sample_name: Optional[str] = None, out=None, rank: int = 0, world: int = 1,
                                  device: int = 0, compute: Optional[Callable] = None, group=None,
                                  frontend: Optional[str] = None) -> None:
-    """Same arguments as call.genotype_repeats plus (rank, world).  Rank 0 writes header + rows."""
+    """Same arguments as call.genotype_repeats plus (rank, world).  Rank 0 writes header + rows.
+    Raises CallError (same status on every rank) if any rank fails."""
     import torch
     import torch.distributed as dist
 
-    # every rank parses and validates the full target list exactly like a single-process run would
-    fe_all = hostcall.FrontEnd(bamp, region=region, region_file=region_file, minlen=minlen, support=support,
-                               threads=1, unphased=unphased, sample_name=sample_name)
-    targets = fe_all.targets()
-    sample = fe_all.sample
-    fe_all.close()
-    n = len(targets)
-    # contiguous slices of the position-sorted list, cut so that every rank has about the same amount of
-    # BAM to read (the .bai linear index gives the file offset of every target; SURVEY.md §8e asks for shards
-    # balanced by work, not by locus count).  Every rank computes the same cuts.
-    order = sorted(range(n), key=lambda i: (targets[i][0], targets[i][1], i))
-    cuts = _cuts_by_file_bytes(bamp, [targets[i] for i in order], world)
-    lo, hi = cuts[rank], cuts[rank + 1]
+    # ---- the work split, computed ONCE (rank 0: BED + .bai through the C++ host library) and broadcast: contiguous slices of
+    # the targets in file order, cut so that every rank has about the same amount of BAM to read (SURVEY.md 8e)
+    plan = [None]
+    st, msg = 0, ""
+    if rank == 0:
+        try:
+            order, cuts = hostcall.partition(bamp, region, region_file, world)
+            plan = [(order, cuts)]
+        except hostcall.CallError as e:
+            st, msg = e.status, e.message
+    if world > 1:
+        head = [(st, msg, plan[0])]
+        dist.broadcast_object_list(head, src=0, group=group)
+        st, msg, plan[0] = head[0]
+    if st != 0:
+        raise hostcall.CallError(st, msg)
+    order, cuts = plan[0]
+    n = len(order)
+    lo, hi = int(cuts[rank]), int(cuts[rank + 1])
     mine = order[lo:hi]
+    # ---- this rank's rows
     p1 = np.full(len(mine), np.nan)
     p2 = np.full(len(mine), np.nan)
-    if mine:
-        with tempfile.NamedTemporaryFile("w", suffix=".bed", delete=False) as f:
-            for i in mine:
-                f.write(f"{targets[i][0]}\t{targets[i][1]}\t{targets[i][2]}\n")
-            sub_bed = f.name
-        try:
-            if compute is None:
-                # the product path: the C++ driver on this rank's slice, which picks the device front end
-                # (inflate + record scan + join on this rank's GPU) or the host sweep by the amount of BAM.
-                # The rows come back as text; integers, halves and NaN survive that exactly.
-                with tempfile.NamedTemporaryFile("w+", suffix=".inq", delete=False) as rows:
-                    rows_path = rows.name
-                try:
-                    with open(rows_path, "w") as rf:
-                        hostcall.genotype_repeats(bamp, None, sub_bed, minlen, support, threads, unphased, sample_name, None,
-                                                  out=rf, device=device, frontend=frontend)
-                    got = {}
-                    with open(rows_path) as rf:
-                        next(rf)
-                        for line in rf:
-                            c, s0, e0, a, b = line.rstrip("\n").split("\t")
-                            got[(c, int(s0), int(e0))] = (float(a), float(b))
-                finally:
-                    os.unlink(rows_path)
-                for k, i in enumerate(mine):
-                    p1[k], p2[k] = got[tuple(targets[i])]
-            else:  # tests: per-batch compute supplied by the caller (the oracle, on CPU-only machines)
+    st, msg = 0, ""
+    try:
+        if len(mine) and compute is None:
+            # the product path: the C++ driver on this rank's share (inq_genotype_repeats_rows), which picks the device front end
+            # (inflate + record scan + join on this rank's GPU) or the host sweep by the amount of BAM; rows come back as f64
+            p1, p2 = hostcall.genotype_repeats_rows(bamp, region, region_file, mine, minlen, support, threads, unphased,
+                                                    device=device, frontend=frontend)
+        elif len(mine):  # tests: per-batch compute supplied by the caller (the oracle, on CPU-only machines)
+            fe_all = hostcall.FrontEnd(bamp, region=region, region_file=region_file)
+            targets = fe_all.targets()
+            fe_all.close()
+            with tempfile.NamedTemporaryFile("w", suffix=".bed", delete=False) as f:
+                for i in mine:
+                    f.write(f"{targets[i][0]}\t{targets[i][1]}\t{targets[i][2]}\n")
+                sub_bed = f.name
+            try:
                 fe = hostcall.FrontEnd(bamp, region_file=sub_bed, minlen=minlen, support=support, threads=threads,
                                        unphased=unphased, sample_name=sample_name)
                 for batch, idx in fe.batches():
                     a, b = compute(batch)
                     p1[idx], p2[idx] = a, b
                 fe.close()
-        finally:
-            os.unlink(sub_bed)
+            finally:
+                os.unlink(sub_bed)
+    except hostcall.CallError as e:
+        st, msg = e.status, e.message
+    except Exception as e:  # noqa: BLE001  anything else (HIP runtime, memory) is an error exit on every rank too
+        st, msg = 1, f"{type(e).__name__}: {e}"
+    st, msg, bad_rank = _exchange_status(st, msg, rank, world, group)
+    if st != 0:
+        raise hostcall.CallError(st, f"rank {bad_rank}: {msg}" if world > 1 else msg)
+    # ---- the one exchange of the path: 2 x f64 per locus to rank 0
     if world > 1:
-        width = max(cuts[r + 1] - cuts[r] for r in range(world))
+        width = max(int(cuts[r + 1] - cuts[r]) for r in range(world))
         gdev = torch.device("cuda", device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
         buf = torch.full((2, max(width, 1)), float("nan"), dtype=torch.float64, device=gdev)
         buf[0, : len(mine)] = torch.from_numpy(p1)
@@ -125,13 +117,17 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
             return
         full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
         for r in range(world):
-            sl = order[cuts[r] : cuts[r + 1]]
+            sl = order[int(cuts[r]) : int(cuts[r + 1])]
             full1[sl] = bufs[r][0, : len(sl)].cpu().numpy()
             full2[sl] = bufs[r][1, : len(sl)].cpu().numpy()
     else:
         full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
         full1[mine], full2[mine] = p1, p2
-    # output, src/call.rs:137-157: BED order for -t 1, (human chrom, start) order otherwise
+    # ---- output (rank 0), src/call.rs:137-157: BED order for -t 1, (human chrom, start) order otherwise
+    fe_all = hostcall.FrontEnd(bamp, region=region, region_file=region_file, sample_name=sample_name)
+    targets = fe_all.targets()
+    sample = fe_all.sample
+    fe_all.close()
     L = hostcall.load()
     import ctypes as C
 
@@ -185,7 +181,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     try:
         genotype_repeats_distributed(a.bam, a.region, a.region_file, a.minlen, a.support, a.threads, a.unphased,
                                      a.sample_name, out=out, rank=rank, world=world, device=device, frontend=a.frontend)
-    except hostcall.CallError as e:
+    except hostcall.CallError as e:  # the same status on every rank (the failure was exchanged before the gather)
         if rank == 0:
             print(e.message, file=sys.stderr)
         return e.status

@@ -423,7 +423,10 @@ private:
 static uint64_t span_bytes_from_env() {
     const char *e = std::getenv("INQ_SPAN_MB");
     const long v = e ? std::atol(e) : 0;
-    return v > 0 ? (uint64_t)v << 20 : (2048ull << 20);  // 30k..80k BGZF blocks against the chip's 81 920 inflate lanes (5 waves x 64 lanes x 256 CUs)
+    // ~10 000 BGZF blocks per span: the workgroup-per-block inflate has no latency floor (1.1 ms per 1000 blocks), so small
+    // spans cost nothing and the device starts on the first one while the loader still reads and uploads the next ones
+    // (1 GB file: 256 MB spans 0.28 s median start to exit, one 1 GB span 0.37 s; profiles/r02_results/l2_span_size.txt)
+    return v > 0 ? (uint64_t)v << 20 : (256ull << 20);
 }
 
 struct inq_spans {
@@ -665,7 +668,15 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
 static int write_rows(const inq_call_args_t *args, inq_frontend *F, const std::vector<double> &p1, const std::vector<double> &p2,
                       int out_fd, char *errbuf, size_t errcap);
 
-static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
+// rows instead of text: the targets named by idx[] (positions in the parsed target list) are called, their rows go to p1 / p2
+struct RowsOut {
+    const uint32_t *idx = nullptr;
+    uint64_t n = 0;
+    double *p1 = nullptr, *p2 = nullptr;
+    bool active = false;
+};
+
+static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap, const RowsOut &rows = RowsOut()) {
     using clk = std::chrono::steady_clock;
     const bool timing = std::getenv("INQ_TIMING") != nullptr;
     auto t_start = clk::now();
@@ -677,8 +688,25 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     int rc = inq_frontend_open_impl(args, &F, errbuf, errcap);
     if (rc != INQ_EXIT_OK) return rc;
     std::unique_ptr<inq_frontend> guard(F);
+    if (rows.active) {  // this caller's share of the targets (one process per GPU: inquistr_amd/call_dist.py)
+        std::vector<RepeatInterval> sub;
+        sub.reserve(rows.n);
+        for (uint64_t k = 0; k < rows.n; ++k) {
+            if (rows.idx[k] >= F->P.targets.size()) {
+                set_err(errbuf, errcap, "target index outside the target list");
+                return INQ_EXIT_ERROR;
+            }
+            sub.push_back(F->P.targets[rows.idx[k]]);
+        }
+        F->P.targets.swap(sub);
+    }
     const size_t n = F->P.targets.size();
     std::vector<double> p1(n, NAN), p2(n, NAN);
+    auto emit = [&]() -> int {
+        if (!rows.active) return write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
+        if (n) std::memcpy(rows.p1, p1.data(), n * sizeof(double)), std::memcpy(rows.p2, p2.data(), n * sizeof(double));
+        return INQ_EXIT_OK;
+    };
 
     const auto t_open = clk::now();
     const bool device_front = use_device_front(args, F->P);
@@ -687,7 +715,7 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
         int drc = run_device_front(args, F, actx, p1, p2, errbuf, errcap, &t_front, &t_dev);
         if (drc != INQ_EXIT_OK) return drc;
         const auto t_run = clk::now();
-        drc = write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
+        drc = emit();
         if (timing)
             std::fprintf(stderr,
                          "[inq timing] device front end: open+targets %.3fs  front-end choice %.3fs  spans %.3fs (waiting for the loader "
@@ -802,7 +830,7 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     if (!need_ctx()) return INQ_EXIT_ERROR;  // no GPU is an error even for an empty target list
 
     {
-        int wrc = write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
+        int wrc = emit();
         if (wrc != INQ_EXIT_OK) return wrc;
     }
     {  // the CLI is about to leave the process: the device context is left to the operating system (see run_device_front)
@@ -987,6 +1015,96 @@ int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, 
 }
 int inq_combine(const char *const *files, size_t n_files, int out_fd, char *errbuf, size_t errcap) {
     INQ_GUARD(inq_combine_impl(files, n_files, out_fd, errbuf, errcap), errbuf, errcap)
+}
+
+// ---- one process per GPU: this process's share of the targets, rows as numbers ----
+static int inq_genotype_repeats_rows_impl(const inq_call_args_t *args, const uint32_t *target_index, uint64_t n_index, double *phase1,
+                                          double *phase2, char *errbuf, size_t errcap) {
+    if (n_index && (!target_index || !phase1 || !phase2)) {
+        set_err(errbuf, errcap, "null argument");
+        return INQ_EXIT_ERROR;
+    }
+    RowsOut r;
+    r.idx = target_index;
+    r.n = n_index;
+    r.p1 = phase1;
+    r.p2 = phase2;
+    r.active = true;
+    return inq_genotype_repeats_impl(args, -1, errbuf, errcap, r);
+}
+int inq_genotype_repeats_rows(const inq_call_args_t *args, const uint32_t *target_index, uint64_t n_index, double *phase1, double *phase2,
+                              char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_genotype_repeats_rows_impl(args, target_index, n_index, phase1, phase2, errbuf, errcap), errbuf, errcap)
+}
+
+// The targets in file order (contig of the BAM header, start, end, position in the list) and `world` + 1 cut points into
+// that order, so that every part needs about the same number of compressed BAM bytes: cost of a target = bytes between its
+// scan start in the .bai's linear index and the next target's, capped so that one far-away locus does not own a contig.
+static int inq_host_partition_impl(const inq_call_args_t *args, uint64_t world, uint32_t *order, uint64_t order_cap, uint64_t *cuts,
+                                   uint64_t *n_targets, char *errbuf, size_t errcap) {
+    if (!world || !cuts || !n_targets) {
+        set_err(errbuf, errcap, "null argument");
+        return INQ_EXIT_ERROR;
+    }
+    Prepared P;
+    std::string msg;
+    int rc = prepare(args, P, msg);
+    if (rc != INQ_EXIT_OK) {
+        set_err(errbuf, errcap, msg);
+        return rc;
+    }
+    const size_t n = P.targets.size();
+    *n_targets = n;
+    if (n > order_cap || (n && !order)) {
+        set_err(errbuf, errcap, "order[] too small for the target list");
+        return INQ_EXIT_ERROR;
+    }
+    std::vector<int> tid(n);
+    {
+        std::map<std::string, int> memo;
+        for (size_t i = 0; i < n; ++i) {
+            auto it = memo.find(P.targets[i].chrom);
+            if (it == memo.end()) it = memo.emplace(P.targets[i].chrom, P.bam->tid(P.targets[i].chrom)).first;
+            tid[i] = it->second;
+        }
+    }
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order, order + n, [&](uint32_t a, uint32_t b) {
+        if (tid[a] != tid[b]) return tid[a] < tid[b];
+        if (P.targets[a].start != P.targets[b].start) return P.targets[a].start < P.targets[b].start;
+        return P.targets[a].end < P.targets[b].end;
+    });
+    std::vector<double> off(n), cost(n, 1.0);
+    for (size_t k = 0; k < n; ++k) {
+        const RepeatInterval &t = P.targets[order[k]];
+        off[k] = (double)(P.bam->index().scan_start(tid[order[k]], t.start >= 10 ? (int64_t)t.start - 10 : 0) >> 16);
+    }
+    std::vector<double> d;
+    for (size_t k = 0; k + 1 < n; ++k)
+        if (tid[order[k]] == tid[order[k + 1]] && off[k + 1] > off[k]) d.push_back(off[k + 1] - off[k]);
+    if (!d.empty()) {
+        std::vector<double> ds = d;
+        std::sort(ds.begin(), ds.end());
+        const double cap = ds[std::min(ds.size() - 1, (size_t)(0.99 * (double)ds.size()))] * 4 + 1, med = ds[ds.size() / 2];
+        for (size_t k = 0; k < n; ++k) {
+            const bool same = k + 1 < n && tid[order[k]] == tid[order[k + 1]] && off[k + 1] > off[k];
+            cost[k] += same ? std::min(off[k + 1] - off[k], cap) : med;  // last target of a contig: a typical gap
+        }
+    }
+    std::vector<double> csum(n + 1, 0.0);
+    for (size_t k = 0; k < n; ++k) csum[k + 1] = csum[k] + cost[k];
+    cuts[0] = 0;
+    for (uint64_t r = 1; r < world; ++r) {
+        const double want = csum[n] * (double)r / (double)world;
+        uint64_t k = (uint64_t)(std::lower_bound(csum.begin(), csum.end(), want) - csum.begin());
+        cuts[r] = std::min<uint64_t>(std::max<uint64_t>(k, cuts[r - 1]), n);
+    }
+    cuts[world] = n;
+    return INQ_EXIT_OK;
+}
+int inq_host_partition(const inq_call_args_t *args, uint64_t world, uint32_t *order, uint64_t order_cap, uint64_t *cuts, uint64_t *n_targets,
+                       char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_host_partition_impl(args, world, order, order_cap, cuts, n_targets, errbuf, errcap), errbuf, errcap)
 }
 
 // ---- spans: the host half of the device front end, on its own (no GPU involved) ----

@@ -48,3 +48,73 @@ def test_distributed_call_equals_single(tmp_path, orc, world, unphased, threads)
     out = str(tmp_path / "dist.inq")
     mp.spawn(_worker, args=(world, _free_port(), bam, bed, unphased, threads, out), nprocs=world, join=True)
     assert open(out).read() == _expected_text(loci, recs, unphased, 5, 3, "S", threads)
+
+
+def _write_bed(path, rows):
+    with open(path, "w") as f:
+        for c, s, e in rows:
+            f.write(f"{c}\t{s}\t{e}\n")
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("kind", ["few_loci_and_duplicates", "all_loci"])
+def test_eight_ranks_with_empty_and_single_locus_shards(tmp_path, orc, kind):
+    """world_size 8 (the node the path is meant for): more ranks than loci (empty shards, one-locus shards), the same locus
+    listed several times, and the plain case; the text must equal the single-process run's."""
+    bam, bed, loci, recs = _make_case(tmp_path, 43, n_loci=30)
+    if kind == "few_loci_and_duplicates":
+        loci = [loci[0], loci[3], loci[0], loci[7], loci[0]]
+        bed = str(tmp_path / "few.bed")
+        _write_bed(bed, [(c, s, e) for c, s, e, _ in loci])
+    out = str(tmp_path / "dist8.inq")
+    mp.spawn(_worker, args=(8, _free_port(), bam, bed, False, 4, out), nprocs=8, join=True)
+    assert open(out).read() == _expected_text(loci, recs, False, 5, 3, "S", 4)
+
+
+def _failing_worker(rank, world, port, bam, bed, status_dir):
+    import torch.distributed as dist
+
+    from inquistr_amd import call, call_dist
+    from oracle import orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def compute(batch):
+        code, res = orc.call_batch(batch)
+        assert code == 0
+        return res.phase1, res.phase2
+
+    status = 0
+    try:
+        with open(os.devnull, "w") as f:
+            call_dist.genotype_repeats_distributed(bam, None, bed, 5, 3, 2, False, "S", out=f, rank=rank, world=world, compute=compute)
+    except call.CallError as e:
+        status = e.status
+    with open(os.path.join(status_dir, f"rank{rank}"), "w") as f:
+        f.write(str(status))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_failure_on_one_rank_ends_every_rank_with_its_status(tmp_path):
+    """A record the reference panics on (HP typed `s`, phased mode: get_phase, src/call.rs:482-491) sits in ONE rank's share of
+    the file.  Every rank must come back with exit status 101 instead of waiting in the row gather."""
+    from tools import bamio
+
+    bam = str(tmp_path / "bad.bam")
+    w = bamio.BamWriter(bam, [("chr1", 1_000_000)])
+    for k in range(40):
+        pos = 10_000 + 20_000 * k
+        for r in range(6):
+            hp = ("s", 1) if (k == 33 and r == 2) else ("C", 1 + r % 2)
+            w.add(f"r{k}_{r}", 0, 0, pos - 300, 60, [("M", 400), ("I", 9), ("M", 400)], [("HP", hp[0], hp[1])])
+    w.close()
+    bed = str(tmp_path / "bad.bed")
+    _write_bed(bed, [("chr1", 10_000 + 20_000 * k, 10_050 + 20_000 * k) for k in range(40)])
+    status_dir = str(tmp_path / "status")
+    os.makedirs(status_dir)
+    mp.spawn(_failing_worker, args=(4, _free_port(), bam, bed, status_dir), nprocs=4, join=True)
+    assert [open(os.path.join(status_dir, f"rank{r}")).read() for r in range(4)] == ["101"] * 4

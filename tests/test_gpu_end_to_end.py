@@ -87,7 +87,7 @@ def test_one_process_per_gpu_rehearsal(tmp_path, frontend):
     from tools import make_synth_bam
 
     prefix = str(tmp_path / "w")
-    make_synth_bam.write("phased10k", 4000, prefix)
+    make_synth_bam.write_native("phased10k", 4000, prefix)
     single = tmp_path / "single.inq"
     with open(single, "w") as f:
         call.genotype_repeats(prefix + ".bam", None, prefix + ".bed", 5, 3, 4, False, "S", None, out=f, frontend=frontend)
