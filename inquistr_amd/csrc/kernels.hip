@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void locus_call_medium(KArgs a) {
 // Deep loci.  Scratch layout: sval[p] (i64) and smeta[p] (u8) indexed by global pair number.
 
 constexpr int kBigBlock = 64;           // reads one wave walks per block in locus_call_big_walk
+constexpr uint32_t kWalkSplit = 16384;  // loci deeper than this are walked by the whole grid
 
 struct BigShared {
     unsigned int cnt_kept, ng[3], ns[3];
@@ -337,124 +338,140 @@ struct BigShared {
     long long split_lo, split_hi;
 };
 
-// Per-read results of one very deep locus (> kSortCap reads) stay in the ctx's global scratch and are
-// ranked there by counting: O(n^2), with agent-scope fences between the passes.  Any depth, slow.
+// Per-read results of one very deep locus (more reads than the LDS sort holds, or a Call beyond the sort key's 47 bits) stay
+// in the ctx's global scratch (L2-resident: 9 bytes per read) and are reduced there by ONE workgroup with a most-significant-
+// byte-first radix select: eight passes of a 256-bin histogram find the k-th smallest value of any subset, O(n) each.  About
+// 60 passes per locus whatever its depth (split of the unphased order, clip threshold and the two middle elements per
+// haplotype): a 100 000-read locus costs ~25 000 element visits per thread.
 struct DeepStore {
-    int64_t *val;
+    const int64_t *val;
     unsigned char *meta;
-    __device__ __forceinline__ void publish() const {
-        __threadfence();
+};
+struct SelectLds {
+    unsigned int hist[256];
+    unsigned int scan[256];
+    unsigned long long prefix;
+    unsigned int k, below, eq, flags;
+    unsigned int cnt[8];
+};
+__device__ __forceinline__ uint64_t order_key(int64_t v) { return (uint64_t)v ^ (1ull << 63); }  // signed order as unsigned order
+
+// k-th smallest (0-based) key among the elements for which pred(e, key) holds, plus `lump_cnt` extra elements of key
+// `lump_key`.  Block-uniform result; L.below = elements smaller than it, L.eq = elements equal to it (lump included).
+template <class Pred>
+__device__ uint64_t radix_select(const DeepStore &S, uint32_t n, Pred pred, uint32_t k, uint64_t lump_key, uint32_t lump_cnt, SelectLds &L) {
+    if (threadIdx.x == 0) L.prefix = 0ull, L.k = k, L.below = 0u;
+    for (int pass = 7; pass >= 0; --pass) {
+        L.hist[threadIdx.x] = 0u;
+        __syncthreads();
+        const uint64_t prefix = L.prefix;  // the bytes above `pass`, already decided
+        auto upper_matches = [&](uint64_t key) { return pass == 7 || (key >> (8 * (pass + 1))) == prefix; };
+        for (uint32_t e = threadIdx.x; e < n; e += 256u) {
+            const uint64_t key = order_key(S.val[e]);
+            if (upper_matches(key) && pred(e, key)) atomicAdd(&L.hist[(key >> (8 * pass)) & 255u], 1u);
+        }
+        if (threadIdx.x == 0 && lump_cnt && upper_matches(lump_key)) atomicAdd(&L.hist[(lump_key >> (8 * pass)) & 255u], lump_cnt);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t c = 0, bin = 255u;
+            const uint32_t want = L.k;
+            for (uint32_t b2 = 0; b2 < 256u; ++b2) {
+                if (want < c + L.hist[b2]) {
+                    bin = b2;
+                    break;
+                }
+                c += L.hist[b2];
+            }
+            L.k = want - c;
+            L.below += c;
+            L.eq = L.hist[bin];
+            L.prefix = (prefix << 8) | bin;
+        }
         __syncthreads();
     }
-};
-
-// rank counting over the store for one group; returns via sh.med[g]
-__device__ void big_group_median(const DeepStore &S, uint32_t n, int g, uint32_t support, BigShared &sh, double &out) {
-    const uint32_t ng = sh.ng[g], ns = sh.ns[g];
-    if (ng < support) {  // uniform over the block
-        out = qnan();
-        return;
-    }
-    const uint32_t take = (ns <= support) ? support - ns : 0u;
-    // chosen = spans of the group, plus the `take` largest clips (src/call.rs:509-513)
-    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-        uint32_t me = S.meta[e];
-        const bool ing = (me & PM_KEPT) && ((me >> PM_GRP_SHIFT) & 3u) == (uint32_t)g;
-        bool ch = false;
-        if (ing) {
-            if (!(me & PM_CLIP))
-                ch = true;
-            else if (take > 0u) {
-                const int64_t v = S.val[e];
-                uint32_t drank = 0;
-                for (uint32_t jx = 0; jx < n && drank < take; ++jx) {
-                    const uint32_t mj = S.meta[jx];
-                    if ((mj & PM_KEPT) && (mj & PM_CLIP) && ((mj >> PM_GRP_SHIFT) & 3u) == (uint32_t)g) {
-                        const int64_t vj = S.val[jx];
-                        drank += (vj > v || (vj == v && jx < e)) ? 1u : 0u;
-                    }
-                }
-                ch = drank < take;
-            }
-        }
-        // the chosen bit of group 1 must not leak into group 2: it is rewritten per group
-        me = ch ? (me | PM_CHOSEN) : (me & ~PM_CHOSEN);
-        S.meta[e] = (unsigned char)me;
-    }
-    S.publish();
-    const uint32_t M = (ns > support) ? ns : support;
-    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-        const uint32_t me = S.meta[e];
-        if (!((me & PM_CHOSEN) && ((me >> PM_GRP_SHIFT) & 3u) == (uint32_t)g)) continue;
-        const int64_t v = S.val[e];
-        uint32_t arank = 0;
-        for (uint32_t jx = 0; jx < n; ++jx) {
-            const uint32_t mj = S.meta[jx];
-            if ((mj & PM_CHOSEN) && ((mj >> PM_GRP_SHIFT) & 3u) == (uint32_t)g) {
-                const int64_t vj = S.val[jx];
-                arank += before(vj, (int)jx, v, (int)e) ? 1u : 0u;
-            }
-        }
-        if (arank == M / 2u) sh.med[g][1] = v;
-        if (!(M & 1u) && arank == M / 2u - 1u) sh.med[g][0] = v;
-    }
-    __syncthreads();
-    if (M & 1u)
-        out = (double)sh.med[g][1];
-    else
-        out = (double)(sh.med[g][0] + sh.med[g][1]) / 2.0;
-    __syncthreads();
+    return L.prefix;
 }
 
-// The whole reduce of one locus over the global store (the > kSortCap fallback).
-template <bool UNPHASED>
-__device__ void reduce_deep_global(const KArgs &a, uint64_t j, uint64_t p0, uint32_t n, BigShared &sh) {
-    DeepStore S{(int64_t *)(a.sval + p0), (unsigned char *)(a.smeta + p0)};
-    if (threadIdx.x == 0) {
-        sh.cnt_kept = 0;
-        for (int g = 0; g < 3; ++g) sh.ng[g] = sh.ns[g] = 0;
-        sh.tie_span = sh.tie_clip = 0;
-    }
-    __syncthreads();
-    if (UNPHASED) {  // global rank -> haplotype group (src/call.rs:311-313)
-        uint32_t local = 0;
-        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) local += (S.meta[e] & PM_KEPT) ? 1u : 0u;
-        if (local) atomicAdd(&sh.cnt_kept, local);
+// median_str_length (src/call.rs:497-522) of haplotype group g (1 / 2) of the store
+__device__ double deep_group_median(const DeepStore &S, uint32_t n, uint32_t g, uint32_t ng, uint32_t ns, uint32_t support, SelectLds &L) {
+    if (ng < support) return qnan();  // :498-500
+    auto in_group = [&](uint32_t e) {
+        const uint32_t me = S.meta[e];
+        return (me & PM_KEPT) && ((me >> PM_GRP_SHIFT) & 3u) == g;
+    };
+    const uint32_t take = ns <= support ? support - ns : 0u;  // :509-513: the largest `take` clipped Calls join the spanning ones
+    uint64_t t_key = 0;
+    uint32_t lump = 0;
+    if (take > 0u) {
+        const uint32_t nc = ng - ns;  // >= take because ng >= support
+        t_key = radix_select(S, n, [&](uint32_t e, uint64_t) { return in_group(e) && (S.meta[e] & PM_CLIP); }, nc - take, 0ull, 0u, L);
+        const uint32_t above = nc - L.below - L.eq;  // clipped Calls larger than the threshold value: all chosen
+        lump = take - above;                          // ... and this many equal to it (which ones does not change the values)
         __syncthreads();
-        const uint32_t mcount = sh.cnt_kept, ks = mcount / 2u;
-        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+    }
+    const uint32_t M = ns + take;  // >= 1 because support >= 1
+    auto chosen = [&](uint32_t e, uint64_t key) { return in_group(e) && (!(S.meta[e] & PM_CLIP) || (take > 0u && key > t_key)); };
+    const int64_t vhi = (int64_t)(radix_select(S, n, chosen, M / 2u, t_key, lump, L) ^ (1ull << 63));
+    __syncthreads();
+    if (M & 1u) return (double)vhi;  // :520
+    const int64_t vlo = (int64_t)(radix_select(S, n, chosen, M / 2u - 1u, t_key, lump, L) ^ (1ull << 63));
+    __syncthreads();
+    return (double)(vlo + vhi) / 2.0;  // :515-518
+}
+
+// The whole reduce of one locus over the global store.
+template <bool UNPHASED>
+__device__ void reduce_deep_select(const KArgs &a, uint64_t j, uint64_t p0, uint32_t n, SelectLds &L) {
+    DeepStore S{a.sval + p0, (unsigned char *)(a.smeta + p0)};
+    bool tie = false;
+    if (UNPHASED) {  // src/call.rs:311-313: sort by (value, file order), h1 = the lower mcount / 2, h2 = the rest
+        if (threadIdx.x < 8) L.cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t local = 0;
+        for (uint32_t e = threadIdx.x; e < n; e += 256u) local += (S.meta[e] & PM_KEPT) ? 1u : 0u;
+        if (local) atomicAdd(&L.cnt[0], local);
+        __syncthreads();
+        const uint32_t mcount = L.cnt[0], ks = mcount / 2u;
+        __syncthreads();
+        uint64_t split = ~0ull;
+        uint32_t r = 0;  // elements equal to the split value that still belong to h1 (the first r in file order)
+        if (mcount) {
+            split = radix_select(S, n, [&](uint32_t e, uint64_t) { return (S.meta[e] & PM_KEPT) != 0; }, ks < mcount ? ks : mcount - 1u, 0ull, 0u, L);
+            r = ks - L.below;
+            __syncthreads();
+        }
+        // groups: each thread owns a contiguous stretch so that "the first r equal ones in file order" is a prefix count
+        const uint32_t chunk = (n + 255u) / 256u, e0 = min(n, threadIdx.x * chunk), e1 = min(n, e0 + chunk);
+        uint32_t eq = 0;
+        for (uint32_t e = e0; e < e1; ++e) eq += ((S.meta[e] & PM_KEPT) && order_key(S.val[e]) == split) ? 1u : 0u;
+        L.scan[threadIdx.x] = eq;
+        if (threadIdx.x == 0) L.flags = 0u;
+        __syncthreads();
+        uint32_t eq_before = 0;
+        for (uint32_t t = 0; t < threadIdx.x; ++t) eq_before += L.scan[t];
+        uint32_t fl = 0;
+        for (uint32_t e = e0; e < e1; ++e) {
             uint32_t me = S.meta[e];
             if (!(me & PM_KEPT)) continue;
-            const int64_t v = S.val[e];
-            uint32_t rank = 0;
-            for (uint32_t jx = 0; jx < n; ++jx)
-                if (S.meta[jx] & PM_KEPT) rank += before(S.val[jx], (int)jx, v, (int)e) ? 1u : 0u;
-            const uint32_t grp = rank < ks ? 1u : 2u;
-            // other threads still read PM_KEPT of this byte while ranks are being counted; the
-            // group bits written here leave PM_KEPT untouched
-            me = (me & ~(3u << PM_GRP_SHIFT)) | (grp << PM_GRP_SHIFT);
-            S.meta[e] = (unsigned char)me;
-            if (ks >= 1u && rank == ks - 1u) sh.split_lo = v;
-            if (rank == ks) sh.split_hi = v;
-        }
-        S.publish();
-        if (ks >= 1u && ks < mcount && sh.split_lo == sh.split_hi) {
-            const int64_t vs = sh.split_lo;
-            for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-                const uint32_t me = S.meta[e];
-                if ((me & PM_KEPT) && S.val[e] == vs) {
-                    if (me & PM_CLIP)
-                        sh.tie_clip = 1u;
-                    else
-                        sh.tie_span = 1u;
-                }
+            const uint64_t key = order_key(S.val[e]);
+            uint32_t grp = key < split ? 1u : 2u;
+            if (key == split) {
+                grp = eq_before < r ? 1u : 2u;
+                ++eq_before;
+                fl |= (me & PM_CLIP) ? 1u : 2u;
             }
+            S.meta[e] = (unsigned char)((me & ~(3u << PM_GRP_SHIFT)) | (grp << PM_GRP_SHIFT));
         }
+        if (fl) atomicOr(&L.flags, fl);
         __syncthreads();
+        // the split cuts through equal values iff some element equal to the split value went to h1 (:312-314 ambiguity)
+        tie = ks >= 1u && ks < mcount && r >= 1u && L.flags == 3u;
     }
+    if (threadIdx.x < 8) L.cnt[threadIdx.x] = 0u;
+    __syncthreads();
     {
         uint32_t c_ng[3] = {0, 0, 0}, c_ns[3] = {0, 0, 0};
-        for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+        for (uint32_t e = threadIdx.x; e < n; e += 256u) {
             const uint32_t me = S.meta[e];
             if (!(me & PM_KEPT)) continue;
             const uint32_t g = (me >> PM_GRP_SHIFT) & 3u;
@@ -464,18 +481,19 @@ __device__ void reduce_deep_global(const KArgs &a, uint64_t j, uint64_t p0, uint
             }
         }
         for (int g = 1; g <= 2; ++g) {
-            if (c_ng[g]) atomicAdd(&sh.ng[g], c_ng[g]);
-            if (c_ns[g]) atomicAdd(&sh.ns[g], c_ns[g]);
+            if (c_ng[g]) atomicAdd(&L.cnt[g], c_ng[g]);
+            if (c_ns[g]) atomicAdd(&L.cnt[4 + g], c_ns[g]);
         }
     }
     __syncthreads();
-    double out1, out2;
-    big_group_median(S, n, 1, a.support, sh, out1);
-    big_group_median(S, n, 2, a.support, sh, out2);
+    const uint32_t ng1 = L.cnt[1], ng2 = L.cnt[2], ns1 = L.cnt[5], ns2 = L.cnt[6];
+    __syncthreads();
+    const double out1 = deep_group_median(S, n, 1u, ng1, ns1, a.support, L);
+    const double out2 = deep_group_median(S, n, 2u, ng2, ns2, a.support, L);
     if (threadIdx.x == 0) {
         a.phase1[j] = out1;
         a.phase2[j] = out2;
-        if (UNPHASED && sh.tie_span && sh.tie_clip) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
+        if (tie) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
     }
     __syncthreads();
 }
@@ -496,12 +514,18 @@ __global__ __launch_bounds__(256) void locus_call_big_walk(KArgs a) {
     uint32_t total = 0;
     for (int k = 0; k < kListShards; ++k) total += cnt[k];
     BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
-    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+    // Every workgroup goes through the whole list.  A locus of up to kWalkSplit reads is walked by ONE workgroup (item modulo
+    // grid); a deeper one (amplicon-depth pile-ups) by ALL of them, 64-read blocks dealt round-robin over every wave of the grid,
+    // so that a single 100 000-read locus streams at the chip's rate instead of one workgroup's.
+    for (uint32_t item = 0; item < total; ++item) {
         uint32_t shard = 0, idx = item;
         while (idx >= cnt[shard]) idx -= cnt[shard++];
         const uint64_t j = a.worklist[((uint64_t)kListShards + shard) * a.shard_cap + idx];
         const uint64_t p0 = a.locus_pair_off[j];
         const uint32_t n = (uint32_t)(a.locus_pair_off[j + 1] - p0);
+        const bool shared = n > kWalkSplit;
+        if (!shared && item % gridDim.x != blockIdx.x) continue;
+        const uint32_t bstep = shared ? 4u * gridDim.x : 4u;  // blocks between two of this wave's
         const uint32_t start = a.locus_start[j], end = a.locus_end[j];
         Window W;
         W.se = start - 10u;
@@ -513,11 +537,11 @@ __global__ __launch_bounds__(256) void locus_call_big_walk(KArgs a) {
         const uint32_t nblk = (n + kBigBlock - 1) / kBigBlock;
         auto blk_cnt = [&](uint32_t blk) { return blk < nblk ? (int)min((uint32_t)kBigBlock, n - blk * kBigBlock) : 0; };
         // software pipeline over this wave's blocks: A = pair index (2 ahead), B = descriptor (1 ahead)
-        uint32_t blk = wave;
+        uint32_t blk = shared ? blockIdx.x * 4u + wave : wave;
         uint32_t ri_b = meta_stage_a(b, p0 + (uint64_t)blk * kBigBlock, blk_cnt(blk), lane);
         uint4 rd = meta_stage_b(b, ri_b);
-        uint32_t ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + 4u) * kBigBlock, blk_cnt(blk + 4u), lane);
-        for (; blk < nblk; blk += 4u) {
+        uint32_t ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + bstep) * kBigBlock, blk_cnt(blk + bstep), lane);
+        for (; blk < nblk; blk += bstep) {
             const int c = blk_cnt(blk);
             const uint64_t first = p0 + (uint64_t)blk * kBigBlock;
             bool valid;
@@ -526,7 +550,7 @@ __global__ __launch_bounds__(256) void locus_call_big_walk(KArgs a) {
             // next block: descriptor load now (its index arrived during the previous walk), index load for the one after
             ri_b = ri_next;
             rd = meta_stage_b(b, ri_b);
-            ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + 8u) * kBigBlock, blk_cnt(blk + 8u), lane);
+            ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + 2u * bstep) * kBigBlock, blk_cnt(blk + 2u * bstep), lane);
             int64_t val;
             uint32_t meta;
             walk_pairs<UNPHASED, AUX>(b, m, valid, c, W, lane, status, lds[wave], val, meta);
@@ -609,7 +633,7 @@ __device__ double median_of_sorted_range(SortLds<CAP> &L, uint32_t lo, uint32_t 
 template <bool UNPHASED, int CAP>
 __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
     __shared__ SortLds<CAP> L;
-    __shared__ BigShared sh;  // for the global fallback
+    __shared__ SelectLds sh;  // for the loci no LDS sort can hold
     __shared__ uint32_t cnt[kListShards];
     if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[1][threadIdx.x].n;
     __syncthreads();
@@ -627,7 +651,7 @@ __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
         constexpr uint32_t kLow = CAP == 2048 ? 0u : CAP == 8192 ? 2048u : 8192u;  // this launch takes (kLow, CAP]
         if (n <= kLow || (CAP != 16384 && n > (uint32_t)CAP)) continue;
         if (n > (uint32_t)CAP) {  // only the last class: deeper than any sort can hold
-            reduce_deep_global<UNPHASED>(a, j, p0, n, sh);
+            reduce_deep_select<UNPHASED>(a, j, p0, n, sh);
             continue;
         }
         if (threadIdx.x == 0) L.m = L.c1 = L.tie_span = L.tie_clip = L.overflow = 0u;
@@ -648,7 +672,7 @@ __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
         }
         __syncthreads();
         if (L.overflow) {  // a Call beyond 47 bits: not representable in the key
-            reduce_deep_global<UNPHASED>(a, j, p0, n, sh);
+            reduce_deep_select<UNPHASED>(a, j, p0, n, sh);
             continue;
         }
         const uint32_t m = L.m;

@@ -1,5 +1,7 @@
 #include "bam_reader.h"
 
+#include <zlib.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -78,11 +80,106 @@ trunc:
     return false;
 }
 
+// [3P] CSI v1 (htslib csi spec): magic, min_shift, depth, l_aux + aux, n_ref, then per contig n_bin x {bin, loffset,
+// n_chunk, chunks}; optional n_no_coor.  The file is BGZF-compressed: gzread() walks the concatenated gzip members.
+bool BaiIndex::load_csi(const std::string &path, std::string *err) {
+    gzFile g = gzopen(path.c_str(), "rb");
+    if (!g) {
+        if (err) *err = "cannot open index " + path;
+        return false;
+    }
+    std::vector<uint8_t> d;
+    uint8_t tmp[1 << 16];
+    int n;
+    while ((n = gzread(g, tmp, sizeof tmp)) > 0) d.insert(d.end(), tmp, tmp + n);
+    gzclose(g);
+    size_t p = 0;
+    auto need = [&](size_t k) { return p + k <= d.size(); };
+    if (n < 0 || !need(16) || std::memcmp(d.data(), "CSI\1", 4) != 0) {
+        if (err) *err = "not a CSI file: " + path;
+        return false;
+    }
+    min_shift = (int)le32(&d[4]);
+    depth = (int)le32(&d[8]);
+    const uint32_t l_aux = le32(&d[12]);
+    if (min_shift < 1 || min_shift > 30 || depth < 1 || depth > 9 || min_shift + 3 * depth > 62) {
+        if (err) *err = "unsupported CSI binning in " + path;
+        return false;
+    }
+    p = 16;
+    if (!need((size_t)l_aux + 4)) goto trunc;
+    p += l_aux;
+    {
+        const uint32_t n_ref = le32(&d[p]);
+        p += 4;
+        refs.assign(n_ref, BaiRef());
+        csi = true;
+        const uint32_t meta = meta_bin();
+        for (uint32_t r = 0; r < n_ref; ++r) {
+            BaiRef &R = refs[r];
+            if (!need(4)) goto trunc;
+            const uint32_t n_bin = le32(&d[p]);
+            p += 4;
+            bool first = true;
+            for (uint32_t b = 0; b < n_bin; ++b) {
+                if (!need(16)) goto trunc;
+                const uint32_t bin = le32(&d[p]);
+                const uint64_t loffset = le64(&d[p + 4]);
+                const uint32_t n_chunk = le32(&d[p + 12]);
+                p += 16;
+                if (!need((size_t)n_chunk * 16)) goto trunc;
+                if (bin == meta && n_chunk == 2) {
+                    R.has_meta = true;
+                    R.n_mapped = le64(&d[p + 16]);
+                    R.n_unmapped = le64(&d[p + 24]);
+                } else {
+                    auto &v = R.bins[bin];
+                    R.loff[bin] = loffset;
+                    for (uint32_t c = 0; c < n_chunk; ++c) {
+                        const uint64_t beg = le64(&d[p + 16 * c]), end = le64(&d[p + 16 * c + 8]);
+                        v.emplace_back(beg, end);
+                        if (first || beg < R.min_offset) R.min_offset = beg;
+                        if (first || end > R.max_offset) R.max_offset = end;
+                        first = false;
+                    }
+                }
+                p += (size_t)n_chunk * 16;
+            }
+        }
+        if (need(8)) n_no_coor = le64(&d[p]);
+    }
+    return true;
+trunc:
+    if (err) *err = "truncated CSI file: " + path;
+    return false;
+}
+
+uint64_t BaiIndex::csi_min_off(int tid, int64_t beg) const {
+    const BaiRef &R = refs[tid];
+    if (beg < 0) beg = 0;
+    const int64_t max_pos = (1ll << (min_shift + 3 * depth)) - 1;
+    if (beg > max_pos) beg = max_pos;
+    uint32_t bin = level_first(depth) + (uint32_t)(beg >> min_shift);
+    for (;;) {
+        auto it = R.loff.find(bin);
+        if (it != R.loff.end()) return it->second;
+        if (bin == 0) return 0;
+        const uint32_t parent = (bin - 1) >> 3, first_sibling = (parent << 3) + 1;
+        bin = bin > first_sibling ? bin - 1 : parent;
+    }
+}
+
 uint64_t BaiIndex::scan_start(int tid, int64_t beg) const {
     if (tid < 0 || (size_t)tid >= refs.size()) return 0;
     const BaiRef &R = refs[tid];
     if (R.bins.empty()) return 0;
     if (beg < 0) beg = 0;
+    if (csi) {
+        // nothing at or behind beg when every bin ends in front of it; otherwise htslib's starting offset, and where that
+        // is 0 (no bin at or in front of beg's window) the contig's first record
+        const uint64_t off = csi_min_off(tid, beg);
+        return off ? off : R.min_offset;
+    }
     size_t w = (size_t)(beg >> 14);
     if (w >= R.ioffset.size()) {
         // no record overlaps any window at or beyond the last indexed one... except through the
@@ -103,16 +200,18 @@ std::vector<std::pair<uint64_t, uint64_t>> BaiIndex::query(int tid, int64_t beg,
     const BaiRef &R = refs[tid];
     if (beg < 0) beg = 0;
     uint64_t min_off = 0;
-    if (!R.ioffset.empty()) {
+    if (csi) min_off = csi_min_off(tid, beg);
+    else if (!R.ioffset.empty()) {
         size_t w = (size_t)(beg >> 14);
         min_off = w < R.ioffset.size() ? R.ioffset[w] : R.ioffset.back();
     }
-    // reg2bins over the 6 levels of the UCSC binning scheme (min_shift 14, depth 5)
+    // reg2bins over the levels of the UCSC binning scheme (.bai: min_shift 14, depth 5)
     int64_t e = end - 1;
-    const int shifts[6] = {29, 26, 23, 20, 17, 14};
-    const uint32_t firsts[6] = {0, 1, 9, 73, 585, 4681};
-    for (int l = 0; l < 6; ++l) {
-        uint32_t b0 = firsts[l] + (uint32_t)(beg >> shifts[l]), b1 = firsts[l] + (uint32_t)(e >> shifts[l]);
+    const int64_t max_pos = (1ll << (min_shift + 3 * depth)) - 1;
+    if (beg > max_pos) beg = max_pos;
+    if (e > max_pos) e = max_pos;
+    for (int l = 0; l <= depth; ++l) {
+        uint32_t b0 = level_first(l) + (uint32_t)(beg >> level_shift(l)), b1 = level_first(l) + (uint32_t)(e >> level_shift(l));
         for (auto it = R.bins.lower_bound(b0); it != R.bins.end() && it->first <= b1; ++it)
             for (auto &c : it->second)
                 if (c.second > min_off) out.emplace_back(c.first, c.second);
@@ -167,17 +266,22 @@ bool BamFile::open(const std::string &path, std::string *err) {
         name2tid_.emplace(name, (int)i);  // first wins, like a hash built front to back
     }
     first_rec_ = bgzf_.tell();
+    // [3P] htslib looks for <path>.csi, then <path>.bai, then the same with the file's extension dropped
     std::string e1, e2;
-    if (!bai_.load(path + ".bai", &e1)) {
-        std::string alt = path;
-        size_t dot = alt.rfind('.');
-        if (dot != std::string::npos) alt = alt.substr(0, dot);
-        if (!bai_.load(alt + ".bai", &e2)) {
-            if (err) *err = "could not load index for " + path + " (" + e1 + ")";
-            return false;
-        }
-    }
-    return true;
+    std::string alt = path;
+    const size_t dot = alt.rfind('.');
+    if (dot != std::string::npos) alt = alt.substr(0, dot);
+    auto exists = [](const std::string &f) {
+        FILE *t = std::fopen(f.c_str(), "rb");
+        if (t) std::fclose(t);
+        return t != nullptr;
+    };
+    if (exists(path + ".csi")) return bai_.load_csi(path + ".csi", err);
+    if (bai_.load(path + ".bai", &e1)) return true;
+    if (exists(alt + ".csi")) return bai_.load_csi(alt + ".csi", err);
+    if (bai_.load(alt + ".bai", &e2)) return true;
+    if (err) *err = "could not load index for " + path + " (" + e1 + ")";
+    return false;
 }
 
 int BamFile::tid(const std::string &name) const {

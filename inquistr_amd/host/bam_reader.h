@@ -23,16 +23,29 @@ struct BamRef {
 
 struct BaiRef {
     std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
-    std::vector<uint64_t> ioffset;  // 16 kb linear index
+    std::map<uint32_t, uint64_t> loff;  // .csi only: per bin, the smallest offset of a record overlapping the bin's first window
+    std::vector<uint64_t> ioffset;  // .bai only: 16 kb linear index
     uint64_t n_mapped = 0, n_unmapped = 0;
     bool has_meta = false;
     uint64_t min_offset = 0, max_offset = 0;  // over real bins
 };
 
+// A .bai, or a .csi ([3P] htslib: IndexedReader::from_path takes either, src/call.rs:242).  Both use the UCSC binning
+// scheme; a .bai fixes min_shift = 14 and depth = 5 and carries a linear index, a .csi states both numbers and keeps one
+// offset per bin instead (the linear index entry of the bin's first window).
 struct BaiIndex {
     std::vector<BaiRef> refs;
     uint64_t n_no_coor = 0;
-    bool load(const std::string &path, std::string *err);
+    int min_shift = 14, depth = 5;
+    bool csi = false;
+    bool load(const std::string &path, std::string *err);      // .bai
+    bool load_csi(const std::string &path, std::string *err);  // .csi (BGZF-compressed)
+    uint32_t level_first(int l) const { return (uint32_t)(((1ull << (3 * l)) - 1) / 7); }  // first bin id of level l
+    int level_shift(int l) const { return min_shift + 3 * (depth - l); }                  // log2 of a level-l bin's width
+    uint32_t meta_bin() const { return level_first(depth + 1) + 1; }                       // htslib's pseudo-bin
+    // .csi: the offset htslib's iterator starts from for position beg - the loff of the deepest existing bin at or in
+    // front of beg's window, walking left through the siblings and up through the parents ([3P] hts_itr_query)
+    uint64_t csi_min_off(int tid, int64_t beg) const;
     // smallest virtual offset from which a forward scan sees every record of `tid` overlapping
     // positions >= beg; 0 when the contig has no records at or after beg.
     uint64_t scan_start(int tid, int64_t beg) const;

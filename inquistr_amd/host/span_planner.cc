@@ -20,15 +20,13 @@ const BaiAnchors::PerRef &BaiAnchors::ref(int tid) {
     PerRef &P = refs_[tid];
     if (P.built) return P;
     const BaiRef &R = idx_.refs[tid];
-    // UCSC binning, min_shift 14, depth 5: first bin id and width (as a shift) of every level
-    const int shifts[6] = {29, 26, 23, 20, 17, 14};
-    const uint32_t firsts[7] = {0, 1, 9, 73, 585, 4681, 37449};
+    // UCSC binning (.bai: min_shift 14, depth 5; .csi: as the file says): first bin id and width (as a shift) of every level
     for (const auto &kv : R.bins) {
         const uint32_t bin = kv.first;
-        if (bin >= 37449 || kv.second.empty()) continue;
+        if (bin >= idx_.level_first(idx_.depth + 1) || kv.second.empty()) continue;
         int l = 0;
-        while (bin >= firsts[l + 1]) ++l;
-        const int64_t start = (int64_t)(bin - firsts[l]) << shifts[l];
+        while (bin >= idx_.level_first(l + 1)) ++l;
+        const int64_t start = (int64_t)(bin - idx_.level_first(l)) << idx_.level_shift(l);
         uint64_t beg = kv.second[0].first;
         for (const auto &c : kv.second) {
             beg = std::min(beg, c.first);
@@ -38,6 +36,8 @@ const BaiAnchors::PerRef &BaiAnchors::ref(int tid) {
     }
     for (uint64_t v : R.ioffset)
         if (v) P.anchors.push_back(v);  // the first record overlapping a 16 kb window
+    for (const auto &kv : R.loff)
+        if (kv.second) P.anchors.push_back(kv.second);  // .csi: the same for the first window of a bin
     std::sort(P.anchors.begin(), P.anchors.end());
     P.anchors.erase(std::unique(P.anchors.begin(), P.anchors.end()), P.anchors.end());
     std::sort(P.bins.begin(), P.bins.end());

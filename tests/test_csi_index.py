@@ -1,0 +1,78 @@
+"""`.csi` indexes ([3P] htslib: IndexedReader::from_path takes a .bai or a .csi, src/call.rs:242): the same BAM indexed
+either way must give the same batches from the host sweep and the same spans from the device front end's planner."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from inquistr_amd import call
+from tests import gen
+from tests.test_host_frontend import REFS, _expected, _make_case
+from tools import bamio
+
+
+def _reindex(tmp_path, bam, recs, min_shift, depth, name, block=bamio.BLOCK):
+    """Rewrites the records of a _make_case BAM with a .csi of the given binning next to it (and no .bai)."""
+    path = str(tmp_path / name)
+    w = bamio.BamWriter(path, REFS, block=block)
+    k = 0
+    for t in range(len(REFS)):
+        for r in recs[t]:
+            tags = [("HP", r.hp[0], r.hp[1])] if r.hp else []
+            if r.sa:
+                tags.append(("SA", "Z", r.sa[1]))
+            w.add(f"read{k}", r.flag, t, r.pos, r.mapq, r.cigar, tags)
+            k += 1
+    w.close(index="csi", csi_min_shift=min_shift, csi_depth=depth)
+    assert os.path.exists(path + ".csi") and not os.path.exists(path + ".bai")
+    return path
+
+
+@pytest.mark.parametrize("min_shift,depth", [(14, 5), (12, 6), (16, 4)])
+@pytest.mark.parametrize("unphased", [False, True])
+def test_host_sweep_through_a_csi_index(tmp_path, orc, min_shift, depth, unphased):
+    bam, bed, loci, recs = _make_case(tmp_path, 21, ultra_long=True)
+    csi_bam = _reindex(tmp_path, bam, recs, min_shift, depth, "csi.sorted.bam")
+    fe = call.FrontEnd(csi_bam, region_file=bed, unphased=unphased, threads=3, max_batch_words=1500)
+    got1 = np.full(len(loci), -1.0)
+    got2 = np.full(len(loci), -1.0)
+    for batch, idx in fe.batches():
+        code, res = orc.call_batch(batch)
+        assert code == 0
+        got1[idx], got2[idx] = res.phase1, res.phase2
+    fe.close()
+    want1, want2 = _expected(loci, recs, unphased, 5, 3)
+    assert gen.same_f64(got1, want1) and gen.same_f64(got2, want2)
+
+
+def test_span_planner_through_a_csi_index(tmp_path, orc, monkeypatch):
+    """The device front end's host half (spans from the index, no GPU): every record a locus needs lies inside its span."""
+    from tests.test_host_spans import emulate_span
+
+    monkeypatch.setenv("INQ_SPAN_GAP_BYTES", "0")  # every gap between loci opens a new segment: anchors matter
+    bam, bed, loci, recs = _make_case(tmp_path, 22, block=1500)
+    csi_bam = _reindex(tmp_path, bam, recs, 14, 5, "csi2.sorted.bam", block=1500)  # small blocks: many segments
+    sp = call.Spans(csi_bam, region_file=bed, minlen=5, support=3, threads=2, unphased=False, max_comp_bytes=4000)
+    got1 = np.full(len(loci), np.nan)
+    got2 = np.full(len(loci), np.nan)
+    seen = np.zeros(len(loci), dtype=int)
+    for span in sp.spans():
+        batch = emulate_span(span)
+        code, res = orc.call_batch(batch)
+        assert code == 0
+        got1[span["locus_index"]], got2[span["locus_index"]] = res.phase1, res.phase2
+        seen[span["locus_index"]] += 1
+    assert seen.max() <= 1
+    want1, want2 = _expected(loci, recs, False, 5, 3)
+    assert gen.same_f64(got1, want1) and gen.same_f64(got2, want2)
+
+
+def test_csi_is_preferred_and_a_broken_one_is_an_error(tmp_path):
+    bam, bed, loci, recs = _make_case(tmp_path, 23, n_loci=5)
+    both = _reindex(tmp_path, bam, recs, 14, 5, "both.sorted.bam")
+    shutil.copy(both + ".csi", both + ".keep")
+    open(both + ".csi", "wb").write(b"not an index")
+    with pytest.raises(call.CallError) as e:  # IndexedReader::from_path panics on an unreadable index (src/call.rs:242-243)
+        call.FrontEnd(both, region_file=bed)
+    assert e.value.status == 101

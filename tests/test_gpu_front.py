@@ -210,6 +210,25 @@ def test_device_front_end_text_equals_host_front_end(tmp_path, seed, unphased, t
     assert texts["host"] == texts["device"] and texts["host"].count("\n") == len(loci) + 1
 
 
+def test_device_front_end_through_a_csi_index(tmp_path):
+    """A BAM that only has a .csi next to it ([3P] IndexedReader::from_path takes either index, src/call.rs:242): spans planned from
+    the .csi's bins and per-bin offsets; the text equals the host sweep's and the Python restatement's."""
+    from inquistr_amd import call
+    from tests.test_csi_index import _reindex
+    from tests.test_gpu_end_to_end import _expected_text
+    from tests.test_host_frontend import _make_case
+
+    bam, bed, loci, recs = _make_case(tmp_path, 31, n_loci=80)
+    csi_bam = _reindex(tmp_path, bam, recs, 14, 5, "only_csi.sorted.bam", block=3000)
+    texts = {}
+    for fe in ("host", "device"):
+        path = tmp_path / f"{fe}.inq"
+        with open(path, "w") as f:
+            call.genotype_repeats(csi_bam, None, bed, 5, 3, 3, False, "S", None, out=f, frontend=fe)
+        texts[fe] = path.read_text()
+    assert texts["host"] == texts["device"] == _expected_text(loci, recs, False, 5, 3, "S", 3)
+
+
 def test_device_front_end_error_classes(tmp_path):
     """The reference's panics that live in the record accessors keep their exit status through the device path."""
     from inquistr_amd import call

@@ -247,6 +247,39 @@ def test_long_cigars(ctx, orc):
     _assert_same(got, want)
 
 
+@pytest.mark.parametrize("unphased,support", [(False, 3), (True, 3), (False, 15_000), (True, 10_000)])
+def test_one_locus_of_100000_reads(ctx, orc, unphased, support):
+    """Amplicon depth: one locus offered 100 000 reads (plus two ordinary loci in the same batch).  The walk of such a locus is
+    spread over the whole grid, the reduce is a radix select over the per-read Calls in global memory; exact against the
+    oracle, per-pair outputs included.  support = 15 000 / 10 000 makes `spanning <= support` true at depth: the clip rule of
+    median_str_length (src/call.rs:509-513) then picks tens of thousands of soft-clipped Calls by value."""
+    import random
+    import time
+
+    rng = random.Random(77)
+    start, end = 500_000, 500_120
+    shapes = gen.random_locus_reads(rng, start, end, 300, long_every=13)
+    bb = B.BatchBuilder(minlen=5, support=support, unphased=unphased)
+    deep = []
+    for k in range(100_000):
+        r = shapes[rng.randrange(len(shapes))]
+        deep.append(bb.add_read(r.pos, B.encode_cigar(r.cigar), mapq=rng.choice([9, 30, 60, 60, 60]), phase=rng.choice([None, 0, 1, 1, 2, 2]),
+                                reverse=bool(r.flag & 0x10), is_2d=(k % 11 == 0)))
+    order = sorted(range(len(deep)), key=lambda i: (bb._reads[deep[i]][2], i))  # file order: by position, then insertion
+    bb.add_locus(start - 4000, start - 3900, deep[:40])
+    bb.add_locus(start, end, [deep[i] for i in order])
+    bb.add_locus(start + 9000, start + 9050, deep[100:130])
+    batch = bb.build()
+    t0 = time.perf_counter()
+    rc, got = ctx.call_batch(batch, debug=True)
+    dt = time.perf_counter() - t0
+    oc, want = orc.call_batch(batch, debug=True, threads=8)
+    assert rc == oc == 0
+    _assert_same(got, want, f"100k reads unphased={unphased} support={support}")
+    assert not np.isnan(got.phase2[1]), "the deep locus must yield a number for the test to mean anything"
+    assert dt < 2.0, f"{dt:.2f} s for the host-buffer call (upload + kernels + download)"
+
+
 def test_domain_errors(ctx, orc):
     def one(**kw):
         bb = B.BatchBuilder(**{k: v for k, v in kw.items() if k in ("minlen", "support", "unphased")})

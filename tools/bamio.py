@@ -105,7 +105,8 @@ class BamWriter:
         self.buf += block
         self.recs.append((u0, len(self.buf), tid, beg, end, flag))
 
-    def close(self, write_index: bool = True):
+    def close(self, write_index: bool = True, index: str = "bai", csi_min_shift: int = 14, csi_depth: int = 5):
+        """index: "bai", "csi" (BGZF-compressed CSI v1 with the given binning) or "both"."""
         data = bytes(self.buf)
         coff, out = [], bytearray()
         for i in range(0, max(len(data), 1), self.block):
@@ -122,8 +123,74 @@ class BamWriter:
                 return end_coff << 16
             return (coff[blk] << 16) | within
 
-        if write_index:
+        if write_index and index in ("bai", "both"):
             self._write_bai(vo)
+        if write_index and index in ("csi", "both"):
+            self._write_csi(vo, csi_min_shift, csi_depth)
+
+    def _write_csi(self, vo, min_shift: int, depth: int):
+        """[3P] htslib CSI v1: per bin the chunk list plus loffset = linear-index entry of the bin's first window, where the
+        linear index (one entry per 2^min_shift window, first record overlapping it) has its empty windows filled from the
+        NEXT filled one; metadata pseudo-bin as in a .bai; the whole file BGZF-compressed."""
+        def reg2bin(beg, end):
+            end -= 1
+            s, t = min_shift, ((1 << depth * 3) - 1) // 7
+            for l in range(depth, 0, -1):
+                if beg >> s == end >> s:
+                    return t + (beg >> s)
+                s += 3
+                t -= 1 << (l - 1) * 3
+            return 0
+
+        def bin_first_window(b):
+            l = 0
+            while b >= ((1 << 3 * (l + 1)) - 1) // 7:
+                l += 1
+            return (b - ((1 << 3 * l) - 1) // 7) << (3 * (depth - l))
+
+        nref = len(self.refs)
+        bins = [dict() for _ in range(nref)]
+        lin = [dict() for _ in range(nref)]
+        meta = [[None, None, 0, 0] for _ in range(nref)]
+        n_no_coor = 0
+        for u0, u1, tid, beg, end, flag in self.recs:
+            if tid < 0:
+                n_no_coor += 1
+                continue
+            v0, v1 = vo(u0), vo(u1)
+            ch = bins[tid].setdefault(reg2bin(max(beg, 0), max(end, 1)), [])
+            if ch and ch[-1][1] == v0:
+                ch[-1][1] = v1
+            else:
+                ch.append([v0, v1])
+            for w in range(max(beg, 0) >> min_shift, ((max(end, 1) - 1) >> min_shift) + 1):
+                lin[tid].setdefault(w, v0)
+            m = meta[tid]
+            m[0] = v0 if m[0] is None else min(m[0], v0)
+            m[1] = v1 if m[1] is None else max(m[1], v1)
+            m[3 if flag & 4 else 2] += 1
+        out = bytearray(b"CSI\1" + struct.pack("<iii", min_shift, depth, 0) + struct.pack("<i", nref))
+        meta_bin = ((1 << (depth + 1) * 3) - 1) // 7 + 1
+        for t in range(nref):
+            nwin = (max(lin[t]) + 1) if lin[t] else 0
+            filled, nxt = [0] * nwin, 0
+            for w in range(nwin - 1, -1, -1):
+                nxt = lin[t].get(w, nxt)
+                filled[w] = nxt
+            out += struct.pack("<i", len(bins[t]) + (1 if meta[t][0] is not None else 0))
+            for b in sorted(bins[t]):
+                w0 = bin_first_window(b)
+                out += struct.pack("<IQi", b, filled[w0] if w0 < nwin else 0, len(bins[t][b]))
+                for v0, v1 in bins[t][b]:
+                    out += struct.pack("<QQ", v0, v1)
+            if meta[t][0] is not None:
+                out += struct.pack("<IQi", meta_bin, 0, 2) + struct.pack("<QQQQ", meta[t][0], meta[t][1], meta[t][2], meta[t][3])
+        out += struct.pack("<Q", n_no_coor)
+        data = bytes(out)
+        with open(self.path + ".csi", "wb") as f:
+            for i in range(0, len(data), self.block):
+                f.write(bgzf_block(data[i : i + self.block], 6))
+            f.write(EOF_BLOCK)
 
     def _write_bai(self, vo):
         nref = len(self.refs)
