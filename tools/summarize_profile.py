@@ -72,7 +72,7 @@ json.dump(
 )
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary `{tag}` — bench.py --workload {workload} ({loci} loci/GPU)\n\n")
-    f.write("Command: `tools/profile_round.sh` = `rocprofv3 --kernel-trace --stats -- python3 bench.py` (the driver's command, defaults)\nplus separate `rocprofv3 --pmc …` passes around `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`.\n\n")
+    f.write("Command: `tools/profile_round.sh` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-l2` (the driver's command and defaults for the timed region; the legs that start other programs are left out under the profiler)\nplus separate `rocprofv3 --pmc …` passes around `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-l2`.\n\n")
     f.write("| kernel | dispatches | avg duration (µs) | min | max |\n|---|---|---|---|---|\n")
     for k, v in trace.items():
         f.write(f"| `{k}` | {len(v)} | {statistics.mean(v)/1e3:.1f} | {min(v)/1e3:.1f} | {max(v)/1e3:.1f} |\n")
