@@ -301,7 +301,10 @@ def main():
     gathered = [torch.empty(world, G, 2, per_gpu, dtype=torch.float64, device=gdev) for _ in range(2)] if (world > 1 and rank == 0) else None
     stage = [torch.empty(G, 2, per_gpu, dtype=torch.float64).pin_memory() for _ in range(2)] if (world > 1 and args.backend == "gloo") else None
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    main_stream = torch.cuda.current_stream()
+    # an explicit stream: torch's default stream has handle 0, which the C ABI reads as "the ctx's own stream" - the kernels would
+    # then run on a stream the events below know nothing about, and the gather of a group could read rows still being written
+    main_stream = torch.cuda.Stream(device=dev)
+    assert main_stream.cuda_stream != 0
     events = [torch.cuda.Event() for _ in range(2)]
 
     from inquistr_amd.batch import InqResultC
