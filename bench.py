@@ -139,7 +139,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         for m in "BAC":
             res[f"speedup_vs_{m}"] = res["gpu_cli_device_front"]["loci_per_s"] / res[f"cpu_{m}"]["loci_per_s"]
         res["note"] = ("speed-ups are ratios of loci/s; cpu_* = oracle/ref_shaped_call (CPU restatement in the reference's control "
-                       "flow, reading through this repo's BAM reader), not the Rust binary; A and C timed on a prefix of the targets")
+                       "flow with its own BGZF / BAM / BAI reader, oracle/minibam.h: no code shared with the product), not the Rust binary; A and C timed on a prefix of the targets")
         return res
     finally:
         import shutil
