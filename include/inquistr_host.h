@@ -37,7 +37,7 @@ typedef struct inq_call_args {
     const char *sample_name; /* --sample-name, NULL if absent */
     const char *reference;   /* --reference (CRAM only; CRAM is not supported here) */
     int32_t device;          /* HIP device ordinal (not a reference argument) */
-    int32_t reserved;        /* front end: 0 = auto (env INQ_FRONTEND=host|device, else device when the loci need >= 3 MiB of BAM per host thread), 1 = host sweep, 2 = device spans */
+    int32_t reserved;        /* front end: 0 = auto (env INQ_FRONTEND=host|device, else device when the loci need >= 1 MiB of BAM per host thread), 1 = host sweep, 2 = device spans */
 } inq_call_args_t;
 
 #define INQ_EXIT_OK 0

@@ -33,8 +33,9 @@ using namespace inqhost;
 
 // auto front-end choice: the device front end inflates a BGZF block per GPU lane, which takes ~40 ms however
 // few blocks there are; the CPU sweep inflates ~70 MB/s of BAM per thread.  Below this many compressed bytes
-// per host thread the sweep is quicker (48 MiB at -t 16, 3 MiB at -t 1).
-static constexpr uint64_t kDeviceFrontMinBytesPerThread = 3ull << 20;
+// per host thread the sweep is as quick (16 MiB at -t 16, 1 MiB at -t 1; round 1's lane-per-block inflate put the line at 3 MiB:
+// profiles/r02_results/front_end_choice.txt).
+static constexpr uint64_t kDeviceFrontMinBytesPerThread = 1ull << 20;
 
 namespace {
 
