@@ -43,7 +43,10 @@ namespace inq {
 namespace {
 
 constexpr int kLitBits = 10, kDistBits = 8;
-constexpr uint32_t kSegBits = 256;  // compressed bits per lane and round
+#ifndef INQ_WG_SEGBITS
+#define INQ_WG_SEGBITS 256
+#endif
+constexpr uint32_t kSegBits = INQ_WG_SEGBITS;  // compressed bits per lane and round (a multiple of 32, > the longest symbol's 48)
 constexpr int kMaxLit = 288, kMaxDist = 32;
 
 constexpr uint32_t E_LIT = 0u, E_LEN = 1u, E_EOB = 2u, E_LONG = 3u;
@@ -72,7 +75,8 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t n) {
 
 template <int T>
 struct WgLds {
-    static constexpr int kStage = 8 * T + 8;        // dwords: T segments of 32 bytes + look-ahead
+    // dwords: T segments + look-ahead; never less than a dynamic block's header (<= ~600 bytes), which is parsed from it too
+    static constexpr int kStage = (T * (int)kSegBits / 32 + 8) > 264 ? (T * (int)kSegBits / 32 + 8) : 264;
 #ifndef INQ_WG_CAP
 #define INQ_WG_CAP 4096
 #endif
@@ -84,6 +88,7 @@ struct WgLds {
     // (a literal points at itself), < 32768 = a byte of an earlier round (deflate distances are <= 32768)
     uint16_t root[kRoundCap];
     uint32_t end_bit[T];   // per lane: where its chain left its segment, | kFlagBit if it stopped (EOB / not a code)
+    uint32_t off_sh[T + 1];  // per lane: first output byte of its chain, relative to the round's; [T] = the round's bytes
     uint16_t sorted[kMaxLit + kMaxDist];  // symbols by (code length, value): literal/length, then distance
     uint32_t limit[2][16], base[2][16], cnt[2][16], run[2][16];
     uint8_t lens[kMaxLit + kMaxDist];
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
     // dev-time probe (debug_flags & 8): per block {deflate blocks, rounds, count passes, match sweeps, kilo-cycles in
     // header+tables, counting, commit, matches} into block_status[8 * bi ..] for bi < n_blocks / 8
     uint32_t dbg_n[4] = {0, 0, 0, 0};
-    uint64_t dbg_c[4] = {0, 0, 0, 0}, dbg_t = clock64();
+    uint64_t dbg_c[5] = {0, 0, 0, 0, 0}, dbg_t = clock64();
 #define DBG_N(i) ++dbg_n[i]
 #define DBG_LAP(i) { const uint64_t now_ = clock64(); dbg_c[i] += now_ - dbg_t; dbg_t = now_; }
 #else
@@ -583,9 +588,10 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
             for (int s = tid; s < 32; s += T) L.lens[kMaxLit + s] = 5;
             __syncthreads();
         }
+        DBG_LAP(0);
         build_tables<T>(L, tid);
         DBG_N(0);
-        DBG_LAP(0);
+        DBG_LAP(4);
         if (L.status) break;
 
         // ================= rounds: T segments of 256 compressed bits each
@@ -623,90 +629,101 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
                 DBG_N(2);
                 __syncthreads();  // end_bit[] read by everyone before it is rewritten
             }
-            // ---- places in the output; the round is cut at the first lane whose bytes would leave the root array
+            // ---- places in the output
             if ((uint32_t)tid >= ncommit) nbytes = 0u;
             uint32_t off_b, tot_b, dummy0, dummy1;
             wg_scan2<T>(nbytes, 0u, off_b, dummy0, tot_b, dummy1, L.red, L.red2);
-            bool lone = false;  // lane 0 alone exceeds the array: it writes its literals and matches in order by itself
-            if (tot_b > (uint32_t)WgLds<T>::kRoundCap) {
-                const uint32_t keep = wg_min<T>(off_b + nbytes > (uint32_t)WgLds<T>::kRoundCap ? (uint32_t)tid : 0xffffu, L.red);
-                lone = keep == 0u;
-                ncommit = lone ? 1u : (keep < ncommit ? keep : ncommit);
-                if ((uint32_t)tid >= ncommit) nbytes = 0u;
-                wg_scan2<T>(nbytes, 0u, off_b, dummy0, tot_b, dummy1, L.red, L.red2);
-            }
-            const bool committed = (uint32_t)tid < ncommit;
-            DBG_LAP(1);
-            if (tot_b > isize - out0) bad |= INQ_INFLATE_OUTPUT_SIZE;  // uniform
-            // ---- commit: literals to the output, roots of all bytes to LDS
-            if (committed && bad == 0u) {
-                uint32_t nb2;
-                if (lone) (void)decode_segment<T, 2>(L, start, seg_end, nb2, out, out0 + off_b, out0, bad);
-                else (void)decode_segment<T, 1>(L, start, seg_end, nb2, out, out0 + off_b, out0, bad);
-            }
-            if (committed && tid == (int)ncommit - 1) {  // the last committed chain: where the next round starts, and why this one ended
+            L.off_sh[tid] = off_b;
+            if (tid == 0) L.off_sh[T] = tot_b;
+            if (tid == (int)ncommit - 1) {  // the last chain of the round: where the next round starts, and why this one ended
                 const uint32_t stop = end & (kStopped | kStopEob);
                 if (stop == kStopped) bad |= INQ_INFLATE_BAD_CODE;
                 L.P = (base_dw << 5) + (end & 0x3fffffffu);
                 L.eob = stop == (kStopped | kStopEob);
                 L.out = out0 + tot_b;
             }
+            if (tot_b > isize - out0) bad |= INQ_INFLATE_OUTPUT_SIZE;  // uniform
             if (bad) atomicOr(&L.status, bad);
-            __syncthreads();  // literals (global) and roots (LDS) are visible to the workgroup
-            DBG_LAP(2);
+            __syncthreads();
+            DBG_LAP(1);
             if (L.status) break;
-            // ---- matches: shorten every chain to its root by pointer jumping, then one gather
-            if (!lone) {
-                // four consecutive bytes per lane and step (one 8-byte LDS access for their roots)
-                const uint32_t n4 = (tot_b + 3u) >> 2;
-                for (int sweep = 0; sweep < 16; ++sweep) {  // chains hop to an earlier lane's stretch each time: <= log2(T) + 1 sweeps
-                    if (tid == 0) L.flag = 0u;
-                    __syncthreads();
-                    bool changed = false;
+            // ---- commit, in stretches of lanes whose bytes fit the root array: the round is counted once, whatever it inflates to
+            uint32_t k0 = 0;
+            while (k0 < ncommit) {
+                const uint32_t r_lo = L.off_sh[k0];
+                // k1 = first lane at or behind k0 whose bytes end beyond the array
+                const bool over = (uint32_t)tid >= k0 && (uint32_t)tid < ncommit && off_b + nbytes - r_lo > (uint32_t)WgLds<T>::kRoundCap;
+                uint32_t k1 = wg_min<T>(over ? (uint32_t)tid : 0xffffu, L.red);
+                const bool lone = k1 == k0;  // a single lane exceeds the array: it writes its literals and matches in order by itself
+                if (k1 == 0xffffu) k1 = ncommit;
+                if (lone) k1 = k0 + 1u;
+                const uint32_t r_hi = k1 < ncommit ? L.off_sh[k1] : tot_b;
+                const uint32_t r0 = out0 + r_lo, nbytes_s = r_hi - r_lo;
+                uint32_t cbad = 0;
+                if ((uint32_t)tid >= k0 && (uint32_t)tid < k1) {
+                    uint32_t nb2;
+                    if (lone) (void)decode_segment<T, 2>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
+                    else (void)decode_segment<T, 1>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
+                }
+                if (cbad) atomicOr(&L.status, cbad);
+                __syncthreads();  // literals (global) and roots (LDS) are visible to the workgroup
+                DBG_LAP(2);
+                if (L.status) break;
+                // ---- matches: shorten every chain to its root by pointer jumping, then one gather
+                if (!lone) {
+                    // four consecutive bytes per lane and step (one 8-byte LDS access for their roots)
+                    const uint32_t n4 = (nbytes_s + 3u) >> 2;
+                    for (int sweep = 0; sweep < 16; ++sweep) {  // chains hop to an earlier lane's bytes each time: <= log2(T) + 1 sweeps
+                        if (tid == 0) L.flag = 0u;
+                        __syncthreads();
+                        bool changed = false;
+                        for (uint32_t g = (uint32_t)tid; g < n4; g += T) {
+                            uint64_t w;
+                            __builtin_memcpy(&w, &L.root[4u * g], 8);  // the array is a multiple of 4 long
+                            const uint32_t r0_ = (uint32_t)w & 0xffffu, r1_ = (uint32_t)(w >> 16) & 0xffffu, r2_ = (uint32_t)(w >> 32) & 0xffffu,
+                                           r3_ = (uint32_t)(w >> 48);
+                            // a literal's root is itself, so following it changes nothing; bytes behind nbytes_s hold stale roots of
+                            // an earlier stretch: following them is harmless (bounded index), and nobody reads them
+                            const uint32_t a0 = r0_ >= 32768u ? L.root[(r0_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r0_;
+                            const uint32_t a1 = r1_ >= 32768u ? L.root[(r1_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r1_;
+                            const uint32_t a2 = r2_ >= 32768u ? L.root[(r2_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r2_;
+                            const uint32_t a3 = r3_ >= 32768u ? L.root[(r3_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r3_;
+                            const uint64_t nw = (uint64_t)a0 | ((uint64_t)a1 << 16) | ((uint64_t)a2 << 32) | ((uint64_t)a3 << 48);
+                            if (nw != w) {
+                                __builtin_memcpy(&L.root[4u * g], &nw, 8);
+                                changed = true;
+                            }
+                        }
+                        if (changed) L.flag = 1u;
+                        DBG_N(3);
+                        __syncthreads();
+                        if (L.flag == 0u) break;
+                        __syncthreads();
+                    }
+                    const uint8_t *from = out + r0 - 32768;  // root r lives at from[r]; never dereferenced in front of the block (distance check)
+                    uint8_t *dstb = out + r0;
                     for (uint32_t g = (uint32_t)tid; g < n4; g += T) {
+                        const uint32_t q = 4u * g;
                         uint64_t w;
-                        __builtin_memcpy(&w, &L.root[4u * g], 8);  // the array is a multiple of 4 long
+                        __builtin_memcpy(&w, &L.root[q], 8);
                         const uint32_t r0_ = (uint32_t)w & 0xffffu, r1_ = (uint32_t)(w >> 16) & 0xffffu, r2_ = (uint32_t)(w >> 32) & 0xffffu,
                                        r3_ = (uint32_t)(w >> 48);
-                        // a literal's root is itself, so following it changes nothing; bytes behind tot_b hold stale roots of
-                        // an earlier round: following them is harmless (bounded index), and nobody reads them
-                        const uint32_t a0 = r0_ >= 32768u ? L.root[(r0_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r0_;
-                        const uint32_t a1 = r1_ >= 32768u ? L.root[(r1_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r1_;
-                        const uint32_t a2 = r2_ >= 32768u ? L.root[(r2_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r2_;
-                        const uint32_t a3 = r3_ >= 32768u ? L.root[(r3_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r3_;
-                        const uint64_t nw = (uint64_t)a0 | ((uint64_t)a1 << 16) | ((uint64_t)a2 << 32) | ((uint64_t)a3 << 48);
-                        if (nw != w) {
-                            __builtin_memcpy(&L.root[4u * g], &nw, 8);
-                            changed = true;
+                        const uint32_t self = q + 32768u;
+                        if (q + 4u <= nbytes_s && r1_ == r0_ + 1u && r2_ == r0_ + 2u && r3_ == r0_ + 3u) {
+                            if (r0_ != self) st_u32(dstb + q, ld_u32(from + r0_));  // four bytes of one match, or four literals (nothing to do)
+                        } else {
+                            if (q < nbytes_s && r0_ != self) dstb[q] = from[r0_];
+                            if (q + 1u < nbytes_s && r1_ != self + 1u) dstb[q + 1u] = from[r1_];
+                            if (q + 2u < nbytes_s && r2_ != self + 2u) dstb[q + 2u] = from[r2_];
+                            if (q + 3u < nbytes_s && r3_ != self + 3u) dstb[q + 3u] = from[r3_];
                         }
                     }
-                    if (changed) L.flag = 1u;
-                    DBG_N(3);
-                    __syncthreads();
-                    if (L.flag == 0u) break;
-                    __syncthreads();
                 }
-                const uint8_t *from = out + out0 - 32768;  // root r lives at from[r]; never dereferenced in front of the block (distance check)
-                uint8_t *dstb = out + out0;
-                for (uint32_t g = (uint32_t)tid; g < n4; g += T) {
-                    const uint32_t q = 4u * g;
-                    uint64_t w;
-                    __builtin_memcpy(&w, &L.root[q], 8);
-                    const uint32_t r0_ = (uint32_t)w & 0xffffu, r1_ = (uint32_t)(w >> 16) & 0xffffu, r2_ = (uint32_t)(w >> 32) & 0xffffu,
-                                   r3_ = (uint32_t)(w >> 48);
-                    const uint32_t self = q + 32768u;
-                    if (q + 4u <= tot_b && r1_ == r0_ + 1u && r2_ == r0_ + 2u && r3_ == r0_ + 3u) {
-                        if (r0_ != self) st_u32(dstb + q, ld_u32(from + r0_));  // four bytes of one match, or four literals (nothing to do)
-                    } else {
-                        if (q < tot_b && r0_ != self) dstb[q] = from[r0_];
-                        if (q + 1u < tot_b && r1_ != self + 1u) dstb[q + 1u] = from[r1_];
-                        if (q + 2u < tot_b && r2_ != self + 2u) dstb[q + 2u] = from[r2_];
-                        if (q + 3u < tot_b && r3_ != self + 3u) dstb[q + 3u] = from[r3_];
-                    }
-                }
+                __syncthreads();  // the stretch is final before the next one roots into it
+                DBG_LAP(3);
+                k0 = k1;
             }
-            __syncthreads();
-            DBG_LAP(3);
+            if (L.status) break;
             if (L.eob) break;
             if (L.P > payload_bits) {  // a round that ran off the payload without meeting end-of-block
                 if (tid == 0) L.status = INQ_INFLATE_INPUT_OVERRUN;
@@ -723,14 +740,22 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
             if (L.out != isize) st = INQ_INFLATE_OUTPUT_SIZE;
             else if (L.P > payload_bits) st = INQ_INFLATE_INPUT_OVERRUN;
         }
+#ifdef INQ_INFLATE_DEBUG_ENV
+        if (!(a.debug_flags & 8u))
+#endif
         if (a.block_status) a.block_status[bi] = st;
         if (st) atomicOr(a.err, st);
     }
 #ifdef INQ_INFLATE_DEBUG_ENV
-    if ((a.debug_flags & 8u) && a.block_status) {
+    if ((a.debug_flags & 8u) && a.block_status) {  // {deflate blocks, rounds, count passes, kcyc header parse, tables, counting, commit, matches}
         __syncthreads();
-        if (tid == 0 && bi < a.n_blocks / 8)
-            for (int k = 0; k < 4; ++k) a.block_status[8 * bi + k] = dbg_n[k], a.block_status[8 * bi + 4 + k] = (uint32_t)(dbg_c[k] >> 10);
+        if (tid == 0 && bi < a.n_blocks / 8) {
+            uint32_t *o = a.block_status + 8 * bi;
+            o[0] = dbg_n[0], o[1] = dbg_n[1], o[2] = dbg_n[2];
+            o[3] = (uint32_t)(dbg_c[0] >> 10), o[4] = (uint32_t)(dbg_c[4] >> 10), o[5] = (uint32_t)(dbg_c[1] >> 10), o[6] = (uint32_t)(dbg_c[2] >> 10),
+            o[7] = (uint32_t)(dbg_c[3] >> 10);
+        }
+        if (tid == 0 && bi >= a.n_blocks / 8) (void)0;
     }
 #endif
 }

@@ -59,7 +59,7 @@ def main():
     if os.environ.get("INQ_INFLATE_DEBUG"):
         if int(os.environ["INQ_INFLATE_DEBUG"]) & 8:
             v = st[: len(st) // 8 * 8].reshape(-1, 8).astype(np.float64)
-            names = ["deflate blocks", "rounds", "count passes", "match sweeps", "kcyc header+tables", "kcyc counting", "kcyc commit", "kcyc matches"]
+            names = ["deflate blocks", "rounds", "count passes", "kcyc header parse", "kcyc tables", "kcyc counting", "kcyc commit", "kcyc matches"]
             for k, nm in enumerate(names):
                 print(f"  {nm}: mean {v[:, k].mean():.1f} median {np.median(v[:, k]):.1f} max {v[:, k].max():.0f}")
         if int(os.environ["INQ_INFLATE_DEBUG"]) & 4:
