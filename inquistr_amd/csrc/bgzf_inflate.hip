@@ -617,10 +617,10 @@ __global__ __launch_bounds__(kLanes) void bgzf_crc32_kernel(InflateArgs a) {
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s) {
     if (!a.n_blocks) return;
     const uint64_t grid = (a.n_blocks + kLanes - 1) / kLanes;
-    // Two kernels, one job.  A workgroup per block (bgzf_inflate_wg.hip) costs ~1.1 ms per 1000 blocks and has no floor; a lane
-    // per block (this file) takes 36-45 ms for anything up to ~60 000 blocks, whatever their number.  Measured crossover
-    // (BAM-like and quality-like data, profiles/r02_inflate/): ~35 000 blocks.
-    const bool wg = a.algo == 0u || (a.algo == 2u && a.n_blocks <= 35000u);
+    // Two kernels, one job.  A workgroup per block (bgzf_inflate_wg.hip) costs 0.85-1.2 ms per 1000 blocks and has no floor; a
+    // lane per block (this file) takes 36-56 ms for anything up to ~65 000 blocks, whatever their number.  Measured crossover
+    // (profiles/r02_front/README.md): ~50 000 blocks of BAM-like data, ~42 000 of quality-like bytes.
+    const bool wg = a.algo == 0u || (a.algo == 2u && a.n_blocks <= 45000u);
     if (wg) launch_bgzf_inflate_wg(a, s);
     else hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
     if (a.verify_crc) hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
