@@ -29,7 +29,8 @@ def test_host_front_end_under_asan_ubsan():
     env["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=1"
     env["UBSAN_OPTIONS"] = "halt_on_error=1:print_stacktrace=1"
     env["INQ_HOST_LIB"] = os.path.join(ROOT, "inquistr_amd", "lib", "libinquistr_host_asan.so")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_host_frontend.py", "tests/test_host_spans.py", "tests/test_outlier_oracle.py", "-x", "-q", "-k", "not cli",
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_host_frontend.py", "tests/test_host_spans.py", "tests/test_outlier_oracle.py", "tests/test_csi_index.py",
+                        "tests/test_error_class.py", "-x", "-q", "-k", "not cli",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout
