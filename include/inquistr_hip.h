@@ -207,8 +207,8 @@ typedef struct inq_bgzf_block {
 #define INQ_INFLATE_BAD_STORED 0x20u    /* stored block LEN / NLEN mismatch                                    */
 #define INQ_INFLATE_BAD_CRC 0x40u       /* inflated bytes do not match the CRC32 of the block's trailer        */
 
-/* Inflates n_blocks BGZF payloads; every pointer is HOST memory (the call uploads, runs one lane per
- * block, downloads, synchronises).  block_status may be NULL.  Returns INQ_ERR_INFLATE if any block
+/* Inflates n_blocks BGZF payloads; every pointer is HOST memory (the call uploads, runs one workgroup or one
+ * lane per block - ctx option "inflate_algo" -, downloads, synchronises).  block_status may be NULL.  Returns INQ_ERR_INFLATE if any block
  * failed.  `comp` holds whole BGZF blocks: the 8 bytes behind every payload are its CRC32 / ISIZE trailer,
  * and the inflated bytes are checked against that CRC32 as htslib does (ctx option "verify_crc", default 1). */
 int inq_bgzf_inflate(inq_ctx_t *ctx, const uint8_t *comp, uint64_t comp_bytes, const inq_bgzf_block_t *blocks,
