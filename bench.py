@@ -356,7 +356,10 @@ def main():
         n = state["n"]
         b, g = (n // G) & 1, n % G
         if world > 1 and g == 0 and len(pending) >= 2:
-            pending.pop(0).wait()  # the group buffer b is free again
+            # the group buffer b is free again once its gather is done.  An NCCL work's wait() orders the CURRENT stream behind
+            # the collective (it does not block the host), so it has to be called with the compute stream current.
+            with torch.cuda.stream(main_stream):
+                pending.pop(0).wait()
         ctx.call_batch_device(shard.c_batch, results[b][g], main_stream.cuda_stream)
         state["n"] = n + 1
         if world > 1 and g == G - 1:
@@ -371,8 +374,9 @@ def main():
 
     def drain():
         flush()
-        while pending:
-            pending.pop(0).wait()
+        with torch.cuda.stream(main_stream):
+            while pending:
+                pending.pop(0).wait()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
