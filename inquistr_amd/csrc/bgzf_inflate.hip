@@ -24,6 +24,7 @@
 
 #include "../../include/inquistr_hip.h"
 #include "front_kernels.h"
+#include "wave_primitives.h"
 
 namespace inq {
 
@@ -565,17 +566,76 @@ __global__ __launch_bounds__(kLanes) void bgzf_inflate_kernel(InflateArgs a) {
 
 // ---------------------------------------------------------------- CRC32 of the inflated blocks
 // htslib checks every block against the CRC32 in its trailer ([3P] bgzf.c check_header / inflate_block);
-// a mismatch is a read error, i.e. a panic in the reference (src/call.rs:295,346).  One lane per block
-// again: slice-by-4 with the 4 KB table shared by the workgroup in LDS, 16 bytes per load.
-__global__ __launch_bounds__(kLanes) void bgzf_crc32_kernel(InflateArgs a) {
-    __shared__ uint32_t T[4][256];
-    for (int i = (int)threadIdx.x; i < 256; i += kLanes) {
+// a mismatch is a read error, i.e. a panic in the reference (src/call.rs:295,346).  One WAVE per block (round 1: one lane
+// per block, 1.4 ms for any number of blocks).  With the register starting at 0 the CRC is linear in the bytes, so every lane
+// can run over its own 16-byte granules (granule g belongs to lane g mod 64: a wave-instruction reads 1 KB of contiguous
+// memory) as if all other bytes were zero: between two of its granules the register just travels through 1008 zero bytes,
+// which is one lookup in four 256-entry tables, like a data word.  At the end lane i's register is moved through the
+// zero bytes between its last granule and the end of the block and the 64 registers are XORed.  Moving a register through
+// 2^k zero bytes is a 32 x 32 bit matrix over GF(2) (kCrcShift, squared up from the one-bit operator at compile time, as
+// zlib's crc32_combine does at run time); the initial 0xffffffff enters as its own journey through the block's length.
+struct CrcShift {
+    uint32_t m[17][32];  // m[k] = the register moved through 2^k zero bytes, column by column
+    uint32_t skip[32];   // ... through 1008 = 16 + 32 + ... + 512 zero bytes (from one granule of a lane to its next)
+};
+constexpr void gf2_square(const uint32_t (&in)[32], uint32_t (&out)[32]) {
+    for (int j = 0; j < 32; ++j) {
+        uint32_t v = in[j], sum = 0;
+        for (int i = 0; v; ++i, v >>= 1)
+            if (v & 1u) sum ^= in[i];
+        out[j] = sum;
+    }
+}
+constexpr CrcShift make_crc_shift() {
+    CrcShift t{};
+    uint32_t cur[32] = {}, nxt[32] = {};
+    cur[0] = 0xEDB88320u;  // one zero BIT: x -> (x >> 1) ^ (poly if x & 1)
+    for (int j = 1; j < 32; ++j) cur[j] = 1u << (j - 1);
+    for (int sq = 0; sq < 3 + 17; ++sq) {  // squaring: 1 bit -> 2 -> 4 -> 8 bits = 1 byte = m[0], then m[k + 1] = m[k]^2
+        if (sq >= 3)
+            for (int j = 0; j < 32; ++j) t.m[sq - 3][j] = cur[j];
+        gf2_square(cur, nxt);
+        for (int j = 0; j < 32; ++j) cur[j] = nxt[j];
+    }
+    // skip = m[9] o m[8] o ... o m[4]: the image of every basis vector under the six operators in turn (they commute)
+    for (int j = 0; j < 32; ++j) {
+        uint32_t v = 1u << j;
+        for (int k = 4; k <= 9; ++k) {
+            uint32_t sum = 0, w = v;
+            for (int i = 0; w; ++i, w >>= 1)
+                if (w & 1u) sum ^= t.m[k][i];
+            v = sum;
+        }
+        t.skip[j] = v;
+    }
+    return t;
+}
+__constant__ CrcShift kCrcShift = make_crc_shift();
+
+__device__ __forceinline__ uint32_t crc_shift(uint32_t v, int k) {  // v moved through 2^k zero bytes
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) sum ^= kCrcShift.m[k][i] & (0u - ((v >> i) & 1u));
+    return sum;
+}
+
+__global__ __launch_bounds__(256) void bgzf_crc32_kernel(InflateArgs a) {
+    __shared__ uint32_t T[4][256];  // slice-by-4: a data word
+    __shared__ uint32_t S[4][256];  // the same shape for "1008 zero bytes"
+    {
+        const int i = (int)threadIdx.x;
         uint32_t c = (uint32_t)i;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
         T[0][i] = c;
+        for (int t = 0; t < 4; ++t) {  // S[t][i] = skip applied to i << 8t: eight columns
+            uint32_t sum = 0;
+            for (int bit = 0; bit < 8; ++bit) sum ^= kCrcShift.skip[8 * t + bit] & (0u - (((uint32_t)i >> bit) & 1u));
+            S[t][i] = sum;
+        }
     }
     __syncthreads();
-    for (int i = (int)threadIdx.x; i < 256; i += kLanes) {
+    {
+        const int i = (int)threadIdx.x;
         uint32_t c = T[0][i];
         for (int t = 1; t < 4; ++t) {
             c = T[0][c & 0xffu] ^ (c >> 8);
@@ -583,34 +643,56 @@ __global__ __launch_bounds__(kLanes) void bgzf_crc32_kernel(InflateArgs a) {
         }
     }
     __syncthreads();
-    const uint64_t bi = (uint64_t)blockIdx.x * kLanes + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t bi = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (bi >= a.n_blocks) return;
     const inq_bgzf_block_t blk = a.blocks[bi];
     // blocks the inflate kernel rejected keep their status; extents were checked there
     if (a.block_status && a.block_status[bi]) return;
     if (blk.comp_off > a.comp_bytes || (uint64_t)blk.comp_len + 8u > a.comp_bytes - blk.comp_off || blk.out_off > a.out_bytes ||
-        (uint64_t)blk.isize > a.out_bytes - blk.out_off)
+        (uint64_t)blk.isize > a.out_bytes - blk.out_off || blk.isize > 65536u)
         return;
     const uint8_t *p = a.out + blk.out_off;
     const uint32_t n = blk.isize;
-    uint32_t crc = 0xffffffffu, k = 0;
+    uint32_t crc = 0u, at = 16u * lane, done_to = 0u;  // done_to = end of this lane's last granule
     auto word = [&](uint32_t w) {
         crc ^= w;
         crc = T[3][crc & 0xffu] ^ T[2][(crc >> 8) & 0xffu] ^ T[1][(crc >> 16) & 0xffu] ^ T[0][crc >> 24];
     };
-    for (; k + 16u <= n; k += 16u) {
-        const uint32_t w0 = load_u32(p + k), w1 = load_u32(p + k + 4), w2 = load_u32(p + k + 8), w3 = load_u32(p + k + 12);
+    auto skip = [&]() { crc = S[0][crc & 0xffu] ^ S[1][(crc >> 8) & 0xffu] ^ S[2][(crc >> 16) & 0xffu] ^ S[3][crc >> 24]; };
+    for (; at + 16u <= n; at += 1024u) {
+        const uint32_t w0 = load_u32(p + at), w1 = load_u32(p + at + 4), w2 = load_u32(p + at + 8), w3 = load_u32(p + at + 12);
+        if (done_to) skip();
         word(w0);
         word(w1);
         word(w2);
         word(w3);
+        done_to = at + 16u;
     }
-    for (; k < n; ++k) crc = T[0][(crc ^ p[k]) & 0xffu] ^ (crc >> 8);
-    crc = ~crc;
-    const uint32_t want = load_u32(a.comp + blk.comp_off + blk.comp_len);
-    if (crc != want) {
-        if (a.block_status) a.block_status[bi] = INQ_INFLATE_BAD_CRC;
-        atomicOr(a.err, INQ_INFLATE_BAD_CRC);
+    if (at < n) {  // the block's last, partial granule
+        if (done_to) skip();
+        for (uint32_t k = at; k < n; ++k) crc = T[0][(crc ^ p[k]) & 0xffu] ^ (crc >> 8);
+        done_to = n;
+    }
+    // through the zero bytes behind the lane's last granule (fewer than 1024), then XOR over the wave
+    {
+        const uint32_t rest = done_to ? n - done_to : 0u;
+        for (int bit = 0; bit < 10; ++bit)
+            if (ballot64(((rest >> bit) & 1u) != 0u))  // wave-uniform branch around the 32-step product
+                crc = ((rest >> bit) & 1u) ? crc_shift(crc, bit) : crc;
+    }
+    for (int off = 32; off; off >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, off);
+    // the register starts at 0xffffffff: its journey through n bytes, by the binary digits of n
+    uint32_t init = 0xffffffffu;
+    for (int bit = 0; bit < 17; ++bit)
+        if ((n >> bit) & 1u) init = crc_shift(init, bit);
+    crc = ~(crc ^ init);
+    if (lane == 0u) {
+        const uint32_t want = load_u32(a.comp + blk.comp_off + blk.comp_len);
+        if (crc != want) {
+            if (a.block_status) a.block_status[bi] = INQ_INFLATE_BAD_CRC;
+            atomicOr(a.err, INQ_INFLATE_BAD_CRC);
+        }
     }
 }
 
@@ -623,7 +705,7 @@ void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s) {
     const bool wg = a.algo == 0u || (a.algo == 2u && a.n_blocks <= 45000u);
     if (wg) launch_bgzf_inflate_wg(a, s);
     else hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
-    if (a.verify_crc) hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
+    if (a.verify_crc) hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((uint32_t)((a.n_blocks + 3) / 4)), dim3(256), 0, s, a);
 }
 
 // An empty launch makes the runtime load this translation unit's code object now (inq_ctx_create, on the
