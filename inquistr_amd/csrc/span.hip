@@ -26,6 +26,11 @@ struct SpanState {
         uint64_t val[4];
         unsigned long long init_n_valid;
     } *h = nullptr;
+    // pinned staging of the rows: the caller's result arrays are ordinary memory, and the FIRST copy to or from pageable
+    // memory costs the runtime 7-20 ms (it builds its own staging then): rows go through this buffer instead
+    double *h_rows = nullptr;
+    size_t h_rows_cap = 0;  // in doubles
+    bool copy_path_warm = false;  // the runtime sets up its device-to-host copy path at the first copy of some size (~8 ms)
     hipEvent_t ev[6] = {};
     bool have_ev = false;
     // inq_span_stage: compressed bytes + block table + anchors of up to three spans, uploaded on their own
@@ -37,6 +42,7 @@ struct SpanState {
         bool valid = false;
     } stage[3];
     hipStream_t copy_stream = nullptr;
+    hipStream_t warm_stream = nullptr;  // the one warm-up copy below: the copy stream may be busy uploading the next span
     // the batch the last inq_call_span built
     uint64_t n_reads = 0, n_cigar_words = 0, n_pairs = 0, n_loci = 0;
 };
@@ -57,8 +63,10 @@ void span_state_destroy(SpanState *S) {
         for (DevBuf *b : {&g.comp, &g.blocks, &g.anchors, &g.anchor_stop})
             if (b->p) (void)hipFree(b->p);
     if (S->copy_stream) (void)hipStreamDestroy(S->copy_stream);
+    if (S->warm_stream) (void)hipStreamDestroy(S->warm_stream);
     if (S->d_st) (void)hipFree(S->d_st);
     if (S->h) (void)hipHostFree(S->h);
+    if (S->h_rows) (void)hipHostFree(S->h_rows);
     if (S->have_ev)
         for (auto &e : S->ev) (void)hipEventDestroy(e);
     delete S;
@@ -77,6 +85,7 @@ int inq::span_state_init(inq_ctx *c) {
     for (auto &e : S->ev) HIP_TRY(c, hipEventCreate(&e));
     S->have_ev = true;
     HIP_TRY(c, hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&S->warm_stream, hipStreamNonBlocking));
     return INQ_OK;
 }
 
@@ -253,6 +262,20 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     launch_chain_count(a, s);
     launch_scan_u32_to_u64(a.anchor_cnt, a.anchor_base, na, (uint64_t *)S->tmp.p, s);
     HIP_TRY(c, hipGetLastError());
+    if (S->h_rows_cap < 2 * nl) {
+        if (S->h_rows) (void)hipHostFree(S->h_rows);
+        S->h_rows = nullptr;
+        S->h_rows_cap = 0;
+        const size_t want = std::max<size_t>(2 * nl + nl / 2 + 1024, 1u << 16);
+        HIP_TRY(c, hipHostMalloc((void **)&S->h_rows, want * sizeof(double), hipHostMallocDefault));
+        S->h_rows_cap = want;
+    }
+    if (!S->copy_path_warm && u_bytes >= (512u << 10)) {
+        // the first device-to-host copy of this size costs the host ~8 ms inside the runtime; spent here, on another stream,
+        // it hides behind the inflate that was just enqueued instead of sitting behind the last kernel of the span
+        HIP_TRY(c, hipMemcpyAsync(S->h_rows, S->u.p, 512u << 10, hipMemcpyDeviceToHost, S->warm_stream));
+        S->copy_path_warm = true;
+    }
     HIP_TRY(c, hipMemcpyAsync(&S->h->val[0], a.anchor_base + na, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -352,13 +375,16 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     c->call_hint = std::max<uint32_t>(S->h->st.max_reads, 1u);
     if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(S->ev[5], s));
-    HIP_TRY(c, hipMemcpyAsync(r->phase1, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(r->phase2, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(S->warm_stream));  // the warm-up copy (long done) must not land in the rows
+    HIP_TRY(c, hipMemcpyAsync(S->h_rows, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(S->h_rows + nl, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&S->h->ks, c->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemsetAsync(&c->d_status->err, 0, sizeof(unsigned int), s));
     HIP_TRY(c, hipMemsetAsync(&c->d_status->ties, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    std::memcpy(r->phase1, S->h_rows, nl * 8);
+    std::memcpy(r->phase2, S->h_rows + nl, nl * 8);
     wall("call done");
     S->n_reads = n_valid;
     S->n_cigar_words = n_units * 4;
