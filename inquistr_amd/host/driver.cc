@@ -278,6 +278,7 @@ public:
         for (int i = 0; i < 3; ++i) slots_[i].slot = i;
         for (auto &it : slots_) free_.push_back(&it);
         th_ = std::thread([this] { run(); });
+        if (stage_) up_ = std::thread([this] { run_uploads(); });  // span k uploads while span k + 1 is being read
     }
     ~SpanPipeline() {
         {
@@ -285,7 +286,9 @@ public:
             stop_ = true;
         }
         cv_free_.notify_all();
+        cv_loaded_.notify_all();
         th_.join();
+        if (up_.joinable()) up_.join();
         for (auto &it : slots_) release_buf(it);
     }
     static void fill_span(const Item &it, inq_span_t *sp) {  // the data part; the caller adds minlen / support / unphased
@@ -360,6 +363,7 @@ private:
         failed_ = true;
         err_ = m;
         cv_item_.notify_all();
+        cv_loaded_.notify_all();
     }
     void run() {
         SpanLoader loader;
@@ -384,25 +388,59 @@ private:
             const auto t2 = std::chrono::steady_clock::now();
             if (!loader.load(it->plan, planner_.anchors(), it->buf, n_threads_, it->data, &e)) return fail(e);
             it->staged = false;
-            if (stage_) {
-                inq_span_t sp;
-                fill_span(*it, &sp);
-                it->staged = stage_(sp, it->slot);
-            }
             if (verbose_) {
                 const auto t3 = std::chrono::steady_clock::now();
                 auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-                std::fprintf(stderr, "[inq loader] plan %.2f ms, buffer %.2f ms (%s), read+tables%s %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
-                             ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", it->staged ? "+upload" : "", ms(t2, t3), nbytes / 1e6,
+                std::fprintf(stderr, "[inq loader] plan %.2f ms, buffer %.2f ms (%s), read+tables %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
+                             ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), nbytes / 1e6,
                              it->plan.segs.size(), it->data.anchors.size());
             }
+            std::lock_guard<std::mutex> g(mu_);
+            if (stage_) {
+                loaded_.push_back(it);
+                cv_loaded_.notify_one();
+            } else {
+                ready_.push_back(it);
+                cv_item_.notify_one();
+            }
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        if (stage_) {
+            load_done_ = true;
+            cv_loaded_.notify_all();
+        } else {
+            done_ = true;
+            cv_item_.notify_all();
+        }
+    }
+    // uploads in file order, one span behind the reader
+    void run_uploads() {
+        for (;;) {
+            Item *it = nullptr;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_loaded_.wait(g, [&] { return !loaded_.empty() || load_done_ || stop_ || failed_; });
+                if (stop_ || failed_) return;
+                if (loaded_.empty()) {  // the reader is through
+                    done_ = true;
+                    cv_item_.notify_all();
+                    return;
+                }
+                it = loaded_.front();
+                loaded_.pop_front();
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            inq_span_t sp;
+            fill_span(*it, &sp);
+            it->staged = stage_(sp, it->slot);
+            if (verbose_)
+                std::fprintf(stderr, "[inq loader] upload %.2f ms for %.1f MB%s\n",
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), it->data.comp_bytes / 1e6,
+                             it->staged ? "" : " (not staged)");
             std::lock_guard<std::mutex> g(mu_);
             ready_.push_back(it);
             cv_item_.notify_one();
         }
-        std::lock_guard<std::mutex> g(mu_);
-        done_ = true;
-        cv_item_.notify_all();
     }
 
     std::string path_;
@@ -413,11 +451,11 @@ private:
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[3];
     std::vector<Item *> free_;
-    std::deque<Item *> ready_;
-    std::thread th_;
+    std::deque<Item *> ready_, loaded_;
+    std::thread th_, up_;
     std::mutex mu_;
-    std::condition_variable cv_item_, cv_free_;
-    bool stop_ = false, done_ = false, failed_ = false;
+    std::condition_variable cv_item_, cv_free_, cv_loaded_;
+    bool stop_ = false, done_ = false, failed_ = false, load_done_ = false;
     std::string err_;
 };
 
