@@ -81,6 +81,9 @@ struct WgLds {
 #define INQ_WG_CAP 4096
 #endif
     static constexpr int kRoundCap = INQ_WG_CAP;    // output bytes per round (rounds are cut at the lane that would exceed it)
+    static_assert(T % 64 == 0 && T >= 64 && T <= 512, "whole waves");
+    static_assert((kRoundCap & (kRoundCap - 1)) == 0 && kRoundCap >= 1024 && kRoundCap <= 32768, "root indices are masked with kRoundCap - 1 and must stay below 32768");
+    static_assert(kSegBits % 32 == 0 && kSegBits >= 64, "segments are whole dwords and longer than the longest symbol (48 bits)");
     uint32_t lut_ll[1 << kLitBits];
     uint32_t lut_d[1 << kDistBits];
     uint32_t stage[kStage];
