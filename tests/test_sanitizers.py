@@ -28,9 +28,10 @@ def test_host_front_end_under_asan_ubsan():
     env["LD_PRELOAD"] = " ".join(_san_libs())
     env["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=1"
     env["UBSAN_OPTIONS"] = "halt_on_error=1:print_stacktrace=1"
+    env["INQ_FUZZ_TRIALS"] = "12"
     env["INQ_HOST_LIB"] = os.path.join(ROOT, "inquistr_amd", "lib", "libinquistr_host_asan.so")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_host_frontend.py", "tests/test_host_spans.py", "tests/test_outlier_oracle.py", "tests/test_csi_index.py",
-                        "tests/test_error_class.py", "-x", "-q", "-k", "not cli",
+                        "tests/test_error_class.py", "tests/test_corrupt_inputs.py", "-x", "-q", "-k", "not cli",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout
