@@ -82,13 +82,13 @@ struct WgLds {
 #endif
     static constexpr int kRoundCap = INQ_WG_CAP;    // output bytes per round (rounds are cut at the lane that would exceed it)
     static_assert(T % 64 == 0 && T >= 64 && T <= 512, "whole waves");
-    static_assert((kRoundCap & (kRoundCap - 1)) == 0 && kRoundCap >= 1024 && kRoundCap <= 32768, "root indices are masked with kRoundCap - 1 and must stay below 32768");
+    static_assert((kRoundCap & (kRoundCap - 1)) == 0 && kRoundCap >= 1024 && kRoundCap <= 16384, "root indices are masked with kRoundCap - 1; 32768 + kRoundCap stays below the literal range");
     static_assert(kSegBits % 32 == 0 && kSegBits >= 64, "segments are whole dwords and longer than the longest symbol (48 bits)");
     uint32_t lut_ll[1 << kLitBits];
     uint32_t lut_d[1 << kDistBits];
     uint32_t stage[kStage];
-    // root of every output byte of the round, as position - (round start - 32768): >= 32768 = a byte of this round
-    // (a literal points at itself), < 32768 = a byte of an earlier round (deflate distances are <= 32768)
+    // root of every output byte of the stretch being committed: a literal's value, or where a match byte is copied from
+    // as position - (stretch start - 32768)
     uint16_t root[kRoundCap];
     uint32_t end_bit[T];   // per lane: where its chain left its segment, | kFlagBit if it stopped (EOB / not a code)
     uint32_t off_sh[T + 1];  // per lane: first output byte of its chain, relative to the round's; [T] = the round's bytes
@@ -102,6 +102,9 @@ struct WgLds {
     uint32_t red[8], red2[8];
 };
 
+// root values: < 32768 a byte of an earlier stretch (deflate distances are <= 32768), 32768 .. 32768 + kRoundCap a byte of
+// this stretch, >= kRootLit a literal (low byte)
+constexpr uint32_t kRootLit = 0xff00u;
 constexpr uint32_t kStopped = 0x80000000u;  // in end_bit: the chain met EOB or a pattern that is no code
 constexpr uint32_t kStopEob = 0x40000000u;  // ... and it was EOB
 
@@ -217,8 +220,8 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
         const uint32_t type = (e >> 4) & 3u;
         if (type == E_LIT) {
             b.consume(n);
-            if (MODE) out[o + nb] = (uint8_t)(e >> 16);
-            if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(o + nb - r0 + 32768u);
+            if (MODE == 2) out[o + nb] = (uint8_t)(e >> 16);
+            if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));  // the byte itself: stored by the gather, coalesced
             ++nb;
             continue;
         }
@@ -685,12 +688,13 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
                             __builtin_memcpy(&w, &L.root[4u * g], 8);  // the array is a multiple of 4 long
                             const uint32_t r0_ = (uint32_t)w & 0xffffu, r1_ = (uint32_t)(w >> 16) & 0xffffu, r2_ = (uint32_t)(w >> 32) & 0xffffu,
                                            r3_ = (uint32_t)(w >> 48);
-                            // a literal's root is itself, so following it changes nothing; bytes behind nbytes_s hold stale roots of
-                            // an earlier stretch: following them is harmless (bounded index), and nobody reads them
-                            const uint32_t a0 = r0_ >= 32768u ? L.root[(r0_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r0_;
-                            const uint32_t a1 = r1_ >= 32768u ? L.root[(r1_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r1_;
-                            const uint32_t a2 = r2_ >= 32768u ? L.root[(r2_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r2_;
-                            const uint32_t a3 = r3_ >= 32768u ? L.root[(r3_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r3_;
+                            // a pointer into this stretch takes over what its target holds (a literal, an earlier byte, or a pointer
+                            // further back); bytes behind nbytes_s hold stale roots of an earlier stretch: following them is
+                            // harmless (bounded index), and nobody reads them
+                            const uint32_t a0 = r0_ - 32768u < kRootLit - 32768u ? L.root[(r0_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r0_;
+                            const uint32_t a1 = r1_ - 32768u < kRootLit - 32768u ? L.root[(r1_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r1_;
+                            const uint32_t a2 = r2_ - 32768u < kRootLit - 32768u ? L.root[(r2_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r2_;
+                            const uint32_t a3 = r3_ - 32768u < kRootLit - 32768u ? L.root[(r3_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r3_;
                             const uint64_t nw = (uint64_t)a0 | ((uint64_t)a1 << 16) | ((uint64_t)a2 << 32) | ((uint64_t)a3 << 48);
                             if (nw != w) {
                                 __builtin_memcpy(&L.root[4u * g], &nw, 8);
@@ -711,14 +715,24 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
                         __builtin_memcpy(&w, &L.root[q], 8);
                         const uint32_t r0_ = (uint32_t)w & 0xffffu, r1_ = (uint32_t)(w >> 16) & 0xffffu, r2_ = (uint32_t)(w >> 32) & 0xffffu,
                                        r3_ = (uint32_t)(w >> 48);
-                        const uint32_t self = q + 32768u;
-                        if (q + 4u <= nbytes_s && r1_ == r0_ + 1u && r2_ == r0_ + 2u && r3_ == r0_ + 3u) {
-                            if (r0_ != self) st_u32(dstb + q, ld_u32(from + r0_));  // four bytes of one match, or four literals (nothing to do)
-                        } else {
-                            if (q < nbytes_s && r0_ != self) dstb[q] = from[r0_];
-                            if (q + 1u < nbytes_s && r1_ != self + 1u) dstb[q + 1u] = from[r1_];
-                            if (q + 2u < nbytes_s && r2_ != self + 2u) dstb[q + 2u] = from[r2_];
-                            if (q + 3u < nbytes_s && r3_ != self + 3u) dstb[q + 3u] = from[r3_];
+                        // every root is final now: a literal, or a byte of an earlier stretch (a pointer the sweeps left over cannot
+                        // exist; it would be taken for a literal: no access depends on it)
+                        if (q + 4u <= nbytes_s) {
+                            uint32_t val;
+                            if ((r0_ & r1_ & r2_ & r3_) >= kRootLit) {
+                                val = (r0_ & 0xffu) | (r1_ & 0xffu) << 8 | (r2_ & 0xffu) << 16 | r3_ << 24;
+                            } else if (r3_ < 32768u && r1_ == r0_ + 1u && r2_ == r0_ + 2u && r3_ == r0_ + 3u) {
+                                val = ld_u32(from + r0_);  // four bytes of one match
+                            } else {
+                                const uint32_t b0 = r0_ < 32768u ? from[r0_] : r0_ & 0xffu, b1 = r1_ < 32768u ? from[r1_] : r1_ & 0xffu;
+                                const uint32_t b2 = r2_ < 32768u ? from[r2_] : r2_ & 0xffu, b3 = r3_ < 32768u ? from[r3_] : r3_ & 0xffu;
+                                val = b0 | b1 << 8 | b2 << 16 | b3 << 24;
+                            }
+                            st_u32(dstb + q, val);
+                        } else {  // the stretch's last bytes: the roots behind them are stale, never followed
+                            if (q < nbytes_s) dstb[q] = (uint8_t)(r0_ < 32768u ? from[r0_] : r0_);
+                            if (q + 1u < nbytes_s) dstb[q + 1u] = (uint8_t)(r1_ < 32768u ? from[r1_] : r1_);
+                            if (q + 2u < nbytes_s) dstb[q + 2u] = (uint8_t)(r2_ < 32768u ? from[r2_] : r2_);
                         }
                     }
                 }
