@@ -17,6 +17,24 @@ def make_blocks(n_blocks: int, level: int, kind: str = "cigar"):
         base = (rng.integers(0, 51, 64 * bamio.BLOCK, dtype=np.uint8)).tobytes()
         comp = [bamio.bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base), bamio.BLOCK)]
         return b"".join((comp * (n_blocks // len(comp) + 1))[:n_blocks])
+    if kind in ("seq", "ont"):
+        # seq: packed bases (two per byte, 16 equiprobable byte values); ont: long reads as a nanopore BAM holds them:
+        # 12 KB of packed bases, then 24 KB of base qualities (skewed Phred), a few tags
+        rng = np.random.default_rng(4)
+        nib = np.array([1, 2, 4, 8], dtype=np.uint8)
+        n = 48 * bamio.BLOCK
+        packed = (nib[rng.integers(0, 4, n)] << 4 | nib[rng.integers(0, 4, n)]).astype(np.uint8)
+        if kind == "seq":
+            base = packed.tobytes()
+        else:
+            q = np.clip(rng.gamma(4.0, 5.0, n), 1, 50).astype(np.uint8)
+            parts, at = [], 0
+            while at + 36_000 < n:
+                parts += [bytes(36), packed[at : at + 12_000].tobytes(), q[at : at + 24_000].tobytes(), b"MLB" + q[at : at + 400].tobytes()]
+                at += 36_000
+            base = b"".join(parts)
+        comp = [bamio.bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base) - bamio.BLOCK, bamio.BLOCK)]
+        return b"".join((comp * (n_blocks // len(comp) + 1))[:n_blocks])
     wl = synth.WORKLOADS["unphased100k"]
     need = n_blocks * bamio.BLOCK
     blob = bytearray()
