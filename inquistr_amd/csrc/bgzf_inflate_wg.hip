@@ -50,24 +50,27 @@ constexpr uint32_t kSegBits = INQ_WG_SEGBITS;  // compressed bits per lane and r
 constexpr int kMaxLit = 288, kMaxDist = 32;
 
 constexpr uint32_t E_LIT = 0u, E_LEN = 1u, E_EOB = 2u, E_LONG = 3u;
-constexpr uint32_t kLongEntry = E_LONG << 4;  // code longer than the table's index: canonical path
-// table entry: bits 0-3 code length (0 = not a code), 4-5 type, 8-11 extra bits, 16-31 literal / base value
+// table entry: bits 0-3 code length (0 = not a code), 4-5 type, 6 = everything the decode loop leaves its fast path for
+// (end of block, not a code, a code longer than the table's index), 8-11 extra bits, 16-31 literal / base value
+constexpr uint32_t kSpecial = 0x40u;
+constexpr uint32_t kLongEntry = (E_LONG << 4) | kSpecial;  // code longer than the table's index: canonical path
+constexpr uint32_t kNoCode = kSpecial;
 __device__ __forceinline__ uint32_t mk_entry(uint32_t n, uint32_t type, uint32_t xb, uint32_t val) {
     return n | (type << 4) | (xb << 8) | (val << 16);
 }
 // RFC 1951 3.2.5: literal/length symbol -> entry
 __device__ __forceinline__ uint32_t ll_entry(uint32_t sym, uint32_t n) {
     if (sym < 256u) return mk_entry(n, E_LIT, 0u, sym);
-    if (sym == 256u) return mk_entry(n, E_EOB, 0u, 0u);
+    if (sym == 256u) return mk_entry(n, E_EOB, 0u, 0u) | kSpecial;
     const uint32_t s = sym - 257u;
-    if (s >= 29u) return 0u;  // 286, 287 take part in the fixed code but never appear in valid data
+    if (s >= 29u) return kNoCode;  // 286, 287 take part in the fixed code but never appear in valid data
     if (s < 8u) return mk_entry(n, E_LEN, 0u, 3u + s);
     if (s == 28u) return mk_entry(n, E_LEN, 0u, 258u);
     const uint32_t xb = (s - 4u) >> 2;
     return mk_entry(n, E_LEN, xb, 3u + ((4u + (s & 3u)) << xb));
 }
 __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t n) {
-    if (sym >= 30u) return 0u;
+    if (sym >= 30u) return kNoCode;
     if (sym < 4u) return mk_entry(n, E_LEN, 0u, 1u + sym);
     const uint32_t xb = (sym - 2u) >> 1;
     return mk_entry(n, E_LEN, xb, 1u + ((2u + (sym & 1u)) << xb));
@@ -192,10 +195,10 @@ __device__ __forceinline__ uint32_t canon_entry(const WgLds<T> &L, int tbl, uint
     uint32_t len = from_len;
     for (; len <= 15u; ++len)
         if (v15 < L.limit[tbl][len]) break;
-    if (len > 15u) return 0u;
+    if (len > 15u) return kNoCode;
     const uint32_t idx = L.base[tbl][len] + (v15 >> (15u - len));
-    if (tbl == 0) return idx < (uint32_t)kMaxLit ? ll_entry(L.sorted[idx], len) : 0u;
-    return idx < (uint32_t)kMaxDist ? dist_entry(L.sorted[kMaxLit + idx], len) : 0u;
+    if (tbl == 0) return idx < (uint32_t)kMaxLit ? ll_entry(L.sorted[idx], len) : kNoCode;
+    return idx < (uint32_t)kMaxDist ? dist_entry(L.sorted[kMaxLit + idx], len) : kNoCode;
 }
 
 // Decodes the symbols that START in [start, seg_end) of one lane's segment.  MODE 0: counts only.  MODE 1 (commit):
@@ -211,38 +214,37 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
     while (b.pos < seg_end) {
         const uint32_t bits = b.peek();
         uint32_t e = L.lut_ll[bits & ((1u << kLitBits) - 1u)];
-        if (e == kLongEntry) e = canon_entry<T>(L, 0, __brev(bits) >> 17, kLitBits + 1);
-        const uint32_t n = e & 15u;
-        if (n == 0u) {
-            stop = kStopped;
-            break;
+        if (e & kSpecial) {  // one test keeps the three rare cases out of the loop's fast path
+            if (e == kLongEntry) e = canon_entry<T>(L, 0, __brev(bits) >> 17, kLitBits + 1);
+            if (e & kSpecial) {
+                if (e & 15u) {  // end of block (a code has a length; "not a code" has none)
+                    b.consume(e & 15u);
+                    stop = kStopped | kStopEob;
+                } else stop = kStopped;
+                break;
+            }
         }
-        const uint32_t type = (e >> 4) & 3u;
-        if (type == E_LIT) {
-            b.consume(n);
+        const uint32_t n = e & 15u, xb = (e >> 8) & 15u;  // a literal has no extra bits
+        b.consume(n + xb);
+        if (!(e & (E_LEN << 4))) {
             if (MODE == 2) out[o + nb] = (uint8_t)(e >> 16);
             if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));  // the byte itself: stored by the gather, coalesced
             ++nb;
             continue;
         }
-        if (type == E_EOB) {
-            b.consume(n);
-            stop = kStopped | kStopEob;
-            break;
-        }
-        const uint32_t xb = (e >> 8) & 15u;
-        const uint32_t len = (e >> 16) + ((bits >> n) & ((1u << xb) - 1u));
-        b.consume(n + xb);
+        const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(bits, n, xb);
         const uint32_t dbits = b.peek();
         uint32_t d = L.lut_d[dbits & ((1u << kDistBits) - 1u)];
-        if (d == kLongEntry) d = canon_entry<T>(L, 1, __brev(dbits) >> 17, kDistBits + 1);
-        const uint32_t dn = d & 15u;
-        if (dn == 0u) {
-            stop = kStopped;
-            break;
+        if (d & kSpecial) {
+            if (d == kLongEntry) d = canon_entry<T>(L, 1, __brev(dbits) >> 17, kDistBits + 1);
+            if (d & kSpecial) {
+                stop = kStopped;
+                break;
+            }
         }
+        const uint32_t dn = d & 15u;
         const uint32_t dxb = (d >> 8) & 15u;
-        const uint32_t dist = (d >> 16) + ((dbits >> dn) & ((1u << dxb) - 1u));
+        const uint32_t dist = (d >> 16) + __builtin_amdgcn_ubfe(dbits, dn, dxb);
         b.consume(dn + dxb);
         if (MODE) {
             if (dist > o + nb) {
@@ -469,11 +471,11 @@ __device__ void build_tables(WgLds<T> &L, int tid) {
     __syncthreads();
     for (int e = tid; e < (1 << kLitBits); e += T) {
         const uint32_t v15 = __brev((uint32_t)e) >> 17;
-        L.lut_ll[e] = v15 < L.limit[0][kLitBits] ? canon_entry<T>(L, 0, v15, 1u) : (v15 < L.limit[0][15] ? kLongEntry : 0u);
+        L.lut_ll[e] = v15 < L.limit[0][kLitBits] ? canon_entry<T>(L, 0, v15, 1u) : (v15 < L.limit[0][15] ? kLongEntry : kNoCode);
     }
     for (int e = tid; e < (1 << kDistBits); e += T) {
         const uint32_t v15 = __brev((uint32_t)e) >> 17;
-        L.lut_d[e] = v15 < L.limit[1][kDistBits] ? canon_entry<T>(L, 1, v15, 1u) : (v15 < L.limit[1][15] ? kLongEntry : 0u);
+        L.lut_d[e] = v15 < L.limit[1][kDistBits] ? canon_entry<T>(L, 1, v15, 1u) : (v15 < L.limit[1][15] ? kLongEntry : kNoCode);
     }
     __syncthreads();
 }
