@@ -178,13 +178,13 @@ struct SegBits {
     }
     __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(hi, lo, pos & 31u); }  // >= 33 valid bits behind pos
     __device__ __forceinline__ void consume(uint32_t n) {  // n < 32
+        // no branch: the dword two behind the cursor's is fetched every time (the same one again while the cursor stays
+        // inside a dword) and nothing waits for it before the cursor has crossed into the next dword
         const uint32_t np = pos + n;
-        if ((np ^ pos) & ~31u) {
-            lo = hi;
-            hi = nxt;
-            ++wi;
-            nxt = st[wi + 2];  // consumed two refills later
-        }
+        const bool cross = ((np ^ pos) & ~31u) != 0u;
+        lo = cross ? hi : lo;
+        hi = cross ? nxt : hi;
+        nxt = st[(np >> 5) + 2u];
         pos = np;
     }
 };
