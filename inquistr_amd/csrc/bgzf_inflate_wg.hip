@@ -211,6 +211,7 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
     SegBits b;
     b.init(L.stage, start);
     uint32_t nb = 0, stop = 0;
+    const uint32_t lane_end = MODE == 1 ? o - r0 + nbytes : 0u;  // MODE 1: nbytes comes in as the lane's counted bytes
     while (b.pos < seg_end) {
         const uint32_t bits = b.peek();
         uint32_t e = L.lut_ll[bits & ((1u << kLitBits) - 1u)];
@@ -254,31 +255,47 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
             }
             if (MODE == 1) {
                 // the lane's own bytes are rooted already (it walks them in order; LDS operations of a wave execute in
-                // order); a source in front of the lane's stretch stays a pointer for the jumping sweeps
-                uint32_t p = o + nb - r0;               // relative to the round
+                // order); a source in front of the lane's stretch stays a pointer for the jumping sweeps.  Roots go four
+                // at a time (8 bytes); a group may write beyond the match's end as long as it stays inside the lane's own
+                // bytes: the symbols behind it write those entries again, later.
+                const uint32_t p = o + nb - r0;  // relative to the stretch
                 const uint32_t own = o - r0;
-                uint32_t k = 0;
-                const int32_t sp0 = (int32_t)(p - dist);  // may lie in front of the round (negative)
+                const int32_t sp0 = (int32_t)(p - dist);  // may lie in front of the stretch (negative)
+                auto put4 = [&](uint32_t at, uint64_t w, uint32_t cnt) {
+                    if (at + 4u <= lane_end) __builtin_memcpy(&L.root[at], &w, 8);
+                    else
+                        for (uint32_t j = 0; j < cnt && j < 4u; ++j, w >>= 16) L.root[at + j] = (uint16_t)w;
+                };
                 if (sp0 + (int32_t)len <= (int32_t)own) {
                     // the whole source lies in front of this lane's stretch: the roots are consecutive pointers
                     const uint32_t v = (uint32_t)(sp0 + 32768);
-                    for (; k + 4u <= len; k += 4u) {
+                    for (uint32_t k = 0; k < len; k += 4u) {
                         const uint32_t a = (v + k) | ((v + k + 1u) << 16), b2 = (v + k + 2u) | ((v + k + 3u) << 16);
-                        const uint64_t w = (uint64_t)a | ((uint64_t)b2 << 32);
-                        __builtin_memcpy(&L.root[p + k], &w, 8);
+                        put4(p + k, (uint64_t)a | ((uint64_t)b2 << 32), len - k);
                     }
-                    for (; k < len; ++k) L.root[p + k] = (uint16_t)(v + k);
-                } else if (sp0 >= (int32_t)own && dist >= 4u) {
-                    // the whole source lies in the lane's own stretch, already rooted: copy roots four at a time
-                    // (a group never reads what it writes; later groups may read what earlier ones wrote: LDS is in order)
-                    for (; k + 4u <= len; k += 4u) {
+                } else if (sp0 >= (int32_t)own) {
+                    // the whole source lies in the lane's own stretch, already rooted: copy roots (a group never reads what
+                    // it writes; later groups may read what earlier ones wrote: LDS is in order).  A period below four
+                    // (runs) gives the first group from the period's entries and the rest from a multiple of it.
+                    uint32_t back = dist, k = 0;
+                    if (dist < 4u) {
                         uint64_t w;
-                        __builtin_memcpy(&w, &L.root[(uint32_t)sp0 + k], 8);
-                        __builtin_memcpy(&L.root[p + k], &w, 8);
+                        __builtin_memcpy(&w, &L.root[(uint32_t)sp0], 8);  // entries sp0 .. sp0 + 3 <= p + 2: inside the match (len >= 3)
+                        const uint64_t e0 = w & 0xffffu, e1 = (w >> 16) & 0xffffu, e2 = (w >> 32) & 0xffffu;
+                        const uint64_t g = dist == 1u ? e0 * 0x0001000100010001ull
+                                           : dist == 2u ? (e0 | e1 << 16) * 0x0000000100000001ull
+                                                        : (e0 | e1 << 16 | e2 << 32 | e0 << 48);
+                        put4(p, g, len);
+                        back = dist == 3u ? 6u : 4u;
+                        k = 4u;
                     }
-                    for (; k < len; ++k) L.root[p + k] = L.root[(uint32_t)sp0 + k];
-                } else {
-                    for (; k < len; ++k) {
+                    for (; k < len; k += 4u) {
+                        uint64_t w;
+                        __builtin_memcpy(&w, &L.root[p + k - back], 8);
+                        put4(p + k, w, len - k);
+                    }
+                } else {  // the source straddles the start of the lane's stretch
+                    for (uint32_t k = 0; k < len; ++k) {
                         const int32_t sp = sp0 + (int32_t)k;
                         L.root[p + k] = sp >= (int32_t)own ? L.root[(uint32_t)sp] : (uint16_t)(sp + 32768);
                     }
@@ -669,7 +686,7 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
                 const uint32_t r0 = out0 + r_lo, nbytes_s = r_hi - r_lo;
                 uint32_t cbad = 0;
                 if ((uint32_t)tid >= k0 && (uint32_t)tid < k1) {
-                    uint32_t nb2;
+                    uint32_t nb2 = nbytes;
                     if (lone) (void)decode_segment<T, 2>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
                     else (void)decode_segment<T, 1>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
                 }
