@@ -42,7 +42,13 @@ namespace inq {
 
 namespace {
 
-constexpr int kLitBits = 10, kDistBits = 8;
+#ifndef INQ_WG_LITBITS
+#define INQ_WG_LITBITS 10
+#endif
+#ifndef INQ_WG_DISTBITS
+#define INQ_WG_DISTBITS 8
+#endif
+constexpr int kLitBits = INQ_WG_LITBITS, kDistBits = INQ_WG_DISTBITS;
 #ifndef INQ_WG_SEGBITS
 #define INQ_WG_SEGBITS 256
 #endif
@@ -92,22 +98,33 @@ struct WgLds {
     uint32_t stage[kStage];
     // root of every output byte of the stretch being committed: a literal's value, or where a match byte is copied from
     // as position - (stretch start - 32768)
-    uint16_t root[kRoundCap];
-    uint32_t end_bit[T];   // per lane: where its chain left its segment, | kFlagBit if it stopped (EOB / not a code)
+    // (the arrays that only live while no stretch is being committed share its storage: header parse, table build, counting)
+    union {
+        uint16_t root[kRoundCap];
+        struct {
+            uint32_t end_bit[T];   // per lane: where its chain left its segment, | kFlagBit if it stopped (EOB / not a code)
+            uint32_t cnt[2][16], run[2][16];
+            uint8_t lens[kMaxLit + kMaxDist];
+            uint8_t cl_lut[128];  // 7 bits of the stream -> code-length symbol | code length << 5 (0 = not a code)
+            uint8_t cl_len[20];
+        };
+    };
     uint32_t off_sh[T + 1];  // per lane: first output byte of its chain, relative to the round's; [T] = the round's bytes
+    // what a commit job needs of a segment besides off_sh: where its chain starts, and its first symbol start in the
+    // segment's second half with the bytes produced before it (position | bytes << 16, kNoMid = the chain ended before)
+    uint16_t start_sh[T];
+    uint32_t mid_sh[T];
     uint16_t sorted[kMaxLit + kMaxDist];  // symbols by (code length, value): literal/length, then distance
-    uint32_t limit[2][16], base[2][16], cnt[2][16], run[2][16];
-    uint8_t lens[kMaxLit + kMaxDist];
-    uint8_t cl_lut[128];  // 7 bits of the stream -> code-length symbol | code length << 5 (0 = not a code)
-    uint8_t cl_len[20];
+    uint32_t limit[2][16], base[2][16];
     // block-uniform state
     uint32_t P, out, status, last, type, eob, hlit, hdist, flag;
-    uint32_t red[8], red2[8];
+    uint32_t red[T / 64], red2[T / 64];
 };
 
 // root values: < 32768 a byte of an earlier stretch (deflate distances are <= 32768), 32768 .. 32768 + kRoundCap a byte of
 // this stretch, >= kRootLit a literal (low byte)
 constexpr uint32_t kRootLit = 0xff00u;
+constexpr uint32_t kNoMid = 0xffffffffu;
 constexpr uint32_t kStopped = 0x80000000u;  // in end_bit: the chain met EOB or a pattern that is no code
 constexpr uint32_t kStopEob = 0x40000000u;  // ... and it was EOB
 
@@ -207,12 +224,20 @@ __device__ __forceinline__ uint32_t canon_entry(const WgLds<T> &L, int tbl, uint
 // Returns the position behind the last decoded symbol (| kStopped / kStopEob).  `bad` collects INQ_INFLATE_* bits.
 template <int T, int MODE>
 __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, uint32_t seg_end, uint32_t &nbytes, uint8_t *out, uint32_t o,
-                                                   uint32_t r0, uint32_t &bad) {
+                                                   uint32_t r0, uint32_t &bad, uint32_t *mid = nullptr) {
     SegBits b;
     b.init(L.stage, start);
     uint32_t nb = 0, stop = 0;
-    const uint32_t lane_end = MODE == 1 ? o - r0 + nbytes : 0u;  // MODE 1: nbytes comes in as the lane's counted bytes
-    while (b.pos < seg_end) {
+    const uint32_t lane_end = MODE == 1 ? o - r0 + nbytes : 0u;  // MODE 1: nbytes comes in as the job's counted bytes
+    // MODE 0 walks the segment's two halves one after the other and notes where the chain enters the second
+    if (MODE == 0) *mid = kNoMid;
+    for (int half = MODE == 0 ? 0 : 1; half < 2; ++half) {
+    const uint32_t lim = half == 0 ? seg_end - kSegBits / 2u : seg_end;
+    if (MODE == 0 && half == 1) {
+        if (stop) break;
+        *mid = b.pos | (nb << 16);
+    }
+    while (b.pos < lim) {
         const uint32_t bits = b.peek();
         uint32_t e = L.lut_ll[bits & ((1u << kLitBits) - 1u)];
         if (e & kSpecial) {  // one test keeps the three rare cases out of the loop's fast path
@@ -305,6 +330,7 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
             }
         }
         nb += len;
+    }
     }
     nbytes = nb;
     return b.pos | stop;
@@ -507,8 +533,11 @@ __device__ __forceinline__ void stage_load(WgLds<T> &L, const uint8_t *payload, 
 
 }  // namespace
 
+#ifndef INQ_WG_WAVES
+#define INQ_WG_WAVES 4
+#endif
 template <int T>
-__global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES, INQ_WG_WAVES))) void bgzf_inflate_wg_kernel(InflateArgs a) {
     __shared__ WgLds<T> L;
     const int tid = (int)threadIdx.x;
     const uint64_t bi = blockIdx.x;
@@ -628,8 +657,8 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
             __syncthreads();
             const uint32_t seg_end = ((uint32_t)tid + 1u) * kSegBits;
             uint32_t start = tid == 0 ? (P & 31u) : (uint32_t)tid * kSegBits;
-            uint32_t nbytes = 0, bad = 0;
-            uint32_t end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad);
+            uint32_t nbytes = 0, bad = 0, mid = kNoMid;
+            uint32_t end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid);
             DBG_N(1);
             DBG_N(2);
             // ---- until every chain starts where its left neighbour's ended (lanes behind the first stop do not matter)
@@ -649,7 +678,7 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
                 }
                 if (mismatch) {
                     start = left & 0x3fffffffu;
-                    end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad);
+                    end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid);
                 }
                 DBG_N(2);
                 __syncthreads();  // end_bit[] read by everyone before it is rewritten
@@ -659,6 +688,8 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
             uint32_t off_b, tot_b, dummy0, dummy1;
             wg_scan2<T>(nbytes, 0u, off_b, dummy0, tot_b, dummy1, L.red, L.red2);
             L.off_sh[tid] = off_b;
+            L.start_sh[tid] = (uint16_t)start;
+            L.mid_sh[tid] = mid;
             if (tid == 0) L.off_sh[T] = tot_b;
             if (tid == (int)ncommit - 1) {  // the last chain of the round: where the next round starts, and why this one ended
                 const uint32_t stop = end & (kStopped | kStopEob);
@@ -685,10 +716,27 @@ __global__ __launch_bounds__(T) void bgzf_inflate_wg_kernel(InflateArgs a) {
                 const uint32_t r_hi = k1 < ncommit ? L.off_sh[k1] : tot_b;
                 const uint32_t r0 = out0 + r_lo, nbytes_s = r_hi - r_lo;
                 uint32_t cbad = 0;
-                if ((uint32_t)tid >= k0 && (uint32_t)tid < k1) {
-                    uint32_t nb2 = nbytes;
-                    if (lone) (void)decode_segment<T, 2>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
-                    else (void)decode_segment<T, 1>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
+                if (lone) {
+                    if ((uint32_t)tid == k0) {
+                        uint32_t nb2 = nbytes;
+                        (void)decode_segment<T, 2>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
+                    }
+                } else {
+                    // two jobs per segment, dealt over all lanes: the first half of its chain, and the rest from where the chain
+                    // enters the second half (any lane can decode any segment: the bits are staged, the places are shared)
+                    const uint32_t njobs = 2u * (k1 - k0);
+                    for (uint32_t j = (uint32_t)tid; j < njobs; j += T) {
+                        const uint32_t seg = k0 + (j >> 1), second = j & 1u;
+                        const uint32_t s0 = L.start_sh[seg], m = L.mid_sh[seg], ob = L.off_sh[seg], oe = L.off_sh[seg + 1u];
+                        const uint32_t send = (seg + 1u) * kSegBits;
+                        uint32_t js, je, jo, jn;  // bits [js, je), bytes [jo, jo + jn) of the round
+                        if (m == kNoMid) js = s0, je = send, jo = ob, jn = oe - ob;
+                        else if (!second) js = s0, je = m & 0xffffu, jo = ob, jn = m >> 16;
+                        else js = m & 0xffffu, je = send, jo = ob + (m >> 16), jn = oe - ob - (m >> 16);
+                        if (m == kNoMid && second) continue;
+                        uint32_t nb2 = jn;
+                        (void)decode_segment<T, 1>(L, js, je, nb2, out, out0 + jo, r0, cbad);
+                    }
                 }
                 if (cbad) atomicOr(&L.status, cbad);
                 __syncthreads();  // literals (global) and roots (LDS) are visible to the workgroup
