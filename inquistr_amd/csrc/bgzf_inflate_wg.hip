@@ -559,7 +559,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
 #ifdef INQ_INFLATE_DEBUG_ENV
     // dev-time probe (debug_flags & 8): per block {deflate blocks, rounds, count passes, match sweeps, kilo-cycles in
     // header+tables, counting, commit, matches} into block_status[8 * bi ..] for bi < n_blocks / 8
-    uint32_t dbg_n[4] = {0, 0, 0, 0};
+    uint32_t dbg_n[5] = {0, 0, 0, 0, 0};
     uint64_t dbg_c[5] = {0, 0, 0, 0, 0}, dbg_t = clock64();
 #define DBG_N(i) ++dbg_n[i]
 #define DBG_LAP(i) { const uint64_t now_ = clock64(); dbg_c[i] += now_ - dbg_t; dbg_t = now_; }
@@ -716,6 +716,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 const uint32_t r_hi = k1 < ncommit ? L.off_sh[k1] : tot_b;
                 const uint32_t r0 = out0 + r_lo, nbytes_s = r_hi - r_lo;
                 uint32_t cbad = 0;
+                DBG_N(4);
                 if (lone) {
                     if ((uint32_t)tid == k0) {
                         uint32_t nb2 = nbytes;
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
         __syncthreads();
         if (tid == 0 && bi < a.n_blocks / 8) {
             uint32_t *o = a.block_status + 8 * bi;
-            o[0] = dbg_n[0], o[1] = dbg_n[1], o[2] = dbg_n[2];
+            o[0] = dbg_n[0] | dbg_n[4] << 8 | dbg_n[3] << 20, o[1] = dbg_n[1], o[2] = dbg_n[2];  // deflate blocks | stretches | sweeps
             o[3] = (uint32_t)(dbg_c[0] >> 10), o[4] = (uint32_t)(dbg_c[4] >> 10), o[5] = (uint32_t)(dbg_c[1] >> 10), o[6] = (uint32_t)(dbg_c[2] >> 10),
             o[7] = (uint32_t)(dbg_c[3] >> 10);
         }
