@@ -699,10 +699,11 @@ __global__ __launch_bounds__(256) void bgzf_crc32_kernel(InflateArgs a) {
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s) {
     if (!a.n_blocks) return;
     const uint64_t grid = (a.n_blocks + kLanes - 1) / kLanes;
-    // Two kernels, one job.  A workgroup per block (bgzf_inflate_wg.hip) costs 0.85-1.2 ms per 1000 blocks and has no floor; a
-    // lane per block (this file) takes 36-56 ms for anything up to ~65 000 blocks, whatever their number.  Measured crossover
-    // (profiles/r02_front/README.md): ~50 000 blocks of BAM-like data, ~42 000 of quality-like bytes.
-    const bool wg = a.algo == 0u || (a.algo == 2u && a.n_blocks <= 45000u);
+    // Two kernels, one job.  A workgroup per block (bgzf_inflate_wg.hip) costs 0.6-0.85 ms per 1000 blocks and has no floor; a
+    // lane per block (this file) takes 36-56 ms for anything up to ~65 000 blocks and then doubles.  Since the round-2 work on
+    // the workgroup kernel it is the quicker one at every size measured (profiles/r02_front/README.md: 80 000 blocks 47 / 84 ms),
+    // so "auto" means it; the lane-per-block kernel stays selectable and goes through the same tests.
+    const bool wg = a.algo != 1u;
     if (wg) launch_bgzf_inflate_wg(a, s);
     else hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((uint32_t)grid), dim3(kLanes), 0, s, a);
     if (a.verify_crc) hipLaunchKernelGGL(bgzf_crc32_kernel, dim3((uint32_t)((a.n_blocks + 3) / 4)), dim3(256), 0, s, a);
