@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: the inflate fuzz of tests/test_gpu_front.py with other seeds (accept / reject and bytes vs zlib).
-usage: python tools/soak_inflate.py [rounds]"""
+usage: python tools/soak_inflate.py [rounds of 4000 damaged streams] [rounds of 1500 valid blocks per kernel]"""
 import os
 import random
 import sys
@@ -10,6 +10,7 @@ import tests.test_gpu_front as t  # noqa: E402
 from inquistr_amd import hipcall  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+valid_rounds = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, rounds // 2)  # 1500 blocks each, per kernel (slow to generate)
 ctx = hipcall.Context(0)
 orig = random.Random
 for r in range(rounds):
@@ -82,7 +83,7 @@ for algo in (0, 1):
     ctx.set_option("inflate_algo", algo)
     rng = orig(4242 + algo)
     n_blocks = 0
-    for r in range(max(1, rounds // 2)):
+    for r in range(valid_rounds):
         items = _blocks(rng, 1500)
         comp = b"".join(b for b, _ in items)
         blocks = hipcall.scan_bgzf(comp)
@@ -91,4 +92,5 @@ for algo in (0, 1):
         assert rc == 0 and not status.any(), (algo, r, [hex(int(s)) for s in status if s][:5])
         assert out.tobytes() == b"".join(d for _, d in items), (algo, r)
         n_blocks += len(items)
+        print(f"  inflate_algo {algo} round {r}: {len(items)} blocks ok", flush=True)
     print(f"inflate_algo {algo}: {n_blocks} valid blocks of nine shapes inflate to their input", flush=True)
