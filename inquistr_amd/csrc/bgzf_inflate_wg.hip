@@ -14,18 +14,22 @@
 //     neighbour's end (lane 0's is true by construction, so after k repeats lanes 0..k are: correctness never
 //     depends on the guess, only speed does; typically 2-3 repeats).  These passes only COUNT (bits, output
 //     bytes, matches).
-//   * A prefix sum of the byte counts gives every lane its place in the output; a COMMIT pass decodes once more,
-//     stores literals where they belong and, for every byte of a match, records its ROOT in LDS: the position the
-//     byte is ultimately copied from.  Inside a lane's own stretch of output the root is known at once
-//     (root[p] = root[p - distance], the lane walks its bytes in order); a source in an earlier lane's stretch
-//     is left as a pointer.  Pointer jumping (root[p] = root[root[p]], all bytes at once) then shortens every
-//     chain to a literal of this round or to bytes of earlier rounds in a few sweeps - the chains CIGAR-like
-//     data produces (3-byte matches at distance 4 or 8, each feeding the next) would take thousands of ordered
-//     copy sweeps otherwise - and ONE coalesced pass copies out[p] = out[root[p]] for the match bytes.
-//   * Symbols are decoded by table: 10 bits index a 1024-entry table in LDS (literal / length base + extra-bit
-//     count / end-of-block, and the code length), 8 bits a distance table; longer codes (rare by construction)
-//     take the canonical limits-and-base path.  Tables are built by the whole workgroup (count, rank by ballot,
-//     scatter, one canonical decode per table entry).
+//   * A prefix sum of the byte counts gives every segment its place in the output.  The round is then COMMITTED in
+//     stretches of segments whose bytes fit the root array, two jobs per segment dealt over all lanes (the counting pass
+//     notes where a chain enters its segment's second half; any lane can decode any half: the bits are staged, starts
+//     and places are shared).  A job decodes once more and records, for every output byte, its ROOT in LDS: a literal's
+//     value, or the position a match byte is ultimately copied from.  Inside the job's own bytes the root is known at
+//     once (root[p] = root[p - distance], the job walks its bytes in order); a source in front of them is left as a
+//     pointer.  Pointer jumping (root[p] = root[root[p]], all bytes at once) then shortens every chain to a literal or
+//     to bytes of earlier stretches in a few sweeps - the chains CIGAR-like data produces (3-byte matches at distance 4
+//     or 8, each feeding the next) would take thousands of ordered copy sweeps otherwise - and ONE coalesced pass stores
+//     the stretch as whole dwords.
+//   * Symbols are decoded by table: 10 bits index a 1024-entry table in LDS (literal / length base + extra-bit count,
+//     and the code length), 8 bits a distance table; end of block, "not a code" and codes longer than the index share
+//     one flag bit, so the loop's fast path tests once; longer codes (rare by construction) take the canonical
+//     limits-and-base path.  The bit cursor refills without a branch.  Tables are built by the whole workgroup (count,
+//     rank by ballot, scatter, one canonical decode per table entry); so are the code lengths of a dynamic block's
+//     header, a Huffman stream of their own, decoded 32 bits per lane with the same guess-and-confirm scheme.
 //   * The output window is the output itself in global memory (L2-resident while the block is in flight), so a
 //     workgroup needs 20 KB of LDS and eight of them share a CU.
 // Every access is bounded (LDS indices masked or checked, output by ISIZE, distances by the bytes produced,
@@ -107,6 +111,7 @@ struct WgLds {
             uint8_t lens[kMaxLit + kMaxDist];
             uint8_t cl_lut[128];  // 7 bits of the stream -> code-length symbol | code length << 5 (0 = not a code)
             uint8_t cl_len[20];
+            uint8_t last_sh[T];  // header: the last code length a lane's symbols leave behind (kNoLast = all of them copy their predecessor)
         };
     };
     uint32_t off_sh[T + 1];  // per lane: first output byte of its chain, relative to the round's; [T] = the round's bytes
@@ -372,8 +377,8 @@ __device__ __forceinline__ void wg_scan2(uint32_t a, uint32_t b, uint32_t &ex_a,
 }
 
 // ---- header of a dynamic block (RFC 1951 3.2.7) from the staged bits, in three steps: lane 0 reads the counts and the
-// code-length code's lengths; lanes 0..18 build that code's 7-bit decode table (one symbol each); lane 0 decodes the
-// literal/length and distance code lengths through it into L.lens.
+// code-length code's lengths; lanes 0..18 build that code's 7-bit decode table (one symbol each); the workgroup decodes the
+// literal/length and distance code lengths through it into L.lens (header_lengths_wg).
 template <int T>
 __device__ uint32_t header_counts(WgLds<T> &L, SegBits &b) {  // lane 0
     const uint32_t bits = b.peek();
@@ -421,39 +426,106 @@ __device__ void header_cl_table(WgLds<T> &L, int tid) {  // lanes 0..18; cl_lut 
     for (uint32_t k = 0; k < (1u << (7u - n)); ++k) L.cl_lut[rev | (k << n)] = (uint8_t)((uint32_t)tid | (n << 5));
 }
 
-template <int T>
-__device__ uint32_t header_lengths(WgLds<T> &L, SegBits &b, uint32_t limit_bits) {  // lane 0
-    const uint32_t hlit = L.hlit, total = L.hlit + L.hdist;
-    uint32_t idx = 0, prev = 0;
-    while (idx < total) {
-        if (b.pos > limit_bits) return INQ_INFLATE_INPUT_OVERRUN;
+// The literal/length and distance code lengths, by the whole workgroup (every lane calls it; L.status == 0 and the
+// code-length code is complete, so every 7-bit pattern is a code).  The code lengths are a Huffman stream of their own: lane k takes the symbols that start in bits
+// [hp + 32 k, hp + 32 k + 32) - 128 lanes cover 4096 bits, a valid sequence of <= 316 lengths ends within 2212 - and, like
+// the rounds of the block body, guesses its first symbol start, counts, and decodes again from where its left neighbour's
+// chain ended until the lanes in front of the sequence's end agree.  A last pass, with every lane's place in lens[] known,
+// writes the lengths and applies zlib's checks (inflate.c CODELENS: "invalid bit length repeat").
+constexpr uint32_t kNoLast = 0xffu;
+template <int T, bool FINAL>
+__device__ __forceinline__ uint32_t cl_walk(WgLds<T> &L, uint32_t from, uint32_t seg_hi, uint32_t idx, uint32_t prev, uint32_t total, uint32_t &cnt,
+                                            uint32_t &last, uint32_t &bad, uint32_t &end_at_total) {
+    SegBits b;
+    b.init(L.stage, from);
+    uint32_t c = 0, own_last = kNoLast;
+    const uint32_t hlit = L.hlit;
+    while (b.pos < seg_hi) {
+        if (FINAL && idx >= total) break;
         const uint32_t bits = b.peek();
         const uint32_t e = L.cl_lut[bits & 127u];
         const uint32_t n = e >> 5, sy = e & 31u;
-        if (n == 0u) return INQ_INFLATE_BAD_CODE;
-        uint32_t len, rep;
-        if (sy < 16u) {
-            len = sy, rep = 1u;
-            b.consume(n);
-        } else if (sy == 16u) {
-            if (idx == 0u) return INQ_INFLATE_BAD_HEADER;
-            len = prev, rep = 3u + ((bits >> n) & 3u);
-            b.consume(n + 2u);
-        } else if (sy == 17u) {
-            len = 0u, rep = 3u + ((bits >> n) & 7u);
-            b.consume(n + 3u);
-        } else {
-            len = 0u, rep = 11u + ((bits >> n) & 127u);
-            b.consume(n + 7u);
+        if (n == 0u) {  // cannot happen with a complete code; keeps the loop finite whatever the table holds
+            if (FINAL) bad |= INQ_INFLATE_BAD_CODE;
+            break;
         }
-        if (idx + rep > total) return INQ_INFLATE_BAD_HEADER;
-        prev = len;
-        if (len)  // literal/length lengths at lens[0 .. hlit), distance lengths at lens[kMaxLit .. kMaxLit + hdist); zero-filled before
-            for (uint32_t r = 0; r < rep; ++r) L.lens[idx + r < hlit ? idx + r : kMaxLit + (idx + r - hlit)] = (uint8_t)len;
-        idx += rep;
+        uint32_t len, rep, adv;
+        if (sy < 16u) len = sy, rep = 1u, adv = n, own_last = sy;
+        else if (sy == 16u) {
+            if (FINAL && idx == 0u) {
+                bad |= INQ_INFLATE_BAD_HEADER;
+                break;
+            }
+            len = prev, rep = 3u + ((bits >> n) & 3u), adv = n + 2u;
+        } else if (sy == 17u) len = 0u, rep = 3u + ((bits >> n) & 7u), adv = n + 3u, own_last = 0u;
+        else len = 0u, rep = 11u + ((bits >> n) & 127u), adv = n + 7u, own_last = 0u;
+        b.consume(adv);
+        c += rep;
+        if (FINAL) {
+            if (idx + rep > total) {
+                bad |= INQ_INFLATE_BAD_HEADER;
+                break;
+            }
+            prev = len;
+            if (len)  // literal/length lengths at lens[0 .. hlit), distance lengths at lens[kMaxLit .. kMaxLit + hdist); zero-filled before
+                for (uint32_t r = 0; r < rep; ++r) L.lens[idx + r < hlit ? idx + r : kMaxLit + (idx + r - hlit)] = (uint8_t)len;
+            idx += rep;
+            if (idx == total) end_at_total = b.pos;
+        }
     }
-    if (L.lens[256] == 0) return INQ_INFLATE_BAD_HEADER;  // zlib: "missing end-of-block"
-    return 0u;
+    cnt = c;
+    last = own_last;
+    return b.pos;
+}
+
+template <int T>
+__device__ void header_lengths_wg(WgLds<T> &L, uint32_t hp, uint32_t stage_bit0, int tid) {
+    const uint32_t total = L.hlit + L.hdist;
+    const uint32_t seg_hi = hp + 32u * ((uint32_t)tid + 1u);
+    uint32_t start = hp + 32u * (uint32_t)tid;  // lane 0's is true
+    uint32_t cnt = 0, last = kNoLast, bad = 0, dummy = 0;
+    uint32_t end = cl_walk<T, false>(L, start, seg_hi, 0u, 0u, total, cnt, last, bad, dummy);
+    uint32_t idx0 = 0;
+    for (int it = 0; it <= T; ++it) {
+        L.end_bit[tid] = end;
+        __syncthreads();
+        const uint32_t left = tid == 0 ? start : L.end_bit[tid - 1];
+        const bool mismatch = left != start;
+        uint32_t tot, d0, d1;
+        wg_scan2<T>(cnt, 0u, idx0, d0, tot, d1, L.red, L.red2);
+        const uint32_t first_bad = wg_min<T>(mismatch ? (uint32_t)tid : 0xffffu, L.red);
+        // the lanes in front of first_bad are final: do their symbols reach the end of the sequence?
+        if (tid == 0) L.flag = first_bad == 0xffffu ? tot : 0u;
+        __syncthreads();
+        if ((uint32_t)tid == first_bad) L.flag = idx0;
+        __syncthreads();
+        if (L.flag >= total) break;  // (128 lanes x 32 bits hold >= 585 lengths: with no lane left to fix, the sum is beyond total)
+        if (mismatch) {
+            start = left;
+            end = cl_walk<T, false>(L, start, seg_hi, 0u, 0u, total, cnt, last, bad, dummy);
+        }
+        __syncthreads();  // end_bit[] and flag read by everyone before they are rewritten
+    }
+    // the length in front of a lane's first symbol (a "copy the previous length" there needs it): the nearest lane to the
+    // left that leaves one behind
+    L.last_sh[tid] = (uint8_t)last;
+    __syncthreads();
+    uint32_t end_at_total = 0xffffffffu;
+    if (idx0 < total) {
+        uint32_t prev = 0;
+        for (int j = tid - 1; j >= 0; --j) {
+            const uint32_t v = L.last_sh[j];
+            if (v != kNoLast) {
+                prev = v;
+                break;
+            }
+        }
+        (void)cl_walk<T, true>(L, start, seg_hi, idx0, prev, total, cnt, last, bad, end_at_total);
+    }
+    if (bad) atomicOr(&L.status, bad);
+    if (end_at_total != 0xffffffffu) L.P = stage_bit0 + end_at_total;
+    __syncthreads();
+    if (tid == 0 && L.status == 0u && L.lens[256] == 0) L.status = INQ_INFLATE_BAD_HEADER;  // zlib: "missing end-of-block"
 }
 
 // ---- code construction by the whole workgroup from L.lens (zeroed beyond hlit / hdist)
@@ -602,11 +674,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
         if (L.type == 2u) {
             if (tid < 19) header_cl_table<T>(L, tid);
             __syncthreads();
-            if (tid == 0 && L.status == 0u) {
-                const uint32_t st = header_lengths<T>(L, hb, (uint32_t)(WgLds<T>::kStage - 4) * 32u);
-                L.P = (P0 & ~31u) + hb.pos;
-                if (st) L.status = st;
-            }
+            if (L.status == 0u) header_lengths_wg<T>(L, L.P - (P0 & ~31u), P0 & ~31u, tid);  // uniform: status was written before the barrier
             __syncthreads();
             if (L.status) break;
         }
