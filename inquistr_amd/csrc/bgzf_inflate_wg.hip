@@ -632,7 +632,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
     // dev-time probe (debug_flags & 8): per block {deflate blocks, rounds, count passes, match sweeps, kilo-cycles in
     // header+tables, counting, commit, matches} into block_status[8 * bi ..] for bi < n_blocks / 8
     uint32_t dbg_n[5] = {0, 0, 0, 0, 0};
-    uint64_t dbg_c[5] = {0, 0, 0, 0, 0}, dbg_t = clock64();
+    uint64_t dbg_c[6] = {0, 0, 0, 0, 0, 0}, dbg_t = clock64();
 #define DBG_N(i) ++dbg_n[i]
 #define DBG_LAP(i) { const uint64_t now_ = clock64(); dbg_c[i] += now_ - dbg_t; dbg_t = now_; }
 #else
@@ -843,6 +843,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                         if (L.flag == 0u) break;
                         __syncthreads();
                     }
+                    DBG_LAP(5);
                     const uint8_t *from = out + r0 - 32768;  // root r lives at from[r]; never dereferenced in front of the block (distance check)
                     uint8_t *dstb = out + r0;
                     for (uint32_t g = (uint32_t)tid; g < n4; g += T) {
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
         __syncthreads();
         if (tid == 0 && bi < a.n_blocks / 8) {
             uint32_t *o = a.block_status + 8 * bi;
-            o[0] = dbg_n[0] | dbg_n[4] << 8 | dbg_n[3] << 20, o[1] = dbg_n[1], o[2] = dbg_n[2];  // deflate blocks | stretches | sweeps
+            o[0] = dbg_n[0] | dbg_n[4] << 8 | dbg_n[3] << 20, o[1] = dbg_n[1] | (uint32_t)(dbg_c[5] >> 10) << 8, o[2] = dbg_n[2];  // deflate blocks | stretches | sweeps; rounds | kcyc in the sweeps
             o[3] = (uint32_t)(dbg_c[0] >> 10), o[4] = (uint32_t)(dbg_c[4] >> 10), o[5] = (uint32_t)(dbg_c[1] >> 10), o[6] = (uint32_t)(dbg_c[2] >> 10),
             o[7] = (uint32_t)(dbg_c[3] >> 10);
         }

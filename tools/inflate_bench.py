@@ -80,6 +80,9 @@ def main():
             first = st[: len(st) // 8 * 8].reshape(-1, 8)[:, 0].astype(np.int64)
             print(f"  stretches: mean {((first >> 8) & 0xfff).mean():.1f}  sweeps: mean {(first >> 20).mean():.1f}")
             v[:, 0] = first & 0xff
+            second = st[: len(st) // 8 * 8].reshape(-1, 8)[:, 1].astype(np.int64)
+            print(f"  kcyc in the sweeps (the rest of 'matches' is the gather): mean {(second >> 8).mean():.1f}")
+            v[:, 1] = second & 0xff
             names = ["deflate blocks", "rounds", "count passes", "kcyc header parse", "kcyc tables", "kcyc counting", "kcyc commit", "kcyc matches"]
             for k, nm in enumerate(names):
                 print(f"  {nm}: mean {v[:, k].mean():.1f} median {np.median(v[:, k]):.1f} max {v[:, k].max():.0f}")
