@@ -172,7 +172,7 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * following batches is offered more than N reads (N <= 64 skips both extra launches; a violated promise
  * is reported as INQ_ERR_ARG), 0 (default) = unknown;
  * "verify_crc" = 0 skips the CRC32 check of the device front end (default 1);
- * "inflate_algo" = 0 inflates with one workgroup per BGZF block (no latency floor, 0.6-0.85 ms per 1000 blocks), 1 with one
+ * "inflate_algo" = 0 inflates with one workgroup per BGZF block (no latency floor, 0.54-0.82 ms per 1000 blocks), 1 with one
  * lane per block (36-56 ms for up to ~65 000 blocks), 2 (default) = the quicker one, which is 0 at every size measured;
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void bgzf_crc32_kernel(InflateArgs a) {
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s) {
     if (!a.n_blocks) return;
     const uint64_t grid = (a.n_blocks + kLanes - 1) / kLanes;
-    // Two kernels, one job.  A workgroup per block (bgzf_inflate_wg.hip) costs 0.6-0.85 ms per 1000 blocks and has no floor; a
+    // Two kernels, one job.  A workgroup per block (bgzf_inflate_wg.hip) costs 0.54-0.82 ms per 1000 blocks and has no floor; a
     // lane per block (this file) takes 36-56 ms for anything up to ~65 000 blocks and then doubles.  Since the round-2 work on
     // the workgroup kernel it is the quicker one at every size measured (profiles/r02_front/README.md: 80 000 blocks 47 / 84 ms),
     // so "auto" means it; the lane-per-block kernel stays selectable and goes through the same tests.
