@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -369,7 +370,10 @@ private:
         SpanLoader loader;
         std::string e;
         if (!loader.open(path_, &e)) return fail(e);
-        for (;;) {
+        // span k + 1 is planned (index searches for some 25 000 loci: ~4 ms) on a helper thread while span k is being read
+        SpanPlan ahead;
+        bool have = planner_.next(ahead);
+        while (have) {
             Item *it = nullptr;
             {
                 std::unique_lock<std::mutex> g(mu_);
@@ -379,7 +383,8 @@ private:
                 free_.pop_back();
             }
             const auto t0 = std::chrono::steady_clock::now();
-            if (!planner_.next(it->plan)) break;
+            std::swap(it->plan, ahead);
+            std::future<bool> more = std::async(std::launch::async, [&] { return planner_.next(ahead); });  // joined by get() or by its destructor
             uint64_t nbytes = 0;
             const auto t1 = std::chrono::steady_clock::now();
             if (!loader.total_bytes(it->plan, &nbytes, &e)) return fail(e);
@@ -395,6 +400,7 @@ private:
                              ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), nbytes / 1e6,
                              it->plan.segs.size(), it->data.anchors.size());
             }
+            have = more.get();
             std::lock_guard<std::mutex> g(mu_);
             if (stage_) {
                 loaded_.push_back(it);

@@ -17,6 +17,7 @@ static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32
 
 // ---------------------------------------------------------------- .bai views
 const BaiAnchors::PerRef &BaiAnchors::ref(int tid) {
+    std::lock_guard<std::mutex> g(mu_);  // built once, never changed afterwards: readers need no lock behind this call
     PerRef &P = refs_[tid];
     if (P.built) return P;
     const BaiRef &R = idx_.refs[tid];

@@ -12,6 +12,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/inquistr_hip.h"
@@ -36,6 +37,7 @@ struct BaiAnchors {
 private:
     const BaiIndex &idx_;
     std::vector<PerRef> refs_;
+    std::mutex mu_;  // a contig's anchors are built on first use, by the planner or the loader, whoever comes first
 };
 
 // A run of consecutive BGZF blocks: from the block of vo_begin to the block of vo_limit.
