@@ -76,6 +76,29 @@ def test_inflate_matches_zlib(ctx):
         assert got == w, (len(w), w[:16])
 
 
+def test_inflate_of_the_references_own_gzip_members(ctx):
+    """The only compressed streams the reference repository holds (test-data/file{1,2,3}.inq.gz, written by another
+    compressor than this repo's zlib): their DEFLATE payloads and CRC32 / ISIZE trailers through the device inflate."""
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    comp, table, want, out_off = b"", [], b"", 0
+    for i in (1, 2, 3):
+        gz = open(os.path.join(golden, f"reference_file{i}.inq.gz"), "rb").read()
+        text = open(os.path.join(golden, f"reference_file{i}.inq"), "rb").read()
+        assert gz[:3] == b"\x1f\x8b\x08" and gz[3] == 8  # FNAME only
+        at = gz.index(b"\0", 10) + 1  # behind the zero-terminated file name
+        crc, isize = struct.unpack("<II", gz[-8:])
+        assert isize == len(text) and crc == zlib.crc32(text)
+        # the kernel's unit is a BGZF block: 18 bytes of header in front of the payload, the trailer behind it
+        comp += bytes(18) + gz[at:]
+        table.append((len(comp) - len(gz[at:]), len(gz[at:]) - 8, isize, out_off))
+        want += text
+        out_off += isize
+    blocks = np.array(table, dtype=hipcall.BGZF_BLOCK_DTYPE)
+    rc, out, status = ctx.bgzf_inflate(comp, blocks)
+    assert rc == 0 and not status.any()
+    assert out.tobytes() == want
+
+
 def test_inflate_multi_member_and_eof_block(ctx):
     # a deflate stream of several blocks inside one BGZF block (Z_FULL_FLUSH between them) + the EOF marker
     rng = random.Random(9)
