@@ -120,6 +120,42 @@ def test_inflate_multi_member_and_eof_block(ctx):
     assert out.tobytes() == data + data
 
 
+def test_inflate_many_deflate_blocks_per_bgzf_block(ctx):
+    """Hundreds of tiny deflate blocks (sync / full flushes, changing strategy) inside one BGZF block: every one has its own
+    header, which the workgroup kernel decodes with all lanes."""
+    rng = random.Random(77)
+    blobs, want = [], []
+    for case in range(24):
+        n_cuts = rng.choice([5, 40, 150, 400])
+        size = rng.choice([3000, 20000, 60000])
+        kind = case % 3
+        if kind == 0:
+            data = bytes(rng.choice(b"ACGTN\x00\x10\x20") for _ in range(size))
+        elif kind == 1:
+            words = [bytes(rng.getrandbits(8) for _ in range(rng.randint(2, 30))) for _ in range(200)]
+            data = b"".join(rng.choice(words) for _ in range(size // 10))[:size]
+        else:
+            data = bytes(rng.getrandbits(8) if rng.random() < 0.5 else 65 for _ in range(size))  # every byte value: full-size headers
+        cuts = sorted(rng.randrange(0, len(data) + 1) for _ in range(n_cuts))
+        co = zlib.compressobj(rng.choice([1, 6, 9]), zlib.DEFLATED, -15, 8, rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE]))
+        payload, prev = b"", 0
+        for c in cuts:
+            payload += co.compress(data[prev:c]) + co.flush(rng.choice([zlib.Z_FULL_FLUSH, zlib.Z_SYNC_FLUSH, zlib.Z_BLOCK]))
+            prev = c
+        payload += co.compress(data[prev:]) + co.flush()
+        if 18 + len(payload) + 8 > 65536:
+            continue
+        hdr = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(payload) + 8 - 1)
+        blobs.append(hdr + payload + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+        want.append(data)
+    assert len(blobs) >= 12
+    comp = b"".join(blobs)
+    blocks = hipcall.scan_bgzf(comp)
+    rc, out, status = ctx.bgzf_inflate(comp, blocks)
+    assert rc == 0 and not status.any()
+    assert out.tobytes() == b"".join(want)
+
+
 def test_inflate_reports_corruption(ctx):
     rng = random.Random(11)
     data = bytes(rng.choice(b"ACGTN") for _ in range(30000))
