@@ -342,19 +342,33 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
 }
 
 // ---- workgroup-wide helpers (T lanes, T / 64 waves); every lane must call them
+// first lane of the workgroup for which p holds (0xffff: none), for two predicates at once: a ballot and a find-first-bit per
+// wave, one exchange through LDS for both
 template <int T>
-__device__ __forceinline__ uint32_t wg_min(uint32_t v, uint32_t *red) {
-    for (int off = 32; off; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, off);
-        v = o < v ? o : v;
+__device__ __forceinline__ void wg_first2(bool pa, bool pb, uint32_t &fa, uint32_t &fb, uint32_t *red, uint32_t *red2) {
+    const uint64_t ma = ballot64(pa), mb = ballot64(pb);
+    const uint32_t w0 = threadIdx.x & ~63u;
+    const uint32_t a = ma ? w0 + (uint32_t)__ffsll((unsigned long long)ma) - 1u : 0xffffu;
+    const uint32_t b = mb ? w0 + (uint32_t)__ffsll((unsigned long long)mb) - 1u : 0xffffu;
+    if (T == 64) {
+        fa = a, fb = b;
+        return;
     }
-    if (T == 64) return v;
     __syncthreads();  // red[] free again
-    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = a, red2[threadIdx.x >> 6] = b;
     __syncthreads();
-    uint32_t r = red[0];
-    for (int w = 1; w < T / 64; ++w) r = red[w] < r ? red[w] : r;
-    return r;
+    uint32_t ra = red[0], rb = red2[0];
+    for (int w = 1; w < T / 64; ++w) {
+        ra = red[w] < ra ? red[w] : ra;
+        rb = red2[w] < rb ? red2[w] : rb;
+    }
+    fa = ra, fb = rb;
+}
+template <int T>
+__device__ __forceinline__ uint32_t wg_first(bool p, uint32_t *red, uint32_t *red2) {
+    uint32_t fa, fb;
+    wg_first2<T>(p, false, fa, fb, red, red2);
+    return fa;
 }
 // exclusive prefix sums of two values at once; totals through tot_a / tot_b
 template <int T>
@@ -493,7 +507,7 @@ __device__ void header_lengths_wg(WgLds<T> &L, uint32_t hp, uint32_t stage_bit0,
         const bool mismatch = left != start;
         uint32_t tot, d0, d1;
         wg_scan2<T>(cnt, 0u, idx0, d0, tot, d1, L.red, L.red2);
-        const uint32_t first_bad = wg_min<T>(mismatch ? (uint32_t)tid : 0xffffu, L.red);
+        const uint32_t first_bad = wg_first<T>(mismatch, L.red, L.red2);
         // the lanes in front of first_bad are final: do their symbols reach the end of the sequence?
         if (tid == 0) L.flag = first_bad == 0xffffu ? tot : 0u;
         __syncthreads();
@@ -738,8 +752,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 const bool left_stopped = tid != 0 && (left & kStopped);
                 const bool mismatch = !left_stopped && (left & 0x3fffffffu) != start;
                 // first lane that has to decode again, first lane that stopped
-                const uint32_t first_bad = wg_min<T>(mismatch ? (uint32_t)tid : 0xffffu, L.red);
-                const uint32_t first_stop = wg_min<T>((end & kStopped) ? (uint32_t)tid : 0xffffu, L.red2);
+                uint32_t first_bad, first_stop;
+                wg_first2<T>(mismatch, (end & kStopped) != 0u, first_bad, first_stop, L.red, L.red2);
                 if (first_bad == 0xffffu || first_stop < first_bad) {
                     ncommit = first_stop == 0xffffu ? (uint32_t)T : first_stop + 1u;
                     break;
@@ -777,7 +791,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 const uint32_t r_lo = L.off_sh[k0];
                 // k1 = first lane at or behind k0 whose bytes end beyond the array
                 const bool over = (uint32_t)tid >= k0 && (uint32_t)tid < ncommit && off_b + nbytes - r_lo > (uint32_t)WgLds<T>::kRoundCap;
-                uint32_t k1 = wg_min<T>(over ? (uint32_t)tid : 0xffffu, L.red);
+                uint32_t k1 = wg_first<T>(over, L.red, L.red2);
                 const bool lone = k1 == k0;  // a single lane exceeds the array: it writes its literals and matches in order by itself
                 if (k1 == 0xffffu) k1 = ncommit;
                 if (lone) k1 = k0 + 1u;
