@@ -96,7 +96,8 @@ struct WgLds {
     static constexpr int kRoundCap = INQ_WG_CAP;    // output bytes per round (rounds are cut at the lane that would exceed it)
     static_assert(T % 64 == 0 && T >= 64 && T <= 512, "whole waves");
     static_assert((kRoundCap & (kRoundCap - 1)) == 0 && kRoundCap >= 1024 && kRoundCap <= 16384, "root indices are masked with kRoundCap - 1; 32768 + kRoundCap stays below the literal range");
-    static_assert(kSegBits % 32 == 0 && kSegBits >= 64, "segments are whole dwords and longer than the longest symbol (48 bits)");
+    static_assert(kSegBits % 64 == 0 && kSegBits >= 128, "segments are whole dwords, and half a segment is longer than the longest symbol (48 bits)");
+    static_assert(T * kSegBits + 64 <= 65536, "bit positions of a round fit 16 bits (start_sh, mid_sh)");
     uint32_t lut_ll[1 << kLitBits];
     uint32_t lut_d[1 << kDistBits];
     uint32_t stage[kStage];
