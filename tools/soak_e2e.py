@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end soak (GPU box): random BAM + BED through the product (C++ sweep front end + HIP kernels) against
 text built from the naive Python restatement over every record of the BAM.  Run by hand.
-usage: python tools/soak_e2e.py [--cases 60]"""
+usage: python tools/soak_e2e.py [--cases 60] [--frontend host|device] [--seed0 5000]"""
 import argparse, os, pathlib, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from inquistr_amd import call
@@ -11,11 +11,12 @@ from tests.test_host_frontend import _make_case
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
 ap.add_argument("--frontend", default=None, choices=[None, "host", "device"])
+ap.add_argument("--seed0", type=int, default=5000)
 a = ap.parse_args()
 bad = 0
 with tempfile.TemporaryDirectory() as td:
     for i in range(a.cases):
-        seed = 5000 + i
+        seed = a.seed0 + i
         unphased, threads = bool(i & 1), [1, 4, 7][i % 3]
         if a.frontend == "device":  # vary how the file is cut into spans and segments, and the BGZF block size
             os.environ["INQ_SPAN_GAP_BYTES"] = str([0, 128 << 10, 2000][i % 3])
@@ -31,5 +32,7 @@ with tempfile.TemporaryDirectory() as td:
             print(f"MISMATCH seed={seed} unphased={unphased} threads={threads}", flush=True)
         for p in (bam, bam + ".bai", bed):
             os.unlink(p)
+        if i % 10 == 9:
+            print(f"  {i + 1} cases, {bad} mismatches so far", flush=True)
 print(f"e2e soak done ({a.frontend or 'auto'} front end): {a.cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
