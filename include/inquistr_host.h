@@ -60,6 +60,24 @@ int inq_genotype_repeats_rows(const inq_call_args_t *args, const uint32_t *targe
 int inq_host_partition(const inq_call_args_t *args, uint64_t world, uint32_t *order, uint64_t order_cap, uint64_t *cuts, uint64_t *n_targets,
                        char *errbuf, size_t errcap);
 
+/* ---- a prepared run: what get_targets + get_bam_reader leave behind (src/call.rs:146-147,182-202), kept open ----
+ * The BAM header, its index and the target list are read ONCE; the handle then serves the work split, this process's rows and
+ * the output stage of a multi-process run (inquistr_amd/call_dist.py), so that rank 0 neither re-opens the BAM nor re-parses
+ * the BED for the names, and the ordered .inq text (src/call.rs:137-157) is written by the same code as in inq_genotype_repeats. */
+typedef struct inq_run inq_run_t;
+int inq_run_open(const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap); /* statuses as inq_genotype_repeats */
+uint64_t inq_run_n_targets(const inq_run_t *run);
+const char *inq_run_sample(const inq_run_t *run);
+int inq_run_target(const inq_run_t *run, uint64_t i, const char **chrom, uint32_t *start, uint32_t *end);
+/* as inq_host_partition; order[] holds inq_run_n_targets() entries, cuts[] world + 1.  No GPU involved. */
+int inq_run_partition(inq_run_t *run, uint64_t world, uint32_t *order, uint64_t *cuts, char *errbuf, size_t errcap);
+/* as inq_genotype_repeats_rows (runs on the GPU) */
+int inq_run_rows(inq_run_t *run, const uint32_t *target_index, uint64_t n_index, double *phase1, double *phase2, char *errbuf, size_t errcap);
+/* header + one row per target (phase1[i], phase2[i] = row of target i of the list; n_rows must equal inq_run_n_targets) to
+ * out_fd: BED order for -t 1, (human_compare(chrom), start) order for -t >= 2 (src/call.rs:33-38,141).  No GPU involved. */
+int inq_run_write_inq(inq_run_t *run, const double *phase1, const double *phase2, uint64_t n_rows, int out_fd, char *errbuf, size_t errcap);
+void inq_run_close(inq_run_t *run);
+
 /* ---- BAM -> batch front end (no GPU involved) ---- */
 typedef struct inq_frontend inq_frontend_t;
 int inq_frontend_open(const inq_call_args_t *args, inq_frontend_t **out, char *errbuf, size_t errcap);

@@ -24,6 +24,14 @@ HOST_ABI_SYMBOLS = (
     "inq_genotype_repeats",
     "inq_genotype_repeats_rows",
     "inq_host_partition",
+    "inq_run_open",
+    "inq_run_n_targets",
+    "inq_run_sample",
+    "inq_run_target",
+    "inq_run_partition",
+    "inq_run_rows",
+    "inq_run_write_inq",
+    "inq_run_close",
     "inq_combine",
     "inq_frontend_open",
     "inq_frontend_n_targets",
@@ -103,6 +111,22 @@ def load():
         L.inq_genotype_repeats_rows.argtypes = [C.POINTER(CallArgsC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
         L.inq_host_partition.restype = C.c_int
         L.inq_host_partition.argtypes = [C.POINTER(CallArgsC), C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+        L.inq_run_open.restype = C.c_int
+        L.inq_run_open.argtypes = [C.POINTER(CallArgsC), C.POINTER(vp), C.c_char_p, C.c_size_t]
+        L.inq_run_n_targets.restype = C.c_uint64
+        L.inq_run_n_targets.argtypes = [vp]
+        L.inq_run_sample.restype = C.c_char_p
+        L.inq_run_sample.argtypes = [vp]
+        L.inq_run_target.restype = C.c_int
+        L.inq_run_target.argtypes = [vp, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.inq_run_partition.restype = C.c_int
+        L.inq_run_partition.argtypes = [vp, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.inq_run_rows.restype = C.c_int
+        L.inq_run_rows.argtypes = [vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.inq_run_write_inq.restype = C.c_int
+        L.inq_run_write_inq.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_char_p, C.c_size_t]
+        L.inq_run_close.restype = None
+        L.inq_run_close.argtypes = [vp]
         L.inq_combine.restype = C.c_int
         L.inq_combine.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
         L.inq_frontend_open.restype = C.c_int
@@ -220,6 +244,72 @@ def partition(bamp: str, region: Optional[str], region_file: Optional[str], worl
         if rc != 0:
             raise CallError(rc, err.value.decode(errors="replace"))
         return order[: n.value].copy(), cuts.astype(np.int64)
+
+
+class Run:
+    """inq_run_*: the BAM header, its index and the targets opened once (get_targets + get_bam_reader, src/call.rs:146-147,
+    182-202); serves the work split, this process's rows and the ordered `.inq` output of a multi-process run."""
+
+    def __init__(self, bamp, region=None, region_file=None, minlen=5, support=3, threads=1, unphased=False, sample_name=None,
+                 device: int = 0, frontend: Optional[str] = None):
+        self._L = load()
+        self._h = C.c_void_p()
+        self._args = _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, None, device, frontend)
+        err = C.create_string_buffer(2048)
+        rc = self._L.inq_run_open(C.byref(self._args), C.byref(self._h), err, len(err))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise CallError(rc, err.value.decode(errors="replace"))
+
+    @property
+    def n_targets(self) -> int:
+        return int(self._L.inq_run_n_targets(self._h))
+
+    @property
+    def sample(self) -> str:
+        return self._L.inq_run_sample(self._h).decode()
+
+    def partition(self, world: int):
+        n = self.n_targets
+        order = np.zeros(max(n, 1), dtype=np.uint32)
+        cuts = np.zeros(world + 1, dtype=np.uint64)
+        err = C.create_string_buffer(2048)
+        rc = self._L.inq_run_partition(self._h, world, order.ctypes.data, cuts.ctypes.data, err, len(err))
+        if rc != 0:
+            raise CallError(rc, err.value.decode(errors="replace"))
+        return order[:n].copy(), cuts.astype(np.int64)
+
+    def rows(self, target_index):
+        idx = np.ascontiguousarray(target_index, dtype=np.uint32)
+        p1 = np.full(len(idx), np.nan)
+        p2 = np.full(len(idx), np.nan)
+        err = C.create_string_buffer(2048)
+        rc = self._L.inq_run_rows(self._h, idx.ctypes.data, len(idx), p1.ctypes.data, p2.ctypes.data, err, len(err))
+        if rc != 0:
+            raise CallError(rc, err.value.decode(errors="replace"))
+        return p1, p2
+
+    def write_inq(self, phase1, phase2, out=None) -> None:
+        """The output stage (src/call.rs:137-157) on rows in target-list order: one C call, whatever the row count."""
+        p1 = np.ascontiguousarray(phase1, dtype=np.float64)
+        p2 = np.ascontiguousarray(phase2, dtype=np.float64)
+        out = sys.stdout if out is None else out
+        out.flush()
+        err = C.create_string_buffer(2048)
+        rc = self._L.inq_run_write_inq(self._h, p1.ctypes.data, p2.ctypes.data, len(p1), out.fileno(), err, len(err))
+        if rc != 0:
+            raise CallError(rc, err.value.decode(errors="replace"))
+
+    def close(self):
+        if self._h and self._h.value:
+            self._L.inq_run_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def combine(calls, out=None) -> None:

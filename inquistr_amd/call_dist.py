@@ -13,7 +13,6 @@ rayon loop over loci (src/call.rs:115-136), which shares nothing but the output 
 from __future__ import annotations
 
 import argparse
-import functools
 import os
 import sys
 import tempfile
@@ -44,22 +43,26 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
                                  support: int = 3, threads: int = 1, unphased: bool = False,
                                  sample_name: Optional[str] = None, out=None, rank: int = 0, world: int = 1,
                                  device: int = 0, compute: Optional[Callable] = None, group=None,
-                                 frontend: Optional[str] = None) -> None:
+                                 frontend: Optional[str] = None, stats: Optional[dict] = None) -> None:
     """Same arguments as call.genotype_repeats plus (rank, world).  Rank 0 writes header + rows.
-    Raises CallError (same status on every rank) if any rank fails."""
+    Raises CallError (same status on every rank) if any rank fails.  stats (rank 0): seconds of the output stage."""
     import torch
     import torch.distributed as dist
 
     # ---- the work split, computed ONCE (rank 0: BED + .bai through the C++ host library) and broadcast: contiguous slices of
-    # the targets in file order, cut so that every rank has about the same amount of BAM to read (SURVEY.md 8e)
+    # the targets in file order, cut so that every rank has about the same amount of BAM to read (SURVEY.md 8e).  Rank 0 keeps
+    # the opened run (header, index, targets) for its own rows and for the output stage: nothing is opened or parsed twice.
     plan = [None]
     st, msg = 0, ""
+    run = None
     if rank == 0:
         try:
-            order, cuts = hostcall.partition(bamp, region, region_file, world)
-            plan = [(order, cuts)]
+            run = hostcall.Run(bamp, region, region_file, minlen, support, threads, unphased, sample_name, device=device, frontend=frontend)
+            plan = [run.partition(world)]
         except hostcall.CallError as e:
             st, msg = e.status, e.message
+        except Exception as e:  # noqa: BLE001  (library missing, out of memory, ...): the other ranks must not wait in the broadcast
+            st, msg = 1, f"{type(e).__name__}: {e}"
     if world > 1:
         head = [(st, msg, plan[0])]
         dist.broadcast_object_list(head, src=0, group=group)
@@ -78,8 +81,11 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
         if len(mine) and compute is None:
             # the product path: the C++ driver on this rank's share (inq_genotype_repeats_rows), which picks the device front end
             # (inflate + record scan + join on this rank's GPU) or the host sweep by the amount of BAM; rows come back as f64
-            p1, p2 = hostcall.genotype_repeats_rows(bamp, region, region_file, mine, minlen, support, threads, unphased,
-                                                    device=device, frontend=frontend)
+            if run is not None:
+                p1, p2 = run.rows(mine)
+            else:
+                p1, p2 = hostcall.genotype_repeats_rows(bamp, region, region_file, mine, minlen, support, threads, unphased,
+                                                        device=device, frontend=frontend)
         elif len(mine):  # tests: per-batch compute supplied by the caller (the oracle, on CPU-only machines)
             fe_all = hostcall.FrontEnd(bamp, region=region, region_file=region_file)
             targets = fe_all.targets()
@@ -123,30 +129,17 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
     else:
         full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
         full1[mine], full2[mine] = p1, p2
-    # ---- output (rank 0), src/call.rs:137-157: BED order for -t 1, (human chrom, start) order otherwise
-    fe_all = hostcall.FrontEnd(bamp, region=region, region_file=region_file, sample_name=sample_name)
-    targets = fe_all.targets()
-    sample = fe_all.sample
-    fe_all.close()
-    L = hostcall.load()
-    import ctypes as C
+    # ---- output (rank 0), src/call.rs:137-157: BED order for -t 1, (human chrom, start) order otherwise.  One call into the
+    # host library on the f64 arrays (the code inq_genotype_repeats itself ends with): 500 000 rows take tens of milliseconds
+    import time
 
-    rows = list(range(n))
-    if threads > 1:
-        def cmp(x, y):
-            c = L.inq_host_human_compare(targets[x][0].encode(), targets[y][0].encode())
-            return c or (targets[x][1] > targets[y][1]) - (targets[x][1] < targets[y][1])
-
-        rows.sort(key=functools.cmp_to_key(cmp))
     out = sys.stdout if out is None else out
-    buf = C.create_string_buffer(4096)
-    L.inq_host_format_header(sample.encode(), buf, len(buf))
-    lines = [buf.value.decode()]
-    for i in rows:
-        L.inq_host_format_row(targets[i][0].encode(), targets[i][1], targets[i][2], float(full1[i]), float(full2[i]), buf, len(buf))
-        lines.append(buf.value.decode())
-    out.write("\n".join(lines) + "\n")
-    out.flush()
+    t0 = time.perf_counter()
+    run.write_inq(full1, full2, out)
+    if stats is not None:
+        stats["output_s"] = time.perf_counter() - t0
+        stats["rows"] = n
+    run.close()
 
 
 def main(argv: Optional[List[str]] = None) -> int:

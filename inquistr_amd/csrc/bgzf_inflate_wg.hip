@@ -495,6 +495,9 @@ __device__ __forceinline__ uint32_t cl_walk(WgLds<T> &L, uint32_t from, uint32_t
 
 template <int T>
 __device__ void header_lengths_wg(WgLds<T> &L, uint32_t hp, uint32_t stage_bit0, int tid) {
+    // 286 + 30 code lengths of <= 7 bits: a valid sequence ends within 2212 bits behind the 14 + 3 * 19 bits in front of it;
+    // with fewer lanes than that the loop below could end without any lane reaching the sequence's end
+    static_assert(T * 32 >= 2212 + 14, "one 32-bit slice per lane must cover the longest code-length sequence (T >= 128)");
     const uint32_t total = L.hlit + L.hdist;
     const uint32_t seg_hi = hp + 32u * ((uint32_t)tid + 1u);
     uint32_t start = hp + 32u * (uint32_t)tid;  // lane 0's is true
@@ -539,8 +542,10 @@ __device__ void header_lengths_wg(WgLds<T> &L, uint32_t hp, uint32_t stage_bit0,
     }
     if (bad) atomicOr(&L.status, bad);
     if (end_at_total != 0xffffffffu) L.P = stage_bit0 + end_at_total;
-    __syncthreads();
-    if (tid == 0 && L.status == 0u && L.lens[256] == 0) L.status = INQ_INFLATE_BAD_HEADER;  // zlib: "missing end-of-block"
+    // no lane saw the last length: the sequence runs out of the staged bits (cannot happen in a valid stream, see the
+    // static_assert) - never continue from a stale L.P
+    const int reached = __syncthreads_or(end_at_total != 0xffffffffu ? 1 : 0);
+    if (tid == 0 && L.status == 0u && (!reached || L.lens[256] == 0)) L.status = INQ_INFLATE_BAD_HEADER;  // zlib: "missing end-of-block"
 }
 
 // ---- code construction by the whole workgroup from L.lens (zeroed beyond hlit / hdist)

@@ -34,6 +34,9 @@ bool BaiIndex::load(const std::string &path, std::string *err) {
     p = 4;
     uint32_t n_ref = le32(&d[p]);
     p += 4;
+    // every contig takes at least its n_bin and n_intv words: a count the file cannot hold is damage, and must be refused
+    // BEFORE one BaiRef per claimed contig is built (a flipped n_ref of 2e8 would otherwise allocate tens of GB first)
+    if ((uint64_t)n_ref > (d.size() - p) / 8) goto trunc;
     refs.assign(n_ref, BaiRef());
     for (uint32_t r = 0; r < n_ref; ++r) {
         BaiRef &R = refs[r];
@@ -112,6 +115,7 @@ bool BaiIndex::load_csi(const std::string &path, std::string *err) {
     {
         const uint32_t n_ref = le32(&d[p]);
         p += 4;
+        if ((uint64_t)n_ref > (d.size() - p) / 4) goto trunc;  // a contig takes at least its n_bin word (see load())
         refs.assign(n_ref, BaiRef());
         csi = true;
         const uint32_t meta = meta_bin();
@@ -135,6 +139,11 @@ bool BaiIndex::load_csi(const std::string &path, std::string *err) {
                 } else {
                     auto &v = R.bins[bin];
                     R.loff[bin] = loffset;
+                    if (n_chunk && bin < level_first(depth + 1)) {
+                        int l = 0;
+                        while (bin >= level_first(l + 1)) ++l;
+                        R.csi_reach = std::max(R.csi_reach, (int64_t)(bin - level_first(l) + 1) << level_shift(l));
+                    }
                     for (uint32_t c = 0; c < n_chunk; ++c) {
                         const uint64_t beg = le64(&d[p + 16 * c]), end = le64(&d[p + 16 * c + 8]);
                         v.emplace_back(beg, end);
@@ -175,8 +184,9 @@ uint64_t BaiIndex::scan_start(int tid, int64_t beg) const {
     if (R.bins.empty()) return 0;
     if (beg < 0) beg = 0;
     if (csi) {
-        // nothing at or behind beg when every bin ends in front of it; otherwise htslib's starting offset, and where that
-        // is 0 (no bin at or in front of beg's window) the contig's first record
+        // nothing at or behind beg when every bin ends in front of it (a record lies inside its bin); otherwise htslib's
+        // starting offset, and where that is 0 (no bin at or in front of beg's window) the contig's first record
+        if (beg >= R.csi_reach) return 0;
         const uint64_t off = csi_min_off(tid, beg);
         return off ? off : R.min_offset;
     }
@@ -266,21 +276,23 @@ bool BamFile::open(const std::string &path, std::string *err) {
         name2tid_.emplace(name, (int)i);  // first wins, like a hash built front to back
     }
     first_rec_ = bgzf_.tell();
-    // [3P] htslib looks for <path>.csi, then <path>.bai, then the same with the file's extension dropped
-    std::string e1, e2;
+    // [3P] htslib (hts_idx_load -> idx_find_and_load: hts_idx_getfn(fn, ".csi") first, ".bai" only after it): <path>.csi, then
+    // <path minus extension>.csi, then <path>.bai, then <path minus extension>.bai.  With x.bam.bai next to x.csi the .csi wins.
+    // The first of the four that EXISTS is the index; failing to load it is an error (no falling through to the next).
     std::string alt = path;
     const size_t dot = alt.rfind('.');
-    if (dot != std::string::npos) alt = alt.substr(0, dot);
+    const size_t slash = alt.rfind('/');
+    if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) alt = alt.substr(0, dot);
     auto exists = [](const std::string &f) {
         FILE *t = std::fopen(f.c_str(), "rb");
         if (t) std::fclose(t);
         return t != nullptr;
     };
     if (exists(path + ".csi")) return bai_.load_csi(path + ".csi", err);
-    if (bai_.load(path + ".bai", &e1)) return true;
-    if (exists(alt + ".csi")) return bai_.load_csi(alt + ".csi", err);
-    if (bai_.load(alt + ".bai", &e2)) return true;
-    if (err) *err = "could not load index for " + path + " (" + e1 + ")";
+    if (alt != path && exists(alt + ".csi")) return bai_.load_csi(alt + ".csi", err);
+    if (exists(path + ".bai")) return bai_.load(path + ".bai", err);
+    if (alt != path && exists(alt + ".bai")) return bai_.load(alt + ".bai", err);
+    if (err) *err = "could not load index for " + path + " (no .csi or .bai next to it)";
     return false;
 }
 

@@ -28,6 +28,7 @@ struct BaiRef {
     uint64_t n_mapped = 0, n_unmapped = 0;
     bool has_meta = false;
     uint64_t min_offset = 0, max_offset = 0;  // over real bins
+    int64_t csi_reach = 0;  // .csi only: end of the right-most real bin - no record of the contig reaches this position
 };
 
 // A .bai, or a .csi ([3P] htslib: IndexedReader::from_path takes either, src/call.rs:242).  Both use the UCSC binning
@@ -46,8 +47,11 @@ struct BaiIndex {
     // .csi: the offset htslib's iterator starts from for position beg - the loff of the deepest existing bin at or in
     // front of beg's window, walking left through the siblings and up through the parents ([3P] hts_itr_query)
     uint64_t csi_min_off(int tid, int64_t beg) const;
-    // smallest virtual offset from which a forward scan sees every record of `tid` overlapping
-    // positions >= beg; 0 when the contig has no records at or after beg.
+    // a virtual offset from which a forward scan sees every record of `tid` overlapping positions >= beg; 0 when the
+    // index shows that the contig has no such record (.bai: no filled linear-index window at or behind beg; .csi: beg
+    // lies behind the contig's right-most bin).  .bai: the smallest such offset, monotone in beg.  .csi: htslib's
+    // iterator start (csi_min_off), which is NOT monotone in beg (a deeper bin left of beg can carry a larger loff
+    // than its parent): the planner opens a new span when an offset steps back.
     uint64_t scan_start(int tid, int64_t beg) const;
     // [3P] htslib hts_itr_query for a BAI: the chunks a region query [beg, end) has to read, from the
     // bins overlapping the region, cut below by the linear index, sorted and merged.
@@ -73,8 +77,8 @@ struct BamRec {
 class BamFile {
 public:
     explicit BamFile(int n_threads = 1) : bgzf_(n_threads) {}
-    // Opens <path> and its index (<path>.bai, else <path minus .bam>.bai). Both are required, as for
-    // IndexedReader::from_path.
+    // Opens <path> and its index (<path>.csi, <path minus extension>.csi, <path>.bai, <path minus extension>.bai: htslib's
+    // order). Both are required, as for IndexedReader::from_path.
     bool open(const std::string &path, std::string *err);
     const std::vector<BamRef> &refs() const { return refs_; }
     const std::string &header_text() const { return text_; }

@@ -118,15 +118,16 @@ int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg) {
     return INQ_EXIT_OK;
 }
 
-bool write_all(int fd, const std::string &s) {
+bool write_all(int fd, const char *data, size_t len) {
     size_t off = 0;
-    while (off < s.size()) {
-        ssize_t w = ::write(fd, s.data() + off, s.size() - off);
+    while (off < len) {
+        ssize_t w = ::write(fd, data + off, len - off);
         if (w <= 0) return false;
         off += (size_t)w;
     }
     return true;
 }
+bool write_all(int fd, const std::string &s) { return write_all(fd, s.data(), s.size()); }
 
 }  // namespace
 
@@ -593,14 +594,14 @@ struct AsyncCtx {
 
 // front end selection: args->reserved 1 = host sweep (BGZF inflate + record decode on CPU threads),
 // 2 = device (inq_call_span); 0 = INQ_FRONTEND=host|device, else by the amount of BAM the loci need
-static bool use_device_front(const inq_call_args_t *args, const Prepared &P) {
+static bool use_device_front(const inq_call_args_t *args, const BamFile &bam, const std::vector<RepeatInterval> &targets) {
     if (args->reserved == 1) return false;
     if (args->reserved == 2) return true;
     const char *e = std::getenv("INQ_FRONTEND");
     if (e && std::strcmp(e, "host") == 0) return false;
     if (e && std::strcmp(e, "device") == 0) return true;
     // auto: plan without reading anything and count the compressed bytes the loci need
-    SpanPlanner planner(*P.bam, P.targets, ~0ull >> 1);
+    SpanPlanner planner(bam, targets, ~0ull >> 1);
     SpanPlan plan;
     uint64_t bytes = 0;
     while (planner.next(plan))
@@ -609,7 +610,16 @@ static bool use_device_front(const inq_call_args_t *args, const Prepared &P) {
 }
 
 // fills p1 / p2 through the device front end; returns an exit status
-static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncCtx &actx, std::vector<double> &p1,
+// what one call works on: the opened BAM (header + index), the targets it was asked for, the options
+struct CallView {
+    BamFile &bam;
+    const std::vector<RepeatInterval> &targets;
+    const std::string &sample;
+    uint32_t minlen, support;
+    bool unphased;
+};
+
+static int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,
                             std::vector<double> &p2, char *errbuf, size_t errcap, double *t_front, double *t_dev) {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -635,7 +645,7 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
             ~PipeHolder() {
                 if (!leak) delete p;
             }
-        } holder{new SpanPipeline(args->bam, *F->P.bam, F->P.targets, span_bytes_from_env(), n_io, pin_env ? pin_env[0] == '1' : false,
+        } holder{new SpanPipeline(args->bam, V.bam, V.targets, span_bytes_from_env(), n_io, pin_env ? pin_env[0] == '1' : false,
                                   // the loader uploads every span it has read (waiting for the context the first time), so
                                   // that the upload of span k+1 overlaps the inflate of span k
                                   [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; }),
@@ -664,9 +674,9 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
             }
             inq_span_t sp;
             SpanPipeline::fill_span(*it, &sp);
-            sp.minlen = F->minlen;
-            sp.support = F->support;
-            sp.unphased = F->unphased ? 1u : 0u;
+            sp.minlen = V.minlen;
+            sp.support = V.support;
+            sp.unphased = V.unphased ? 1u : 0u;
             b1.assign(sp.n_loci, NAN);
             b2.assign(sp.n_loci, NAN);
             inq_result_t res;
@@ -710,8 +720,8 @@ static int run_device_front(const inq_call_args_t *args, inq_frontend *F, AsyncC
     return INQ_EXIT_OK;
 }
 
-static int write_rows(const inq_call_args_t *args, inq_frontend *F, const std::vector<double> &p1, const std::vector<double> &p2,
-                      int out_fd, char *errbuf, size_t errcap);
+static int write_rows(uint64_t threads, const std::vector<RepeatInterval> &targets, const std::string &sample, const double *p1,
+                      const double *p2, int out_fd, char *errbuf, size_t errcap);
 
 // rows instead of text: the targets named by idx[] (positions in the parsed target list) are called, their rows go to p1 / p2
 struct RowsOut {
@@ -721,43 +731,39 @@ struct RowsOut {
     bool active = false;
 };
 
-static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap, const RowsOut &rows = RowsOut()) {
+// the call on an opened BAM + parsed targets, on a device context that may outlive it (a session calls many BAMs on one)
+static int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepared &P, int out_fd, char *errbuf, size_t errcap,
+                             const RowsOut &rows, std::chrono::steady_clock::time_point t_start) {
     using clk = std::chrono::steady_clock;
     const bool timing = std::getenv("INQ_TIMING") != nullptr;
-    auto t_start = clk::now();
     double t_front = 0, t_dev = 0;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    AsyncCtx actx;
-    if (args) actx.start(args->device);
-    inq_frontend_t *F = nullptr;
-    int rc = inq_frontend_open_impl(args, &F, errbuf, errcap);
-    if (rc != INQ_EXIT_OK) return rc;
-    std::unique_ptr<inq_frontend> guard(F);
+    std::vector<RepeatInterval> sub;
     if (rows.active) {  // this caller's share of the targets (one process per GPU: inquistr_amd/call_dist.py)
-        std::vector<RepeatInterval> sub;
         sub.reserve(rows.n);
         for (uint64_t k = 0; k < rows.n; ++k) {
-            if (rows.idx[k] >= F->P.targets.size()) {
+            if (rows.idx[k] >= P.targets.size()) {
                 set_err(errbuf, errcap, "target index outside the target list");
                 return INQ_EXIT_ERROR;
             }
-            sub.push_back(F->P.targets[rows.idx[k]]);
+            sub.push_back(P.targets[rows.idx[k]]);
         }
-        F->P.targets.swap(sub);
     }
-    const size_t n = F->P.targets.size();
+    const CallView V{*P.bam, rows.active ? sub : P.targets, P.sample, args->minlen,
+                     (uint32_t)std::min<uint64_t>(args->support, 0xffffffffull), args->unphased != 0};
+    const size_t n = V.targets.size();
     std::vector<double> p1(n, NAN), p2(n, NAN);
     auto emit = [&]() -> int {
-        if (!rows.active) return write_rows(args, F, p1, p2, out_fd, errbuf, errcap);
+        if (!rows.active) return write_rows(args->threads, V.targets, V.sample, p1.data(), p2.data(), out_fd, errbuf, errcap);
         if (n) std::memcpy(rows.p1, p1.data(), n * sizeof(double)), std::memcpy(rows.p2, p2.data(), n * sizeof(double));
         return INQ_EXIT_OK;
     };
 
     const auto t_open = clk::now();
-    const bool device_front = use_device_front(args, F->P);
+    const bool device_front = use_device_front(args, V.bam, V.targets);
     if (device_front) {
         const auto t_choice = clk::now();
-        int drc = run_device_front(args, F, actx, p1, p2, errbuf, errcap, &t_front, &t_dev);
+        int drc = run_device_front(args, V, actx, p1, p2, errbuf, errcap, &t_front, &t_dev);
         if (drc != INQ_EXIT_OK) return drc;
         const auto t_run = clk::now();
         drc = emit();
@@ -804,7 +810,7 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
         }
     } pin;
     const int n_workers = (int)std::max<uint64_t>(1, std::min<uint64_t>(args->threads > 1 ? args->threads - 1 : 1, 64));
-    ParallelFrontEnd pfe(args->bam, *F->P.bam, F->P.targets, F->unphased, n_workers);
+    ParallelFrontEnd pfe(args->bam, V.bam, V.targets, V.unphased, n_workers);
     auto t_ctx = clk::now();
     std::vector<double> b1, b2;
     for (;;) {
@@ -822,7 +828,7 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
         if (nb == 0) break;
         if (!need_ctx()) return INQ_EXIT_ERROR;
         inq_batch_t batch;
-        item.batch.view(&batch, F->minlen, F->support, F->unphased);
+        item.batch.view(&batch, V.minlen, V.support, V.unphased);
         {
             auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
             const size_t s0 = al(batch.n_cigar_words * 4), s1 = al(batch.n_reads * sizeof(inq_read_t)),
@@ -888,18 +894,21 @@ static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, ch
     return INQ_EXIT_OK;
 }
 
-static int write_rows(const inq_call_args_t *args, inq_frontend *F, const std::vector<double> &p1, const std::vector<double> &p2,
-                      int out_fd, char *errbuf, size_t errcap) {
-    const size_t n = F->P.targets.size();
-    // output, src/call.rs:137-157
+// the output stage, src/call.rs:137-157
+static int write_rows(uint64_t threads, const std::vector<RepeatInterval> &targets, const std::string &sample, const double *p1,
+                      const double *p2, int out_fd, char *errbuf, size_t errcap) {
+    const size_t n = targets.size();
+    const bool timing = std::getenv("INQ_TIMING") != nullptr;
+    const auto t_w0 = std::chrono::steady_clock::now();
     std::vector<uint32_t> order(n);
     for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-    if (args->threads > 1) {
+    if (threads > 1) {
         // genotypes_vec.sort_unstable() with Ord = (human_compare(chrom), start), :33-38,141.  Equal keys
         // are in completion order in the reference (nondeterministic); BED order is kept here.
         // The contig names are ranked once (a BED has few distinct ones), the rows sorted on integers.
         std::map<std::string, uint32_t> rank;
-        for (const auto &t : F->P.targets) rank.emplace(t.chrom, 0u);
+        for (size_t i = 0; i < n; ++i)
+            if (i == 0 || targets[i].chrom != targets[i - 1].chrom) rank.emplace(targets[i].chrom, 0u);
         std::vector<const std::string *> names;
         for (auto &kv : rank) names.push_back(&kv.first);
         std::stable_sort(names.begin(), names.end(), [](const std::string *a, const std::string *b) { return human_compare(*a, *b) < 0; });
@@ -908,28 +917,104 @@ static int write_rows(const inq_call_args_t *args, inq_frontend *F, const std::v
             rank[*names[i]] = (uint32_t)r;
         }
         std::vector<uint64_t> key(n);
-        for (size_t i = 0; i < n; ++i) key[i] = ((uint64_t)rank[F->P.targets[i].chrom] << 32) | F->P.targets[i].start;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
-    }
-    std::string text = format_header(F->P.sample) + "\n";
-    text.reserve(64 * (n + 1));
-    for (uint32_t i : order) {
-        const RepeatInterval &t = F->P.targets[i];
-        append_row(text, t.chrom, t.start, t.end, p1[i], p2[i]);
-        text += '\n';
-        if (text.size() > (1u << 20)) {
-            if (!write_all(out_fd, text)) {
-                set_err(errbuf, errcap, "Failed writing the result.");
-                return INQ_EXIT_PANIC;
+        const std::string *last = nullptr;  // neighbouring targets mostly share the contig: one map lookup per run of them
+        uint32_t last_rank = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (!last || *last != targets[i].chrom) last = &targets[i].chrom, last_rank = rank[*last];
+            key[i] = ((uint64_t)last_rank << 32) | targets[i].start;
+        }
+        if (!std::is_sorted(key.begin(), key.end())) {
+            // stable LSD radix sort of the row numbers on the 64-bit key, 16 bits a pass; digits all keys share are skipped
+            // (a BED has few contigs and starts below 2^28: two or three passes instead of n log n compares)
+            uint64_t all_or = 0, all_and = ~0ull;
+            for (uint64_t k : key) all_or |= k, all_and &= k;
+            std::vector<uint32_t> tmp(n);
+            std::vector<uint32_t> cnt(65536);
+            for (int shift = 0; shift < 64; shift += 16) {
+                if ((((all_or ^ all_and) >> shift) & 0xffffu) == 0) continue;
+                std::fill(cnt.begin(), cnt.end(), 0u);
+                for (size_t i = 0; i < n; ++i) ++cnt[(key[order[i]] >> shift) & 0xffffu];
+                uint32_t run = 0;
+                for (auto &c : cnt) {
+                    const uint32_t v = c;
+                    c = run;
+                    run += v;
+                }
+                for (size_t i = 0; i < n; ++i) tmp[cnt[(key[order[i]] >> shift) & 0xffffu]++] = order[i];
+                order.swap(tmp);
             }
-            text.clear();
         }
     }
-    if (!write_all(out_fd, text)) {
+    const auto t_w1 = std::chrono::steady_clock::now();
+    // the text: rows formatted by a few threads into their own stretches of one buffer (sized from an upper bound per row,
+    // written through a bare pointer: no per-character capacity checks), written in order.  Four threads at most: 500 000
+    // rows are 17 MB of text, ~20 ms on one core, and starting a thread costs up to 2 ms on virtualised hosts.
+    const size_t n_parts = n < 65536 ? 1 : std::min<size_t>(4, std::max(1u, std::thread::hardware_concurrency()));
+    const std::string header = format_header(sample) + "\n";
+    std::vector<size_t> part_off(n_parts + 1, 0), part_len(n_parts, 0);
+    auto value_bound = [](double v) -> size_t { return std::fabs(v) < 9007199254740992.0 || std::isnan(v) ? 20 : 330; };
+    for (size_t k = 0; k < n_parts; ++k) {
+        const size_t lo = n * k / n_parts, hi = n * (k + 1) / n_parts;
+        size_t cap = (k == 0 ? header.size() : 0) + (hi - lo) * (2 * 10 + 5) + 128;
+        for (size_t j = lo; j < hi; ++j) {
+            const uint32_t i = order[j];
+            cap += targets[i].chrom.size() + value_bound(p1[i]) + value_bound(p2[i]);
+        }
+        part_off[k + 1] = part_off[k] + ((cap + 63) & ~(size_t)63);
+    }
+    const auto t_w1b = std::chrono::steady_clock::now();
+    const size_t huge = 2u << 20, map_len = (part_off[n_parts] + huge - 1) / huge * huge;
+    char *const base = (char *)::mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == (char *)MAP_FAILED) {
+        set_err(errbuf, errcap, "cannot allocate the output buffer");
+        return INQ_EXIT_ERROR;
+    }
+    auto format_part = [&](size_t k) {
+        const size_t lo = n * k / n_parts, hi = n * (k + 1) / n_parts;
+        char *p = base + part_off[k];
+        if (k == 0) std::memcpy(p, header.data(), header.size()), p += header.size();
+        for (size_t j = lo; j < hi; ++j) {
+            const uint32_t i = order[j];
+            const RepeatInterval &t = targets[i];
+            p = write_row(p, t.chrom, t.start, t.end, p1[i], p2[i]);
+            *p++ = '\n';
+        }
+        part_len[k] = (size_t)(p - (base + part_off[k]));
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < n_parts; ++k) th.emplace_back(format_part, k);
+        format_part(0);
+        for (auto &x : th) x.join();
+    }
+    const auto t_w2 = std::chrono::steady_clock::now();
+    bool wrote = true;
+    for (size_t k = 0; k < n_parts && wrote; ++k) wrote = write_all(out_fd, base + part_off[k], part_len[k]);
+    ::munmap(base, map_len);
+    if (!wrote) {
         set_err(errbuf, errcap, "Failed writing the result.");
         return INQ_EXIT_PANIC;
     }
+    if (timing) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[inq output] %zu rows: order %.2f ms, bounds %.2f ms, text %.2f ms (%zu threads), write %.2f ms\n", n, ms(t_w0, t_w1), ms(t_w1, t_w1b), ms(t_w1b, t_w2),
+                     n_parts, ms(t_w2, std::chrono::steady_clock::now()));
+    }
     return INQ_EXIT_OK;
+}
+
+static int inq_genotype_repeats_impl(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap, const RowsOut &rows = RowsOut()) {
+    const auto t_start = std::chrono::steady_clock::now();
+    AsyncCtx actx;
+    if (args) actx.start(args->device);
+    Prepared P;
+    std::string msg;
+    int rc = prepare(args, P, msg);
+    if (rc != INQ_EXIT_OK) {
+        set_err(errbuf, errcap, msg);
+        return rc;
+    }
+    return genotype_prepared(args, actx, P, out_fd, errbuf, errcap, rows, t_start);
 }
 
 // ---- combine, src/combine.rs ----
@@ -1085,25 +1170,8 @@ int inq_genotype_repeats_rows(const inq_call_args_t *args, const uint32_t *targe
 // The targets in file order (contig of the BAM header, start, end, position in the list) and `world` + 1 cut points into
 // that order, so that every part needs about the same number of compressed BAM bytes: cost of a target = bytes between its
 // scan start in the .bai's linear index and the next target's, capped so that one far-away locus does not own a contig.
-static int inq_host_partition_impl(const inq_call_args_t *args, uint64_t world, uint32_t *order, uint64_t order_cap, uint64_t *cuts,
-                                   uint64_t *n_targets, char *errbuf, size_t errcap) {
-    if (!world || !cuts || !n_targets) {
-        set_err(errbuf, errcap, "null argument");
-        return INQ_EXIT_ERROR;
-    }
-    Prepared P;
-    std::string msg;
-    int rc = prepare(args, P, msg);
-    if (rc != INQ_EXIT_OK) {
-        set_err(errbuf, errcap, msg);
-        return rc;
-    }
+static int partition_prepared(Prepared &P, uint64_t world, uint32_t *order, uint64_t *cuts) {
     const size_t n = P.targets.size();
-    *n_targets = n;
-    if (n > order_cap || (n && !order)) {
-        set_err(errbuf, errcap, "order[] too small for the target list");
-        return INQ_EXIT_ERROR;
-    }
     std::vector<int> tid(n);
     {
         std::map<std::string, int> memo;
@@ -1147,10 +1215,109 @@ static int inq_host_partition_impl(const inq_call_args_t *args, uint64_t world, 
     cuts[world] = n;
     return INQ_EXIT_OK;
 }
+static int inq_host_partition_impl(const inq_call_args_t *args, uint64_t world, uint32_t *order, uint64_t order_cap, uint64_t *cuts,
+                                   uint64_t *n_targets, char *errbuf, size_t errcap) {
+    if (!world || !cuts || !n_targets) {
+        set_err(errbuf, errcap, "null argument");
+        return INQ_EXIT_ERROR;
+    }
+    Prepared P;
+    std::string msg;
+    int rc = prepare(args, P, msg);
+    if (rc != INQ_EXIT_OK) {
+        set_err(errbuf, errcap, msg);
+        return rc;
+    }
+    const size_t n = P.targets.size();
+    *n_targets = n;
+    if (n > order_cap || (n && !order)) {
+        set_err(errbuf, errcap, "order[] too small for the target list");
+        return INQ_EXIT_ERROR;
+    }
+    return partition_prepared(P, world, order, cuts);
+}
 int inq_host_partition(const inq_call_args_t *args, uint64_t world, uint32_t *order, uint64_t order_cap, uint64_t *cuts, uint64_t *n_targets,
                        char *errbuf, size_t errcap) {
     INQ_GUARD(inq_host_partition_impl(args, world, order, order_cap, cuts, n_targets, errbuf, errcap), errbuf, errcap)
 }
+
+// ---- a prepared run: BAM header + index + targets opened once and used for the split, this process's rows and the output ----
+struct OwnedArgs {
+    inq_call_args_t a;
+    std::string bam, region, region_file, sample_name, reference;
+    explicit OwnedArgs(const inq_call_args_t &src) : a(src) {
+        auto own = [](const char *&p, std::string &keep) {
+            if (p) keep = p, p = keep.c_str();
+        };
+        own(a.bam, bam), own(a.region, region), own(a.region_file, region_file), own(a.sample_name, sample_name), own(a.reference, reference);
+    }
+    OwnedArgs(const OwnedArgs &) = delete;
+};
+
+struct inq_run {
+    std::unique_ptr<OwnedArgs> args;
+    Prepared P;
+};
+
+static int partition_prepared(Prepared &P, uint64_t world, uint32_t *order, uint64_t *cuts);
+
+static int inq_run_open_impl(const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap) {
+    if (!out || !args) return INQ_EXIT_ERROR;
+    *out = nullptr;
+    std::unique_ptr<inq_run> R(new inq_run());
+    R->args.reset(new OwnedArgs(*args));
+    std::string msg;
+    int rc = prepare(&R->args->a, R->P, msg);
+    if (rc != INQ_EXIT_OK) {
+        set_err(errbuf, errcap, msg);
+        return rc;
+    }
+    *out = R.release();
+    return INQ_EXIT_OK;
+}
+int inq_run_open(const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_run_open_impl(args, out, errbuf, errcap), errbuf, errcap)
+}
+uint64_t inq_run_n_targets(const inq_run_t *r) { return r ? r->P.targets.size() : 0; }
+const char *inq_run_sample(const inq_run_t *r) { return r ? r->P.sample.c_str() : ""; }
+int inq_run_target(const inq_run_t *r, uint64_t i, const char **chrom, uint32_t *start, uint32_t *end) {
+    if (!r || i >= r->P.targets.size()) return -1;
+    if (chrom) *chrom = r->P.targets[i].chrom.c_str();
+    if (start) *start = r->P.targets[i].start;
+    if (end) *end = r->P.targets[i].end;
+    return 0;
+}
+int inq_run_partition(inq_run_t *r, uint64_t world, uint32_t *order, uint64_t *cuts, char *errbuf, size_t errcap) {
+    if (!r || !world || !cuts || (!order && !r->P.targets.empty())) {
+        set_err(errbuf, errcap, "null argument");
+        return INQ_EXIT_ERROR;
+    }
+    INQ_GUARD(partition_prepared(r->P, world, order, cuts), errbuf, errcap)
+}
+static int inq_run_rows_impl(inq_run_t *r, const uint32_t *target_index, uint64_t n_index, double *phase1, double *phase2, char *errbuf,
+                             size_t errcap) {
+    if (!r || (n_index && (!target_index || !phase1 || !phase2))) {
+        set_err(errbuf, errcap, "null argument");
+        return INQ_EXIT_ERROR;
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+    AsyncCtx actx;
+    actx.start(r->args->a.device);
+    RowsOut ro;
+    ro.idx = target_index, ro.n = n_index, ro.p1 = phase1, ro.p2 = phase2, ro.active = true;
+    return genotype_prepared(&r->args->a, actx, r->P, -1, errbuf, errcap, ro, t_start);
+}
+int inq_run_rows(inq_run_t *r, const uint32_t *target_index, uint64_t n_index, double *phase1, double *phase2, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_run_rows_impl(r, target_index, n_index, phase1, phase2, errbuf, errcap), errbuf, errcap)
+}
+int inq_run_write_inq(inq_run_t *r, const double *phase1, const double *phase2, uint64_t n_rows, int out_fd, char *errbuf, size_t errcap) {
+    if (!r || n_rows != r->P.targets.size() || (n_rows && (!phase1 || !phase2))) {
+        set_err(errbuf, errcap, "row count does not match the target list");
+        return INQ_EXIT_ERROR;
+    }
+    INQ_GUARD(write_rows(r->args->a.threads, r->P.targets, r->P.sample, phase1, phase2, out_fd, errbuf, errcap), errbuf, errcap)
+}
+void inq_run_close(inq_run_t *r) { delete r; }
 
 // ---- spans: the host half of the device front end, on its own (no GPU involved) ----
 static int inq_spans_open_impl(const inq_call_args_t *args, uint64_t max_comp_bytes, inq_spans_t **out, char *errbuf, size_t errcap) {

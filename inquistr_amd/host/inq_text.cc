@@ -60,6 +60,50 @@ void append_row(std::string &out, const std::string &chrom, uint32_t start, uint
     append_f64(out, p2);
 }
 
+// the same text through a bare pointer (the output stage formats 10^5 .. 10^6 rows): dst must hold row_capacity(chrom) bytes
+static inline char *put_u64(char *p, uint64_t v) {
+    char buf[24];
+    int n = 0;
+    do {
+        buf[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = buf[--n];
+    return p;
+}
+static inline char *put_f64(char *p, double v) {
+    if (std::isnan(v)) {
+        *p++ = 'N', *p++ = 'a', *p++ = 'N';
+        return p;
+    }
+    const double a = std::fabs(v);
+    if (a < 9007199254740992.0) {
+        const uint64_t twice = (uint64_t)(a * 2.0);
+        if ((double)twice == a * 2.0) {
+            if (std::signbit(v)) *p++ = '-';
+            p = put_u64(p, twice >> 1);
+            if (twice & 1u) *p++ = '.', *p++ = '5';
+            return p;
+        }
+    }
+    std::string s;
+    append_f64(s, v);  // the rare rest (not produced by the path): up to 1 + 309 digits + ".5"
+    for (char c : s) *p++ = c;
+    return p;
+}
+char *write_row(char *p, const std::string &chrom, uint32_t start, uint32_t end, double p1, double p2) {
+    for (char c : chrom) *p++ = c;
+    *p++ = '\t';
+    p = put_u64(p, start);
+    *p++ = '\t';
+    p = put_u64(p, end);
+    *p++ = '\t';
+    p = put_f64(p, p1);
+    *p++ = '\t';
+    p = put_f64(p, p2);
+    return p;
+}
+
 std::string format_row(const std::string &chrom, uint32_t start, uint32_t end, double p1, double p2) {
     std::string s;
     append_row(s, chrom, start, end, p1, p2);

@@ -118,3 +118,70 @@ def test_failure_on_one_rank_ends_every_rank_with_its_status(tmp_path):
     os.makedirs(status_dir)
     mp.spawn(_failing_worker, args=(4, _free_port(), bam, bed, status_dir), nprocs=4, join=True)
     assert [open(os.path.join(status_dir, f"rank{r}")).read() for r in range(4)] == ["101"] * 4
+
+
+def _fmt(v):
+    import math
+
+    return "NaN" if math.isnan(v) else (str(int(v)) if float(v).is_integer() else repr(float(v)))
+
+
+def _big_worker(rank, world, port, bam, bed, out_path, stats_path):
+    import json
+
+    import numpy as np
+    import torch.distributed as dist
+
+    from inquistr_amd import call_dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def compute(batch):  # a function of the locus alone, so the expected text does not depend on the split
+        return batch.locus_start.astype(np.float64) / 2.0, -batch.locus_end.astype(np.float64)
+
+    stats = {}
+    with open(out_path if rank == 0 else os.devnull, "w") as f:
+        call_dist.genotype_repeats_distributed(bam, None, bed, 5, 3, 8, False, "S", out=f, rank=rank, world=world, compute=compute,
+                                               stats=stats)
+    if rank == 0:
+        json.dump(stats, open(stats_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_config4_row_count_through_eight_ranks(tmp_path):
+    """BASELINE config #4's row count (500 000 loci, 8 ranks): split, per-rank sweeps, gather and the output stage.  The output
+    stage is ONE call into libinquistr_host.so (inq_run_write_inq: the code inq_genotype_repeats ends with, src/call.rs:137-157)
+    and must stay far below the per-row Python it replaced (round 2: ~10^7 ctypes round trips)."""
+    import json
+
+    from tools import bamio
+
+    n_contigs, per = 50, 10_000
+    names = [f"chr{c + 1}" for c in range(n_contigs)]
+    bam = str(tmp_path / "sparse.bam")
+    w = bamio.BamWriter(bam, [(nm, 20_000 * per + 100_000) for nm in names])
+    for c in range(n_contigs):  # one spanning read per locus: every locus reaches a batch
+        for k in range(per):
+            w.add("r", 0, c, 10_000 + 20_000 * k - 50, 60, [("M", 200)], [("HP", "C", 1)])
+    w.close()
+    bed = str(tmp_path / "loci.bed")
+    with open(bed, "w") as f:  # BED order differs from the -t >= 2 output order (chr10 before chr2 in the file)
+        for c in sorted(range(n_contigs), key=lambda c: names[c]):
+            f.write("".join(f"{names[c]}\t{10_000 + 20_000 * k}\t{10_040 + 20_000 * k}\n" for k in range(per)))
+    out, st = str(tmp_path / "big.inq"), str(tmp_path / "stats.json")
+    mp.spawn(_big_worker, args=(8, _free_port(), bam, bed, out, st), nprocs=8, join=True)
+    lines = open(out).read().split("\n")
+    assert lines[0] == "chromosome\tbegin\tend\tS_H1\tS_H2" and lines[-1] == "" and len(lines) == n_contigs * per + 2
+    k = 1
+    for c in range(n_contigs):  # human order: chr1, chr2, ..., chr50
+        for j in (0, 1, per // 2, per - 1):
+            s, e = 10_000 + 20_000 * j, 10_040 + 20_000 * j
+            assert lines[k + j] == f"{names[c]}\t{s}\t{e}\t{_fmt(s / 2.0)}\t{_fmt(-float(e))}"
+        k += per
+    stats = json.load(open(st))
+    print("output stage:", stats)
+    assert stats["rows"] == n_contigs * per and stats["output_s"] < 0.1, stats

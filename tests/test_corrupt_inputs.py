@@ -57,3 +57,42 @@ def test_damaged_files_never_crash(tmp_path, what):
     open(target, "wb").write(good)
     assert _drain(bam, bed) == "ok"
     assert outcomes - {"ok"}, "none of the damaged files was noticed"
+
+
+@pytest.mark.parametrize("what", ["bai", "csi"])
+@pytest.mark.parametrize("count", [0x7FFFFFFF, 200_000_000, 100_000_000])
+@pytest.mark.parametrize("field", ["n_ref", "n_bin", "n_chunk"])
+@pytest.mark.timeout(60)
+def test_counts_the_file_cannot_hold_are_refused_at_once(tmp_path, what, count, field):
+    """One 4-byte count of a valid index set to 10^8 .. 2^31 - 1 (n_ref = 2 * 10^8 built one BaiRef per claimed
+    contig for 192 s and tens of GB before noticing; 2^31 - 1 ended in bad_alloc = exit 1).  htslib fails at once; the
+    reference then panics in IndexedReader::from_path (src/call.rs:242-243): status 101, within the test's time limit."""
+    import gzip
+    import struct
+    import time
+
+    bam, bed, loci, recs = _make_case(tmp_path, 52, n_loci=5)
+    if what == "csi":
+        bam = _reindex(tmp_path, bam, recs, 14, 5, "counts.sorted.bam")
+        raw = bytearray(gzip.open(bam + ".csi", "rb").read())
+        l_aux = struct.unpack_from("<I", raw, 12)[0]
+        at_ref = 16 + l_aux
+        at_bin = at_ref + 4
+        at_chunk = at_bin + 4 + 12  # first bin: bin u32, loffset u64, n_chunk u32
+    else:
+        raw = bytearray(open(bam + ".bai", "rb").read())
+        at_ref, at_bin = 4, 8
+        at_chunk = at_bin + 4 + 4  # first bin: bin u32, n_chunk u32
+    at = {"n_ref": at_ref, "n_bin": at_bin, "n_chunk": at_chunk}[field]
+    struct.pack_into("<I", raw, at, count)
+    if what == "csi":
+        from tools import bamio
+
+        open(bam + ".csi", "wb").write(bamio.bgzf_block(bytes(raw)) + bamio.EOF_BLOCK)
+    else:
+        open(bam + ".bai", "wb").write(bytes(raw))
+    t0 = time.perf_counter()
+    with pytest.raises(call.CallError) as e:
+        call.FrontEnd(bam, region_file=bed)
+    assert e.value.status == 101, e.value
+    assert time.perf_counter() - t0 < 5.0

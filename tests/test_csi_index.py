@@ -46,13 +46,15 @@ def test_host_sweep_through_a_csi_index(tmp_path, orc, min_shift, depth, unphase
     assert gen.same_f64(got1, want1) and gen.same_f64(got2, want2)
 
 
-def test_span_planner_through_a_csi_index(tmp_path, orc, monkeypatch):
-    """The device front end's host half (spans from the index, no GPU): every record a locus needs lies inside its span."""
+@pytest.mark.parametrize("min_shift,depth", [(14, 5), (12, 6), (16, 4), (10, 7)])
+def test_span_planner_through_a_csi_index(tmp_path, orc, monkeypatch, min_shift, depth):
+    """The device front end's host half (spans from the index, no GPU): every record a locus needs lies inside its span,
+    whatever the binning (the iterator start of a .csi is not monotone in the position: the planner must cope)."""
     from tests.test_host_spans import emulate_span
 
     monkeypatch.setenv("INQ_SPAN_GAP_BYTES", "0")  # every gap between loci opens a new segment: anchors matter
     bam, bed, loci, recs = _make_case(tmp_path, 22, block=1500)
-    csi_bam = _reindex(tmp_path, bam, recs, 14, 5, "csi2.sorted.bam", block=1500)  # small blocks: many segments
+    csi_bam = _reindex(tmp_path, bam, recs, min_shift, depth, "csi2.sorted.bam", block=1500)  # small blocks: many segments
     sp = call.Spans(csi_bam, region_file=bed, minlen=5, support=3, threads=2, unphased=False, max_comp_bytes=4000)
     got1 = np.full(len(loci), np.nan)
     got2 = np.full(len(loci), np.nan)
@@ -76,3 +78,34 @@ def test_csi_is_preferred_and_a_broken_one_is_an_error(tmp_path):
     with pytest.raises(call.CallError) as e:  # IndexedReader::from_path panics on an unreadable index (src/call.rs:242-243)
         call.FrontEnd(both, region_file=bed)
     assert e.value.status == 101
+
+
+def test_index_lookup_order_is_htslibs(tmp_path):
+    """[3P] htslib hts_idx_load: <path>.csi, <path minus extension>.csi, then <path>.bai, <path minus extension>.bai.  With
+    x.bam.bai next to x.csi the .csi is the one opened - shown by breaking one of the two at a time."""
+    bam, bed, loci, recs = _make_case(tmp_path, 24, n_loci=5)  # <bam> + <bam>.bai
+    csi_bam = _reindex(tmp_path, bam, recs, 14, 5, "order.bam")
+    stem = csi_bam[: -len(".bam")]
+    shutil.copy(bam + ".bai", csi_bam + ".bai")
+    # order.bam.csi present and broken, order.bam.bai good: the .csi is taken -> error
+    good_csi = open(csi_bam + ".csi", "rb").read()
+    open(csi_bam + ".csi", "wb").write(b"not an index")
+    with pytest.raises(call.CallError):
+        call.FrontEnd(csi_bam, region_file=bed)
+    # order.csi (extension dropped) broken next to a good order.bam.bai: still the .csi
+    os.remove(csi_bam + ".csi")
+    open(stem + ".csi", "wb").write(b"not an index")
+    with pytest.raises(call.CallError):
+        call.FrontEnd(csi_bam, region_file=bed)
+    # a good order.csi wins over a broken order.bam.bai
+    open(stem + ".csi", "wb").write(good_csi)
+    open(csi_bam + ".bai", "wb").write(b"BAI\1 broken")
+    call.FrontEnd(csi_bam, region_file=bed).close()
+    # no .csi anywhere: order.bam.bai before order.bai, and the first that EXISTS is the index - a broken one is an error
+    # even with a good one further down the list
+    os.remove(stem + ".csi")
+    shutil.copy(bam + ".bai", stem + ".bai")
+    with pytest.raises(call.CallError):
+        call.FrontEnd(csi_bam, region_file=bed)
+    os.remove(csi_bam + ".bai")
+    call.FrontEnd(csi_bam, region_file=bed).close()  # order.bai alone
