@@ -25,17 +25,29 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def host_threads() -> int:
-    """Host cores this process may really use: cgroup CPU quota if one is set, else the affinity
-    mask, capped at 16 (the per-GPU CPU share of the measurement box)."""
+def host_cores_available() -> int:
+    """Host cores this process may really use, uncapped: the affinity mask, cut by the cgroup CPU quota if one is set."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            n = min(n, max(1, int(q) // int(p)))
-    except Exception:
-        pass
-    return max(1, min(n, int(os.environ.get("INQ_CPU_THREADS", "16"))))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                q, p = txt
+            else:
+                q, p = txt[0], open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0]
+            if q not in ("max", "-1"):
+                n = min(n, max(1, int(q) // int(p)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def host_threads() -> int:
+    """The product's own -t and the CPU legs' default thread count: the available cores capped at 16 (the per-GPU CPU
+    share of the measurement box; INQ_CPU_THREADS overrides).  CPU mode B is ALSO timed on host_cores_available() threads
+    when that is more (the reference's -t >= 2 runs on rayon's global pool = all cores, src/call.rs:104-118)."""
+    return max(1, min(host_cores_available(), int(os.environ.get("INQ_CPU_THREADS", "16"))))
 
 
 def cpu_baseline(wl, sample_loci: int, budget_s: float = 10.0):
@@ -70,13 +82,18 @@ def cpu_baseline(wl, sample_loci: int, budget_s: float = 10.0):
     }
 
 
-def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_loci: int = 10_000, c_loci: int = 2_000):
+def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_loci: int = 10_000, c_loci: int = 2_000, seq: bool = False,
+             level: int = 1):
     """End to end (BAM + BED -> .inq) next to the reference-shaped CPU programs, small enough for the default run.
     Product CLI with the device front end: median of `reps` whole-process wall times (HIP start-up included; the CLI
     leaves through _Exit once the rows are written).  CPU side = oracle/ref_shaped_call, the reference's control flow
     (B = one reader per worker, A = BAM + .bai re-opened per locus as src/call.rs:217 does with -t >= 2,
     C = serial) around the CPU restatement - not the Rust binary.  A and C run on the first a_loci / c_loci targets of the
-    same BAM (A costs ~0.5 ms per locus and core), B on all of them; outputs are compared byte for byte."""
+    same BAM (A costs ~0.5 ms per locus and core), B on all of them - at `threads` threads and, when the box offers more, at
+    host_cores_available() threads too; outputs are compared byte for byte.
+    seq: records shaped like a real long-read BAM (SEQ + QUAL of the query length, NM, ML / MM tags, HP last: ~18 KB per
+    record instead of ~0.85 KB; tools/synth_bam_writer.cc inq_synth_write_bam_seq), the shape north_star's ">= 10x the
+    reference CPU inquiSTR call on a synthetic long-read BAM" is about."""
     import statistics
     import subprocess
     import tempfile
@@ -89,7 +106,8 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
     prefix = os.path.join(tmp, f"{workload}_{loci}")
     try:
         t0 = time.perf_counter()
-        make_synth_bam.write_native(workload, loci, prefix, threads=threads, device=device)
+        info = {}
+        make_synth_bam.write_native(workload, loci, prefix, threads=host_cores_available(), device=device, seq=seq, level=level, info=info)
         gen_s = time.perf_counter() - t0
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
         cli = os.path.join(ROOT, "inquistr_amd", "lib", "inquistr")
@@ -117,9 +135,14 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         out_dev = dev[0][1]
         t_host, out_host = run(cmd, dict(os.environ, INQ_FRONTEND="host"))
         rows = out_dev.splitlines(keepends=True)
+        bam_bytes = os.path.getsize(prefix + ".bam")
         res = {
             "level": "L2: BAM + BED -> .inq, whole process, start to exit", "workload": workload, "loci": loci, "threads": threads,
-            "bam_mb": os.path.getsize(prefix + ".bam") / 1e6, "bam_gen_s": gen_s, "records": "SEQ '*' (CIGAR-only records), HP:C",
+            "host_cores_available": host_cores_available(),
+            "bam_mb": bam_bytes / 1e6, "bam_gen_s": gen_s, "zlib_level": level,
+            "records": ("SEQ + QUAL of the query length, NM:i, ML:B,C + MM:Z, HP:C last (long-read record shape, ~18 KB per record; "
+                        "bases ACGT, Phred a clamped random walk)" if seq else "SEQ '*' (CIGAR-only records), HP:C"),
+            **({"inflated_mb": info["inflated_bytes"] / 1e6, "bgzf_blocks": info["n_blocks"]} if info else {}),
             "gpu_cli_device_front": {"seconds_median": t_dev, "seconds_all": [t for t, _ in dev], "runs": reps,
                                      "loci_per_s": loci / t_dev, "identical_across_runs": all(o == out_dev for _, o in dev)},
             "gpu_cli_host_front": {"seconds": t_host, "loci_per_s": loci / t_host, "inq_identical": out_host == out_dev},
@@ -127,6 +150,13 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         args_tail = [str(int(wl.unphased)), str(wl.minlen), str(wl.support), "S"]
         tb, out_b = run([ref, prefix + ".bam", prefix + ".bed", "B", str(threads)] + args_tail)
         res["cpu_B"] = {"seconds": tb, "loci": loci, "loci_per_s": loci / tb, "cores": threads, "inq_identical": out_b == out_dev}
+        all_cores = host_cores_available()
+        if all_cores > threads:  # the reference's -t >= 2 uses every core (src/call.rs:104-118): mode B there as well
+            tb2, out_b2 = run([ref, prefix + ".bam", prefix + ".bed", "B", str(all_cores)] + args_tail)
+            res["cpu_B_all_cores"] = {"seconds": tb2, "loci": loci, "loci_per_s": loci / tb2, "cores": all_cores, "inq_identical": out_b2 == out_dev}
+        # the device front end's own stage times for this file (HIP events / host clocks inside the CLI, one extra run)
+        r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="2"))
+        res["device_front_stages"] = stage_summary(r.stderr.decode(), bam_bytes)
         na, nc = min(a_loci, loci), min(c_loci, loci)
         ta, out_a = run([ref, prefix + ".bam", sub_bed(na), "A", str(threads)] + args_tail)
         res["cpu_A"] = {"seconds": ta, "loci": na, "loci_per_s": na / ta, "cores": threads,
@@ -138,6 +168,9 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                                     and res["gpu_cli_host_front"]["inq_identical"])
         for m in "BAC":
             res[f"speedup_vs_{m}"] = res["gpu_cli_device_front"]["loci_per_s"] / res[f"cpu_{m}"]["loci_per_s"]
+        if "cpu_B_all_cores" in res:
+            res["inq_identical"] = bool(res["inq_identical"] and res["cpu_B_all_cores"]["inq_identical"])
+            res["speedup_vs_B_all_cores"] = res["gpu_cli_device_front"]["loci_per_s"] / res["cpu_B_all_cores"]["loci_per_s"]
         res["note"] = ("speed-ups are ratios of loci/s; cpu_* = oracle/ref_shaped_call (CPU restatement in the reference's control "
                        "flow with its own BGZF / BAM / BAI reader, oracle/minibam.h: no code shared with the product), not the Rust binary; A and C timed on a prefix of the targets")
         return res
@@ -145,6 +178,33 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         import shutil
 
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def stage_summary(stderr_text: str, bam_bytes: int):
+    """Sums the per-span stage lines the CLI prints with INQ_TIMING=2 ("[inq span] ... | upload U inflate I scan S join J call C
+    ms | wall W ms": HIP-event times of the device stages) into per-file figures, the inflate's rate among them."""
+    import re
+
+    tot = {"spans": 0, "comp_mb": 0.0, "inflated_mb": 0.0, "upload_ms": 0.0, "inflate_ms": 0.0, "scan_ms": 0.0, "join_ms": 0.0, "call_ms": 0.0,
+           "wall_ms": 0.0, "loci_per_span": []}
+    pat = re.compile(r"\[inq span\] loci (\d+) comp ([\d.]+) MB -> ([\d.]+) MB.*upload ([\d.]+) inflate ([\d.]+) scan ([\d.]+) join ([\d.]+) call ([\d.]+) ms \| wall ([\d.]+) ms")
+    for ln in stderr_text.splitlines():
+        m = pat.search(ln)
+        if not m:
+            continue
+        v = [float(x) for x in m.groups()]
+        tot["spans"] += 1
+        tot["loci_per_span"].append(int(v[0]))
+        for k, x in zip(("comp_mb", "inflated_mb", "upload_ms", "inflate_ms", "scan_ms", "join_ms", "call_ms", "wall_ms"), v[1:]):
+            tot[k] += x
+    if tot["spans"] and tot["inflate_ms"] > 0:
+        tot["inflate_in_GBps"] = tot["comp_mb"] / tot["inflate_ms"]   # MB / ms = GB / s
+        tot["inflate_out_GBps"] = tot["inflated_mb"] / tot["inflate_ms"]
+        tot["note"] = "inflate_ms includes the CRC check of every block; rates = compressed bytes in / inflated bytes out per second of it"
+    for ln in stderr_text.splitlines():
+        if ln.startswith("[inq timing] device front end:"):
+            tot["cli_timing"] = ln[len("[inq timing] "):]
+    return tot
 
 
 def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str = "", cpu_modes: str = "CBA", seq: bool = False):
@@ -230,6 +290,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-l2", action="store_true", help="skip the end-to-end block of the default N=1 line")
     ap.add_argument("--l2-default-loci", type=int, default=100_000, help="loci of the BAM the default line's l2 block is timed on")
+    ap.add_argument("--l2-seq-default-loci", type=int, default=6_000,
+                    help="loci of the SEQ / QUAL-bearing BAM the default line's l2_seq block is timed on (30 reads x ~18 KB each per locus)")
+    ap.add_argument("--no-l2-seq", action="store_true", help="skip the l2_seq block of the default N=1 line")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: the workload's n_loci are split over the ranks (config #4: --workload shard500k --scaling strong)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_latest.json"))
@@ -317,33 +380,16 @@ def main():
 
     results = [[result_for(outs[b][g]) for g in range(G)] for b in range(2)]
     pending = []
-    # gather-to-rank-0 is what the path needs; if this torch/RCCL build lacks NCCL gather (the error is a
-    # backend capability error, raised on every rank before any traffic) fall back to all_gather
-    use_all_gather = False
-    all_bufs = None
-    if world > 1 and args.backend == "nccl":
-        try:
-            probe = torch.zeros(4, device=dev)
-            dist.gather(probe, [torch.zeros(4, device=dev) for _ in range(world)] if rank == 0 else None, dst=0)
-        except Exception as e:  # noqa: BLE001
-            use_all_gather = True
-            if rank == 0:
-                print(f"[bench] NCCL gather unavailable ({type(e).__name__}); using all_gather_into_tensor", file=sys.stderr)
-        flag = torch.tensor([1 if use_all_gather else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # one decision for all ranks, reported in config.sharding
-        use_all_gather = bool(flag.item())
-        if use_all_gather:
-            all_bufs = [torch.empty(world, G, 2, per_gpu, dtype=torch.float64, device=dev) for _ in range(2)]
-
+    # ONE stated collective: gather to rank 0 (ProcessGroupNCCL::gather = grouped ncclSend / ncclRecv over xGMI; 16 B per locus).
+    # No fallback: if this RCCL build cannot do it the run fails loudly (tests/test_gpu_parity.py::test_nccl_gather_is_available
+    # exercises the call on the GPU box).
     def send_group(b):
         ev = events[b]
         ev.record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev)
             glist = list(gathered[b].unbind(0)) if rank == 0 else None
-            if args.backend == "nccl" and use_all_gather:
-                pending.append(dist.all_gather_into_tensor(all_bufs[b], outs[b], async_op=True))
-            elif args.backend == "nccl":
+            if args.backend == "nccl":
                 pending.append(dist.gather(outs[b], glist, dst=0, async_op=True))
             else:  # rehearsal: stage through pinned host memory, gather on gloo
                 stage[b].copy_(outs[b], non_blocking=True)
@@ -414,7 +460,7 @@ def main():
     if rank == 0 and world > 1:
         # the last gathered group must hold rank 0's own rows in slot 0
         lb, lg = state["last"]
-        src = all_bufs[lb] if use_all_gather else gathered[lb]
+        src = gathered[lb]
         own = outs[lb][lg].to(src.device)
         g0 = src[0][lg]
         if not bool(((own == g0) | (own.isnan() & g0.isnan())).all()):
@@ -424,6 +470,8 @@ def main():
         alg_bytes = shard.algorithmic_bytes()
         avg_kernel_s = kern_ms / 1e3 / max(1, launches)
         achieved = alg_bytes / avg_kernel_s / 1e9
+        # PMC counters cannot be read from inside this process: `traffic` is the figure STORED by the last rocprofv3 --pmc run of
+        # this very command and workload (profiles/pmc_latest.json, written by tools/summarize_profile.py), labelled as such
         traffic = None
         pmc_note = None
         if os.path.exists(args.pmc_summary):
@@ -431,7 +479,7 @@ def main():
                 pmc = json.load(open(args.pmc_summary))
                 if pmc.get("workload") == wl.name and pmc.get("loci_per_gpu") == per_gpu:
                     traffic = pmc.get("hbm_bytes_per_launch")
-                    pmc_note = pmc.get("source")
+                    pmc_note = {"kind": "stored", "source": pmc.get("source"), "commit": pmc.get("commit"), "profile": pmc.get("profile")}
             except Exception:
                 traffic = None
         line = {
@@ -456,7 +504,7 @@ def main():
                 "cigar_ops_per_gpu": shard.n_ops_total,
                 "minlen": wl.minlen,
                 "support": wl.support,
-                "sharding": f"loci x {world} ranks ({args.backend} {'all_gather_into_tensor' if use_all_gather else 'gather'}), "
+                "sharding": f"loci x {world} ranks ({args.backend} gather), "
                 f"rows of {G} steps per collective to rank 0 (16 B/locus), overlapped" if world > 1 else "single GPU",
                 "total_loci": total_loci,
             },
@@ -495,6 +543,11 @@ def main():
                 line["l2"] = l2_block(wl.name, min(args.l2_default_loci, wl.n_loci), host_threads(), dev)
             except Exception as e:  # noqa: BLE001  the L0 line above stays valid without it
                 line["l2"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_l2 and not args.no_l2_seq:
+            try:  # the same comparison on records shaped like a real long-read BAM (SEQ, QUAL, ML / MM, HP last)
+                line["l2_seq"] = l2_block(wl.name, min(args.l2_seq_default_loci, wl.n_loci), host_threads(), dev, a_loci=2_000, c_loci=300, seq=True)
+            except Exception as e:  # noqa: BLE001
+                line["l2_seq"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

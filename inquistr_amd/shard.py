@@ -47,6 +47,24 @@ def shard_batch(batch: Batch, rank: int, world: int) -> Tuple[Batch, List[Tuple[
     return batch.slice_loci(lo, hi), ranges
 
 
+def pack_rows(p1, p2, width: int):
+    """This rank's rows as the rectangular [2, width] f64 buffer the gather moves (NaN-padded)."""
+    import torch
+
+    mine = torch.full((2, max(width, 1)), float("nan"), dtype=torch.float64, device=p1.device)
+    n = p1.shape[0]
+    mine[0, :n] = p1
+    mine[1, :n] = p2
+    return mine
+
+
+def unpack_rows(bufs, ranges: Sequence[Tuple[int, int]]):
+    """Rank 0: the gathered buffers (one per rank, in rank order) back into locus order."""
+    out1 = np.concatenate([bufs[r][0, : ranges[r][1] - ranges[r][0]].cpu().numpy() for r in range(len(ranges))])
+    out2 = np.concatenate([bufs[r][1, : ranges[r][1] - ranges[r][0]].cpu().numpy() for r in range(len(ranges))])
+    return out1, out2
+
+
 def gather_rows(p1, p2, ranges: Sequence[Tuple[int, int]], rank: int, world: int, group=None):
     """Gathers the shards' (phase1, phase2) rows to rank 0 in locus order.  p1/p2 are this rank's
     rows as torch tensors (CPU for gloo, device for nccl).  Returns (phase1, phase2) numpy arrays on
@@ -56,18 +74,12 @@ def gather_rows(p1, p2, ranges: Sequence[Tuple[int, int]], rank: int, world: int
 
     if world == 1:
         return p1.cpu().numpy(), p2.cpu().numpy()
-    width = max(hi - lo for lo, hi in ranges)
-    mine = torch.full((2, max(width, 1)), float("nan"), dtype=torch.float64, device=p1.device)
-    n = p1.shape[0]
-    mine[0, :n] = p1
-    mine[1, :n] = p2
+    mine = pack_rows(p1, p2, max(hi - lo for lo, hi in ranges))
     bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, bufs, dst=0, group=group)
     if rank != 0:
         return None
-    out1 = np.concatenate([bufs[r][0, : ranges[r][1] - ranges[r][0]].cpu().numpy() for r in range(world)])
-    out2 = np.concatenate([bufs[r][1, : ranges[r][1] - ranges[r][0]].cpu().numpy() for r in range(world)])
-    return out1, out2
+    return unpack_rows(bufs, ranges)
 
 
 def run_sharded(batch: Batch, compute: Callable[[Batch], Tuple[np.ndarray, np.ndarray]], rank: int, world: int,

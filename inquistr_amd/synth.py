@@ -338,3 +338,12 @@ class DeviceBatch:
 
     def algorithmic_bytes(self) -> int:
         return 4 * self.n_ops_total + 20 * self.n_pairs + 32 * self.n_loci
+
+    def ops_per_locus(self):
+        """CIGAR ops each locus makes the device walk (sum over its pairs): the cost inquistr_amd.shard balances by."""
+        import torch
+
+        ops = self.reads[:, 1].to(torch.int64)[self.pair_read.to(torch.int64)]
+        csum = torch.zeros(self.n_pairs + 1, dtype=torch.int64, device=ops.device)
+        torch.cumsum(ops, 0, out=csum[1:])
+        return csum[self.locus_pair_off[1:]] - csum[self.locus_pair_off[:-1]]

@@ -429,6 +429,78 @@ def test_full_size_other_configs(ctx, orc, name, lo, hi, samples):
     assert np.all(np.mod(p1[~np.isnan(p1)] * 2, 1) == 0)
 
 
+@pytest.mark.timeout(900)
+def test_config4_all_500k_loci_as_eight_shards(ctx, orc):
+    """BASELINE config #4 completely, on the one GPU there is: all 500 000 loci of shard500k (a) in one unsharded launch and
+    (b) as the eight contiguous shards inquistr_amd.shard cuts them into (balanced by CIGAR-op count), every shard generated and
+    called on its own as rank r would, the rows packed, and unpacked in rank order by the very code gather_rows() runs on either
+    side of its collective (the collective itself: tests/test_shard_gloo.py, tests/test_call_dist_gloo.py at world 8).
+    (b) must equal (a) bit for bit, and both the oracle on a sample from EVERY shard."""
+    import torch
+
+    from inquistr_amd import shard
+
+    wl = synth.WORKLOADS["shard500k"]
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    full = synth.DeviceBatch(wl, dev, 0, wl.n_loci)
+    ctx.call_batch_device(full.c_batch, full.c_result, st)
+    rc, ties = ctx.status()
+    assert rc == 0
+    p1, p2 = full.phase1.cpu().numpy().copy(), full.phase2.cpu().numpy().copy()
+    ops_per_locus = full.ops_per_locus().cpu().numpy()
+    assert ops_per_locus.shape == (wl.n_loci,) and int(ops_per_locus.sum()) == full.n_ops_total
+    del full
+    world = 8
+    ranges = shard.balanced_ranges(ops_per_locus, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == wl.n_loci
+    loads = [int(ops_per_locus[lo:hi].sum()) for lo, hi in ranges]
+    assert max(loads) - min(loads) <= 2 * int(ops_per_locus.max())  # the cut is balanced by work, not by count
+    width = max(hi - lo for lo, hi in ranges)
+    bufs = []
+    for r, (lo, hi) in enumerate(ranges):
+        d = synth.DeviceBatch(wl, dev, lo, hi)
+        ctx.call_batch_device(d.c_batch, d.c_result, st)
+        assert ctx.status()[0] == 0, r
+        bufs.append(shard.pack_rows(d.phase1, d.phase2, width))
+        # the oracle on a sample of THIS shard: its first and last 150 loci
+        for a, b in ((lo, lo + 150), (hi - 150, hi)):
+            sub = synth.generate_numpy(wl, a, b)
+            oc, want = orc.call_batch(sub, threads=8)
+            assert oc == 0
+            assert gen.same_f64(d.phase1[a - lo : b - lo].cpu().numpy(), want.phase1), (r, a, b)
+            assert gen.same_f64(d.phase2[a - lo : b - lo].cpu().numpy(), want.phase2), (r, a, b)
+        del d
+    g1, g2 = shard.unpack_rows(bufs, ranges)
+    assert g1.shape == (wl.n_loci,) and gen.same_f64(g1, p1) and gen.same_f64(g2, p2)
+    assert not np.isnan(g1).any() and np.all(g1 <= g2)
+
+
+def test_nccl_gather_is_available():
+    """bench.py --gpus N moves the rows with ONE stated collective, dist.gather on the nccl (= RCCL) backend, and has no
+    fallback: this exercises that very call on the GPU box (one rank: the backend's gather entry, buffers on the device)."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        src = torch.arange(8, dtype=torch.float64, device=dev).reshape(2, 4)
+        out = [torch.empty_like(src)]
+        work = dist.gather(src, out, dst=0, async_op=True)
+        work.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], src)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_superset_of_candidates_changes_nothing(ctx):
     """The ABI lets the host offer more reads than fetch() would yield (one sweep over the file instead
     of an index query per locus): the device applies htslib's overlap rule.  Offering every locus the

@@ -165,13 +165,21 @@ def native_lib():
         L.inq_synth_write_bam.restype = C.c_int
         L.inq_synth_write_bam.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        L.inq_synth_write_bam_seq.restype = C.c_int
+        L.inq_synth_write_bam_seq.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         _NATIVE = L
     return _NATIVE
 
 
-def write_native(workload: str, n_loci: int, prefix: str, level: int = 1, threads: int = 0, device=None):
+def write_native(workload: str, n_loci: int, prefix: str, level: int = 1, threads: int = 0, device=None, seq: bool = False,
+                 qual_mode: int = 1, seed: int = 12345, slab_blocks: int = 0, info: dict = None):
     """Same files as write() (byte for byte, tests/test_synth_bam_native.py), records assembled, deflated and indexed by
-    native threads.  device: a torch device to generate the workload on (bit-identical to the numpy generator)."""
+    native threads.  device: a torch device to generate the workload on (bit-identical to the numpy generator).
+    seq: records shaped like a real long-read BAM (SEQ + QUAL of the query length, NM, ML / MM, HP last; see
+    inq_synth_write_bam_seq: same CIGARs, positions and HP as the CIGAR-only file, NOT the Python writer's random bytes),
+    written slab by slab so that tens of GB need a few hundred MB of memory.  info: receives inflated_bytes / n_blocks."""
     import ctypes as C
 
     wl = synth.WORKLOADS[workload]
@@ -196,19 +204,30 @@ def write_native(workload: str, n_loci: int, prefix: str, level: int = 1, thread
     cigar = np.ascontiguousarray(cigar)
     reads = np.ascontiguousarray(reads)
     err = C.create_string_buffer(512)
-    rc = native_lib().inq_synth_write_bam((prefix + ".bam").encode(), n, reads.ctypes.data, cigar.ctypes.data, order.ctypes.data,
-                                          tid.ctypes.data, name_id.ctypes.data, n_contigs, CONTIG_LEN, level,
-                                          threads or len(os.sched_getaffinity(0)), err, len(err))
+    if seq:
+        infl, nblk = C.c_uint64(0), C.c_uint64(0)
+        rc = native_lib().inq_synth_write_bam_seq((prefix + ".bam").encode(), n, reads.ctypes.data, cigar.ctypes.data, order.ctypes.data,
+                                                  tid.ctypes.data, name_id.ctypes.data, n_contigs, CONTIG_LEN, level,
+                                                  threads or len(os.sched_getaffinity(0)), qual_mode, seed, slab_blocks,
+                                                  C.byref(infl), C.byref(nblk), err, len(err))
+        if info is not None:
+            info.update(inflated_bytes=int(infl.value), n_blocks=int(nblk.value))
+    else:
+        rc = native_lib().inq_synth_write_bam((prefix + ".bam").encode(), n, reads.ctypes.data, cigar.ctypes.data, order.ctypes.data,
+                                              tid.ctypes.data, name_id.ctypes.data, n_contigs, CONTIG_LEN, level,
+                                              threads or len(os.sched_getaffinity(0)), err, len(err))
     if rc != 0:
         raise RuntimeError("synth_bam_writer: " + err.value.decode())
     return n
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 4 and sys.argv[4] == "native":  # native writer, workload generated on the GPU when there is one
+    if len(sys.argv) > 4 and sys.argv[4] in ("native", "native-seq", "native-seq-random"):  # native writer, workload generated on the GPU when there is one
         import torch
 
-        n = write_native(sys.argv[1], int(sys.argv[2]), sys.argv[3], device=torch.device("cuda:0") if torch.cuda.is_available() else None)
+        n = write_native(sys.argv[1], int(sys.argv[2]), sys.argv[3], device=torch.device("cuda:0") if torch.cuda.is_available() else None,
+                         seq=sys.argv[4] != "native", qual_mode=0 if sys.argv[4].endswith("random") else 1,
+                         level=int(sys.argv[5]) if len(sys.argv) > 5 else 1)
     else:
         n = write(sys.argv[1], int(sys.argv[2]), sys.argv[3], seq=len(sys.argv) > 4 and sys.argv[4] == "seq")
     print(f"wrote {sys.argv[3]}.bam/.bai/.bed: {n} reads, {os.path.getsize(sys.argv[3] + '.bam') / 1e6:.1f} MB")

@@ -64,6 +64,8 @@ json.dump(
         "fetch_size_kib_raw": fetch_kib,
         "write_size_kib_raw": write_kib,
         "avg_kernel_ns_profiled": avg_ns,
+        "profile": f"profiles/{tag}_pmc.csv",
+        "commit": (os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip() or None),
         "source": f"profiles/{tag}_pmc.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
         "2 x FETCH_SIZE (gfx950 wide-stream correction) + WRITE_SIZE, KiB -> bytes, mean over dispatches",
     },
