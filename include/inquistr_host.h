@@ -141,6 +141,14 @@ int inq_host_parse_region(const char *reg, const char *chrom_name, uint64_t chro
  * >= pos, from the .bai linear index; 0 if the contig has nothing there.  Lets a multi-process run split the
  * targets by the amount of BAM each rank has to read rather than by locus count. */
 uint64_t inq_host_bai_file_offset(const char *bai_path, int32_t tid, int64_t pos);
+/* The same as a full virtual offset (compressed offset << 16 | offset in the inflated block); bai_path may name a .csi.
+ * This is where both front ends start reading for a window that begins at pos (the reference: bam.fetch(), src/call.rs:288,338). */
+uint64_t inq_host_bai_scan_start(const char *bai_path, int32_t tid, int64_t pos);
+/* The device front end's plan on its own (host/span_planner.cc): for the targets of args, every segment [vo_begin, vo_limit) of
+ * every span (seg_span[k] = number of the span segment k belongs to; *n_segs = how many there are, also when seg_cap is smaller)
+ * and, per target, the span it is called in (0xffffffff: no record can overlap it).  Reads the BAM's header and index only. */
+int inq_host_plan_spans(const inq_call_args_t *args, uint64_t max_comp_bytes, uint64_t *seg_vo_begin, uint64_t *seg_vo_limit, uint32_t *seg_span,
+                        uint64_t seg_cap, uint64_t *n_segs, uint32_t *target_span, uint64_t target_cap, char *errbuf, size_t errcap);
 int inq_host_bam_tid(const char *bam_path, const char *contig);
 int inq_host_bai_stats(const char *bai_path, uint32_t *n_ref, int32_t tid, uint64_t *n_mapped, uint64_t *n_unmapped,
                        uint64_t *n_bins, uint64_t *n_intv);

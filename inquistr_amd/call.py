@@ -48,6 +48,8 @@ HOST_ABI_SYMBOLS = (
     "inq_host_parse_region",
     "inq_host_bai_stats",
     "inq_host_bai_file_offset",
+    "inq_host_bai_scan_start",
+    "inq_host_plan_spans",
     "inq_host_bam_tid",
     "inq_spans_open",
     "inq_spans_n_targets",
@@ -157,6 +159,11 @@ def load():
         L.inq_host_parse_region.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.inq_host_bai_file_offset.restype = C.c_uint64
         L.inq_host_bai_file_offset.argtypes = [C.c_char_p, C.c_int32, C.c_int64]
+        L.inq_host_bai_scan_start.restype = C.c_uint64
+        L.inq_host_bai_scan_start.argtypes = [C.c_char_p, C.c_int32, C.c_int64]
+        L.inq_host_plan_spans.restype = C.c_int
+        L.inq_host_plan_spans.argtypes = [C.POINTER(CallArgsC), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                          C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
         L.inq_host_bam_tid.restype = C.c_int
         L.inq_host_bam_tid.argtypes = [C.c_char_p, C.c_char_p]
         L.inq_host_bai_stats.restype = C.c_int
@@ -310,6 +317,27 @@ class Run:
             self.close()
         except Exception:
             pass
+
+
+def plan_spans(bamp, region=None, region_file=None, max_comp_bytes: int = 0, n_targets_cap: int = 1 << 20):
+    """inq_host_plan_spans: (segments as an array of (vo_begin, vo_limit, span), per-target span number) - the plan alone."""
+    L = load()
+    a = _args(bamp, region, region_file, 5, 3, 1, False, None, None)
+    err = C.create_string_buffer(2048)
+    n = C.c_uint64(0)
+    cap = 1024
+    tspan = np.zeros(n_targets_cap, dtype=np.uint32)
+    while True:
+        vb, vl, sp = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint32)
+        rc = L.inq_host_plan_spans(C.byref(a), max_comp_bytes, vb.ctypes.data, vl.ctypes.data, sp.ctypes.data, cap, C.byref(n), tspan.ctypes.data,
+                                   len(tspan), err, len(err))
+        if rc != 0:
+            raise CallError(rc, err.value.decode(errors="replace"))
+        if n.value > cap:
+            cap = int(n.value)
+            continue
+        k = int(n.value)
+        return [(int(vb[i]), int(vl[i]), int(sp[i])) for i in range(k)], tspan
 
 
 def combine(calls, out=None) -> None:

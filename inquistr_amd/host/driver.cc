@@ -1424,6 +1424,66 @@ uint64_t inq_host_bai_file_offset(const char *bai_path, int32_t tid, int64_t pos
     }
 }
 
+uint64_t inq_host_bai_scan_start(const char *bai_path, int32_t tid, int64_t pos) {
+    try {
+        BaiIndex idx;
+        std::string e;
+        const std::string p = bai_path;
+        const bool is_csi = p.size() > 4 && p.compare(p.size() - 4, 4, ".csi") == 0;
+        if (!(is_csi ? idx.load_csi(p, &e) : idx.load(p, &e))) return 0;
+        return idx.scan_start(tid, pos);
+    } catch (...) {
+        return 0;
+    }
+}
+
+// The plan alone: every segment of every span the device front end would read for these targets, nothing read from the BAM
+// beyond its header and index.
+static int inq_host_plan_spans_impl(const inq_call_args_t *args, uint64_t max_comp_bytes, uint64_t *seg_vo_begin, uint64_t *seg_vo_limit,
+                                    uint32_t *seg_span, uint64_t seg_cap, uint64_t *n_segs, uint32_t *target_span, uint64_t target_cap,
+                                    char *errbuf, size_t errcap) {
+    if (!n_segs) return INQ_EXIT_ERROR;
+    Prepared P;
+    std::string msg;
+    int rc = prepare(args, P, msg);
+    if (rc != INQ_EXIT_OK) {
+        set_err(errbuf, errcap, msg);
+        return rc;
+    }
+    if (target_span) {
+        if (target_cap < P.targets.size()) {
+            set_err(errbuf, errcap, "target_span[] too small for the target list");
+            return INQ_EXIT_ERROR;
+        }
+        for (size_t i = 0; i < P.targets.size(); ++i) target_span[i] = 0xffffffffu;
+    }
+    SpanPlanner planner(*P.bam, P.targets, max_comp_bytes ? max_comp_bytes : span_bytes_from_env());
+    SpanPlan plan;
+    uint64_t n = 0;
+    uint32_t span = 0;
+    while (planner.next(plan)) {
+        for (const Segment &g : plan.segs) {
+            if (n < seg_cap && seg_vo_begin && seg_vo_limit) {
+                seg_vo_begin[n] = g.vo_begin;
+                seg_vo_limit[n] = g.vo_limit;
+                if (seg_span) seg_span[n] = span;
+            }
+            ++n;
+        }
+        if (target_span)
+            for (uint32_t i : plan.locus_index) target_span[i] = span;
+        ++span;
+    }
+    *n_segs = n;
+    return INQ_EXIT_OK;
+}
+int inq_host_plan_spans(const inq_call_args_t *args, uint64_t max_comp_bytes, uint64_t *seg_vo_begin, uint64_t *seg_vo_limit, uint32_t *seg_span,
+                        uint64_t seg_cap, uint64_t *n_segs, uint32_t *target_span, uint64_t target_cap, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_host_plan_spans_impl(args, max_comp_bytes, seg_vo_begin, seg_vo_limit, seg_span, seg_cap, n_segs, target_span, target_cap, errbuf,
+                                       errcap),
+              errbuf, errcap)
+}
+
 int inq_host_bam_tid(const char *bam_path, const char *contig) {
     try {
         BamFile b(1);

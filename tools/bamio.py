@@ -231,11 +231,16 @@ class BamWriter:
                 out += struct.pack("<II", 37450, 2) + struct.pack("<QQQQ", meta[t][0], meta[t][1], meta[t][2], meta[t][3])
             nint = (max(lin[t]) + 1) if lin[t] else 0
             out += struct.pack("<I", nint)
-            last = 0
-            for w in range(nint):
+            # [3P] htslib (hts_idx_finish) fills a window no record overlaps with the offset of the NEXT filled window, from
+            # the right: the reference's own small-test.bam.bai carries the first record's offset in all 9 326 windows in
+            # front of it (tests/test_reference_bai_pin.py).  (samtools 0.1's fill_missing copied the previous one.)
+            filled = [0] * nint
+            nxt = 0
+            for w in range(nint - 1, -1, -1):
                 if w in lin[t]:
-                    last = lin[t][w]
-                out += struct.pack("<Q", last)  # htslib fills empty windows with the previous offset
+                    nxt = lin[t][w]
+                filled[w] = nxt
+            out += struct.pack("<%dQ" % nint, *filled)
         out += struct.pack("<Q", n_no_coor)
         with open(self.path + ".bai", "wb") as f:
             f.write(out)

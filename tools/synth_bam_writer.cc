@@ -115,11 +115,12 @@ std::string write_bai(const char *bam_path, uint64_t n_reads, const uint64_t *or
             put<uint64_t>(bai, m0), put<uint64_t>(bai, m1), put<uint64_t>(bai, n_mapped), put<uint64_t>(bai, 0);
         }
         put<uint32_t>(bai, (uint32_t)lin.size());
-        uint64_t last = 0;
-        for (size_t w = 0; w < lin.size(); ++w) {
-            if (lin_set[w]) last = lin[w];
-            put<uint64_t>(bai, last);  // htslib fills empty windows with the previous offset
+        uint64_t nxt = 0;  // [3P] htslib fills empty windows with the NEXT filled window's offset, from the right (bamio._write_bai)
+        for (size_t w = lin.size(); w-- > 0;) {
+            if (lin_set[w]) nxt = lin[w];
+            lin[w] = nxt;
         }
+        for (size_t w = 0; w < lin.size(); ++w) put<uint64_t>(bai, lin[w]);
     }
     if (k != n_reads) return fail("order[] is not grouped by ascending tid");
     put<uint64_t>(bai, 0);  // n_no_coor
