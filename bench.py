@@ -187,7 +187,7 @@ def stage_summary(stderr_text: str, bam_bytes: int):
 
     tot = {"spans": 0, "comp_mb": 0.0, "inflated_mb": 0.0, "upload_ms": 0.0, "inflate_ms": 0.0, "scan_ms": 0.0, "join_ms": 0.0, "call_ms": 0.0,
            "wall_ms": 0.0, "loci_per_span": []}
-    pat = re.compile(r"\[inq span\] loci (\d+) comp ([\d.]+) MB -> ([\d.]+) MB.*upload ([\d.]+) inflate ([\d.]+) scan ([\d.]+) join ([\d.]+) call ([\d.]+) ms \| wall ([\d.]+) ms")
+    pat = re.compile(r"\[inq span\].*?loci (\d+) comp ([\d.]+) MB -> ([\d.]+) MB.*upload ([\d.]+) inflate ([\d.]+) scan ([\d.]+) join ([\d.]+) call ([\d.]+) ms \| wall ([\d.]+) ms")
     for ln in stderr_text.splitlines():
         m = pat.search(ln)
         if not m:

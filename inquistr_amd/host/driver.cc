@@ -40,6 +40,10 @@ static constexpr uint64_t kDeviceFrontMinBytesPerThread = 1ull << 20;
 
 namespace {
 
+// INQ_TIMING=2 stamps every stage with milliseconds since the library was loaded (about the start of the process)
+const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+double stamp_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0).count(); }
+
 void set_err(char *buf, size_t cap, const std::string &m) {
     if (buf && cap) std::snprintf(buf, cap, "%s", m.c_str());
 }
@@ -397,8 +401,8 @@ private:
             if (verbose_) {
                 const auto t3 = std::chrono::steady_clock::now();
                 auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-                std::fprintf(stderr, "[inq loader] plan %.2f ms, buffer %.2f ms (%s), read+tables %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
-                             ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), nbytes / 1e6,
+                std::fprintf(stderr, "[inq loader] @%.1f slot %d: plan %.2f ms, buffer %.2f ms (%s), read+tables %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
+                             stamp_ms(), it->slot, ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), nbytes / 1e6,
                              it->plan.segs.size(), it->data.anchors.size());
             }
             have = more.get();
@@ -441,7 +445,7 @@ private:
             fill_span(*it, &sp);
             it->staged = stage_(sp, it->slot);
             if (verbose_)
-                std::fprintf(stderr, "[inq loader] upload %.2f ms for %.1f MB%s\n",
+                std::fprintf(stderr, "[inq loader] @%.1f slot %d: upload %.2f ms for %.1f MB%s\n", stamp_ms(), it->slot,
                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), it->data.comp_bytes / 1e6,
                              it->staged ? "" : " (not staged)");
             std::lock_guard<std::mutex> g(mu_);
@@ -578,7 +582,12 @@ struct AsyncCtx {
     std::thread th;
     bool leak = false;  // set after a clean run when the process is about to exit (INQ_FAST_EXIT)
     void start(int device) {
-        th = std::thread([this, device] { hrc = inq_ctx_create(device, &ctx); });
+        th = std::thread([this, device] {
+            const double a = stamp_ms();
+            hrc = inq_ctx_create(device, &ctx);
+            const char *e = std::getenv("INQ_TIMING");
+            if (e && e[0] == '2') std::fprintf(stderr, "[inq ctx] @%.1f device context ready (inq_ctx_create %.1f ms)\n", stamp_ms(), stamp_ms() - a);
+        });
     }
     std::mutex mu;
     bool wait() {  // any thread
@@ -688,9 +697,9 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
             *t_dev += secs(tb, clk::now());
             if (timing == 2)
                 std::fprintf(stderr,
-                             "[inq span] loci %llu comp %.1f MB -> %.1f MB, %llu records, %llu pairs | upload %.2f inflate %.2f scan %.2f "
+                             "[inq span] @%.1f waited %.2f ms | loci %llu comp %.1f MB -> %.1f MB, %llu records, %llu pairs | upload %.2f inflate %.2f scan %.2f "
                              "join %.2f call %.2f ms | wall %.2f ms\n",
-                             (unsigned long long)sp.n_loci, sp.comp_bytes / 1e6, stt.inflated_bytes / 1e6,
+                             stamp_ms(), secs(ta, tb) * 1e3, (unsigned long long)sp.n_loci, sp.comp_bytes / 1e6, stt.inflated_bytes / 1e6,
                              (unsigned long long)stt.n_records, (unsigned long long)stt.n_pairs, stt.ms_upload, stt.ms_inflate,
                              stt.ms_scan, stt.ms_join, stt.ms_call, secs(tb, clk::now()) * 1e3);
             if (rc2 != INQ_OK) {
