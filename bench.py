@@ -186,17 +186,22 @@ def stage_summary(stderr_text: str, bam_bytes: int):
     import re
 
     tot = {"spans": 0, "comp_mb": 0.0, "inflated_mb": 0.0, "upload_ms": 0.0, "inflate_ms": 0.0, "scan_ms": 0.0, "join_ms": 0.0, "call_ms": 0.0,
-           "wall_ms": 0.0, "loci_per_span": []}
-    pat = re.compile(r"\[inq span\].*?loci (\d+) comp ([\d.]+) MB -> ([\d.]+) MB.*upload ([\d.]+) inflate ([\d.]+) scan ([\d.]+) join ([\d.]+) call ([\d.]+) ms \| wall ([\d.]+) ms")
+           "wall_ms": 0.0, "loci_per_span": [], "loci_per_call_launch": []}
+    pat = re.compile(r"\[inq span\].*?loci (\d+) comp ([\d.]+) MB -> ([\d.]+) MB.*upload ([\d.]+) inflate ([\d.]+) scan ([\d.]+) join ([\d.]+) ms \| wall ([\d.]+) ms")
+    pat_call = re.compile(r"\[inq call\].*? (\d+) loci, ([\d.]+) MB of CIGARs: locus kernels ([\d.]+) ms \| wall ([\d.]+) ms")
     for ln in stderr_text.splitlines():
         m = pat.search(ln)
-        if not m:
-            continue
-        v = [float(x) for x in m.groups()]
-        tot["spans"] += 1
-        tot["loci_per_span"].append(int(v[0]))
-        for k, x in zip(("comp_mb", "inflated_mb", "upload_ms", "inflate_ms", "scan_ms", "join_ms", "call_ms", "wall_ms"), v[1:]):
-            tot[k] += x
+        if m:
+            v = [float(x) for x in m.groups()]
+            tot["spans"] += 1
+            tot["loci_per_span"].append(int(v[0]))
+            for k, x in zip(("comp_mb", "inflated_mb", "upload_ms", "inflate_ms", "scan_ms", "join_ms", "wall_ms"), v[1:]):
+                tot[k] += x
+        m = pat_call.search(ln)
+        if m:  # the locus kernels run over the batches of several spans at once (inq_call_flush)
+            tot["loci_per_call_launch"].append(int(m.group(1)))
+            tot["call_ms"] += float(m.group(3))
+            tot["wall_ms"] += float(m.group(4))
     if tot["spans"] and tot["inflate_ms"] > 0:
         tot["inflate_in_GBps"] = tot["comp_mb"] / tot["inflate_ms"]   # MB / ms = GB / s
         tot["inflate_out_GBps"] = tot["inflated_mb"] / tot["inflate_ms"]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define INQ_ABI_VERSION 3
+#define INQ_ABI_VERSION 4
 
 /* ---- error codes (0 = ok, negative = failure; never throws / aborts) ---- */
 enum {
@@ -257,7 +257,7 @@ typedef struct inq_span_stats {
 int inq_call_span(inq_ctx_t *ctx, const inq_span_t *span, inq_result_t *result, inq_span_stats_t *stats);
 
 /* Two-step form for files of many spans: inq_span_stage uploads the compressed bytes, the block table and the
- * anchors of a span into one of three device-side slots on the library's copy stream and returns when they are
+ * anchors of a span into one of six device-side slots (0 .. 5) on the library's copy stream and returns when they are
  * there; inq_call_span_staged then runs the span from that slot without uploading.  inq_span_stage may be
  * called from another host thread while an inq_call_span / inq_call_span_staged of an EARLIER span is in
  * progress on the same ctx (different slot): the upload of span k+1 then overlaps the inflate of span k.
@@ -267,7 +267,19 @@ int inq_span_stage(inq_ctx_t *ctx, const inq_span_t *span, int slot);
 int inq_call_span_staged(inq_ctx_t *ctx, const inq_span_t *span, int slot, inq_result_t *result,
                          inq_span_stats_t *stats);
 
-/* Test / debug: copies the batch the last inq_call_span built on the device into caller-allocated HOST
+/* Deferred form, for spans that hold too few loci to fill the chip on their own (a span of 256 MB of SEQ / QUAL-bearing records
+ * holds under a thousand loci; the locus kernels want tens of thousands per launch): inq_call_span_deferred does everything
+ * inq_call_span / inq_call_span_staged (slot >= 0) does up to the overlap join and APPENDS the span's batch - CIGARs, read
+ * descriptors, pairs, loci - to a batch that stays on the device; inq_call_flush runs the locus kernels once over everything
+ * appended since the last flush and returns the rows in the order the loci were appended (n_loci must be their number;
+ * ms_call, if not NULL, receives the HIP-event time of the launch sequence).  minlen / support / unphased must be the same in
+ * every span of one batch.  The reference's counterpart is still the per-locus loop of src/call.rs:115-136,150-157: which loci
+ * share a launch is not observable in the rows. */
+int inq_call_span_deferred(inq_ctx_t *ctx, const inq_span_t *span, int slot /* -1: not staged */, inq_span_stats_t *stats);
+int inq_call_flush(inq_ctx_t *ctx, inq_result_t *result, uint64_t n_loci, double *ms_call);
+uint64_t inq_call_deferred_loci(const inq_ctx_t *ctx); /* loci appended since the last flush */
+
+/* Test / debug: copies the batch the last inq_call_span (or inq_call_flush) built on the device into caller-allocated HOST
  * arrays sized from that call's stats: cigar[n_cigar_words], reads[n_reads], pair_read[n_pairs],
  * locus_pair_off[n_loci + 1].  Any pointer may be NULL. */
 int inq_span_fetch_batch(inq_ctx_t *ctx, uint32_t *cigar, inq_read_t *reads, uint32_t *pair_read, uint64_t *locus_pair_off);

@@ -78,6 +78,20 @@ int inq_run_rows(inq_run_t *run, const uint32_t *target_index, uint64_t n_index,
 int inq_run_write_inq(inq_run_t *run, const double *phase1, const double *phase2, uint64_t n_rows, int out_fd, char *errbuf, size_t errcap);
 void inq_run_close(inq_run_t *run);
 
+/* ---- a session: many BAMs on one device context ----
+ * A cohort is called sample by sample with the same targets and pasted together by `combine` (src/combine.rs).  One process per
+ * sample pays the HIP runtime's start-up (0.1 - 0.3 s: all of a 1 GB file's time) every time; a session pays it once.
+ * inq_session_call is inq_genotype_repeats on the session's context.  inq_session_call_many runs args[0 .. n) in order, file
+ * k + 1 being opened, planned, read and uploaded while file k is called; out_fds[k] receives file k's .inq - byte for byte what
+ * its own `inquistr call` prints -, statuses[k] (may be NULL) its exit status; a failing file does not stop the others.
+ * Returns 0, or the status of the first failing file (its message in errbuf).  The per-BAM surface of the reference is
+ * unchanged: this is the loop a caller would otherwise write around `inquiSTR call`. */
+typedef struct inq_session inq_session_t;
+int inq_session_open(int32_t device, inq_session_t **out); /* returns at once; the runtime starts on a thread of its own */
+int inq_session_call(inq_session_t *s, const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap);
+int inq_session_call_many(inq_session_t *s, const inq_call_args_t *args, size_t n, const int *out_fds, int *statuses, char *errbuf, size_t errcap);
+void inq_session_close(inq_session_t *s);
+
 /* ---- BAM -> batch front end (no GPU involved) ---- */
 typedef struct inq_frontend inq_frontend_t;
 int inq_frontend_open(const inq_call_args_t *args, inq_frontend_t **out, char *errbuf, size_t errcap);

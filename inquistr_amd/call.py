@@ -32,6 +32,10 @@ HOST_ABI_SYMBOLS = (
     "inq_run_rows",
     "inq_run_write_inq",
     "inq_run_close",
+    "inq_session_open",
+    "inq_session_call",
+    "inq_session_call_many",
+    "inq_session_close",
     "inq_combine",
     "inq_frontend_open",
     "inq_frontend_n_targets",
@@ -129,6 +133,14 @@ def load():
         L.inq_run_write_inq.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_char_p, C.c_size_t]
         L.inq_run_close.restype = None
         L.inq_run_close.argtypes = [vp]
+        L.inq_session_open.restype = C.c_int
+        L.inq_session_open.argtypes = [C.c_int32, C.POINTER(vp)]
+        L.inq_session_call.restype = C.c_int
+        L.inq_session_call.argtypes = [vp, C.POINTER(CallArgsC), C.c_int, C.c_char_p, C.c_size_t]
+        L.inq_session_call_many.restype = C.c_int
+        L.inq_session_call_many.argtypes = [vp, C.POINTER(CallArgsC), C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        L.inq_session_close.restype = None
+        L.inq_session_close.argtypes = [vp]
         L.inq_combine.restype = C.c_int
         L.inq_combine.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
         L.inq_frontend_open.restype = C.c_int
@@ -311,6 +323,64 @@ class Run:
         if self._h and self._h.value:
             self._L.inq_run_close(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Session:
+    """inq_session_*: many BAMs on one device context (the HIP runtime starts once; file k + 1 is staged while file k is called)."""
+
+    def __init__(self, device: int = 0):
+        self._L = load()
+        self._h = C.c_void_p()
+        rc = self._L.inq_session_open(device, C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise CallError(rc, "cannot open a session")
+
+    def call(self, bamp, region=None, region_file=None, minlen=5, support=3, threads=1, unphased=False, sample_name=None, out=None,
+             frontend: Optional[str] = None) -> None:
+        a = _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, None, 0, frontend)
+        err = C.create_string_buffer(2048)
+        out = sys.stdout if out is None else out
+        out.flush()
+        rc = self._L.inq_session_call(self._h, C.byref(a), out.fileno(), err, len(err))
+        if rc != 0:
+            raise CallError(rc, err.value.decode(errors="replace"))
+
+    def call_many(self, bams, outs, region=None, region_file=None, minlen=5, support=3, threads=1, unphased=False, sample_names=None,
+                  frontend: Optional[str] = None):
+        """Runs the files in order; returns the list of exit statuses (no exception for failing files)."""
+        n = len(bams)
+        arr = (CallArgsC * n)()
+        keep = []
+        for k, b in enumerate(bams):
+            a = _args(b, region, region_file, minlen, support, threads, unphased, sample_names[k] if sample_names else None, None, 0, frontend)
+            keep.append(a)
+            arr[k] = a
+        for o in outs:
+            o.flush()
+        fds = (C.c_int * n)(*[o.fileno() for o in outs])
+        st = (C.c_int * n)()
+        err = C.create_string_buffer(2048)
+        self._L.inq_session_call_many(self._h, arr, n, fds, st, err, len(err))
+        self.last_message = err.value.decode(errors="replace")
+        return list(st)
+
+    def close(self):
+        if self._h and self._h.value:
+            self._L.inq_session_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
     def __del__(self):
         try:

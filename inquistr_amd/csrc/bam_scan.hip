@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void cigar_gather_kernel(ScanArgs a, uint64_t 
         if ((rd.bits & INQ_READ_UNMAPPED) || rlen == 0) rlen = 1;  // [3P] bam_endpos
         const int64_t endpos = (int64_t)rd.pos + rlen;
         a.endkey[i] = (a.key[i] & ~0xffffffffll) + (endpos + 1);
-        rd.cigar_off4 = (uint32_t)unit0;
+        rd.cigar_off4 = (uint32_t)unit0 + a.unit_base;
         // is_accidental_2d is only reached from a soft-clip op (src/call.rs:394)
         if (clip && ri.sa_off) {
             const uint32_t v = is_accidental_2d(a.u, ri, (rd.bits & INQ_READ_REVERSE) != 0, (int64_t)rd.pos, endpos);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void join_kernel(ScanArgs a, uint64_t n_valid)
         for (uint64_t r = lo; r < last; ++r) {
             if (a.endkey[r] > kstart) {  // [3P] htslib: pos < end && endpos > beg
                 if (FILL) {
-                    a.pair_read[w++] = (uint32_t)r;
+                    a.pair_read[w++] = (uint32_t)r + a.read_base;
                     const uint32_t e = a.info[r].err;
                     if (e) raise(a.st, e, r);
                 }
@@ -518,6 +518,14 @@ void launch_join_count(const ScanArgs &a, uint64_t n_valid, hipStream_t s) {
 void launch_join_fill(const ScanArgs &a, uint64_t n_valid, hipStream_t s) {
     if (!a.n_loci) return;
     hipLaunchKernelGGL((join_kernel<true>), dim3((uint32_t)((a.n_loci + 255) / 256)), dim3(256), 0, s, a, n_valid);
+}
+__global__ __launch_bounds__(256) void offset_copy_kernel(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = src[i] + base;
+}
+void launch_offset_copy(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(offset_copy_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dst, src, n, base);
 }
 
 void launch_scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *tmp, hipStream_t s) {

@@ -76,6 +76,8 @@ struct ScanArgs {
     uint64_t *locus_pair_off;  // [n_loci + 1]
     uint32_t *pair_read;
     FrontStatus *st;
+    // a span appended to the batch of earlier spans (inq_call_span_deferred): the CIGAR units / reads that are already there
+    uint32_t unit_base, read_base;
 };
 
 void launch_chain_count(const ScanArgs &a, hipStream_t s);
@@ -84,6 +86,8 @@ void launch_record_parse(const ScanArgs &a, hipStream_t s);
 void launch_cigar_gather(const ScanArgs &a, uint64_t n_valid, hipStream_t s);
 void launch_join_count(const ScanArgs &a, uint64_t n_valid, hipStream_t s);
 void launch_join_fill(const ScanArgs &a, uint64_t n_valid, hipStream_t s);
+// dst[i] = src[i] + base, i < n (the CSR offsets of an appended span)
+void launch_offset_copy(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t s);
 
 // exclusive prefix sums (out[n] = total) and the running maximum; `tmp` holds ceil(n / 4096) + 1 u64
 void launch_scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *tmp, hipStream_t s);

@@ -40,11 +40,19 @@ struct SpanState {
         const void *host_comp = nullptr;
         uint64_t comp_bytes = 0, n_blocks = 0, n_anchors = 0;
         bool valid = false;
-    } stage[3];
+    } stage[6];  // two sets of three: the spans of the NEXT file of a cohort are staged while this file's are still being called
     hipStream_t copy_stream = nullptr;
     hipStream_t warm_stream = nullptr;  // the one warm-up copy below: the copy stream may be busy uploading the next span
     // the batch the last inq_call_span built
     uint64_t n_reads = 0, n_cigar_words = 0, n_pairs = 0, n_loci = 0;
+    bool last_from_acc = false;
+    // inq_call_span_deferred: the batches of several spans appended to one (CIGAR units, reads, pairs, loci so far), called
+    // together by inq_call_flush - a span of SEQ-bearing records holds a few hundred loci, far too few to fill the chip
+    struct Acc {
+        DevBuf cigar, reads, pair_read, off, lstart, lend;
+        uint64_t n_units = 0, n_reads = 0, n_pairs = 0, n_loci = 0, n_spans = 0;
+        uint32_t minlen = 0, support = 0, unphased = 0, max_reads = 0;
+    } acc;
 };
 
 double span_last_inflate_ms(SpanState *S) {
@@ -62,6 +70,8 @@ void span_state_destroy(SpanState *S) {
     for (auto &g : S->stage)
         for (DevBuf *b : {&g.comp, &g.blocks, &g.anchors, &g.anchor_stop})
             if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : {&S->acc.cigar, &S->acc.reads, &S->acc.pair_read, &S->acc.off, &S->acc.lstart, &S->acc.lend})
+        if (b->p) (void)hipFree(b->p);
     if (S->copy_stream) (void)hipStreamDestroy(S->copy_stream);
     if (S->warm_stream) (void)hipStreamDestroy(S->warm_stream);
     if (S->d_st) (void)hipFree(S->d_st);
@@ -94,6 +104,30 @@ namespace {
 int span_state(inq_ctx *c, SpanState **out) {
     if (!c->span) return INQ_ERR_HIP;  // created with the ctx (span_state_init): two host threads may come here at once
     *out = c->span;
+    return INQ_OK;
+}
+
+// grows b to `bytes`, keeping its first `used` bytes (the accumulated batch)
+int ensure_keep(inq_ctx *c, DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
+    if (bytes <= b.cap && b.p) return INQ_OK;
+    void *np = nullptr;
+    const size_t want = bytes + bytes / 2 + (1u << 20);
+    HIP_TRY(c, hipMalloc(&np, want));
+    if (b.p) {
+        if (used) {
+            hipError_t e = hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                (void)hipFree(np);
+                c->last_err = std::string("growing the deferred batch: ") + hipGetErrorString(e);
+                return INQ_ERR_HIP;
+            }
+        }
+        HIP_TRY(c, hipDeviceSynchronize());
+        (void)hipFree(b.p);
+    }
+    b.p = np;
+    b.cap = want;
     return INQ_OK;
 }
 
@@ -176,11 +210,12 @@ int bgzf_inflate_impl(inq_ctx *c, const uint8_t *comp, uint64_t comp_bytes, cons
     return S->h->st.inflate ? INQ_ERR_INFLATE : INQ_OK;
 }
 
-int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_stats_t *stats, int slot) {
-    if (!c || !sp || !r || slot > 2) return INQ_ERR_ARG;
+// defer: the span's batch is appended to S->acc instead of being called (r may be null then)
+int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_stats_t *stats, int slot, bool defer = false) {
+    if (!c || !sp || (!r && !defer) || slot > 5) return INQ_ERR_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (sp->reserved || sp->unphased > 1) return INQ_ERR_ARG;
-    if (sp->n_loci && (!sp->locus_tid || !sp->locus_start || !sp->locus_end || !r->phase1 || !r->phase2)) return INQ_ERR_ARG;
+    if (sp->n_loci && (!sp->locus_tid || !sp->locus_start || !sp->locus_end || (!defer && (!r->phase1 || !r->phase2)))) return INQ_ERR_ARG;
     if (sp->n_anchors && (!sp->anchors || !sp->anchor_stop)) return INQ_ERR_ARG;
     if (sp->n_loci >= 0xfffffff0ull) return INQ_ERR_ARG;
     if (sp->support == 0) return INQ_ERR_SUPPORT_ZERO;
@@ -197,13 +232,15 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
         if (sp->locus_tid[j] < 0) return INQ_ERR_ARG;
         if (sp->locus_start[j] < 10 || sp->locus_end[j] < sp->locus_start[j]) return INQ_ERR_LOCUS;
     }
-    r->n_tie_loci = 0;
+    if (r) r->n_tie_loci = 0;
     if (sp->n_loci == 0) return INQ_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     SpanState *S;
     if ((rc = span_state(c, &S)) != INQ_OK) return rc;
     hipStream_t s = c->stream;
     const uint64_t nl = sp->n_loci, na = sp->n_anchors;
+    SpanState::Acc &A = S->acc;
+    if (defer && A.n_spans && (A.minlen != sp->minlen || A.support != sp->support || A.unphased != sp->unphased)) return INQ_ERR_ARG;
     const SpanState::Stage *staged = nullptr;
     if (slot >= 0) {  // the span inq_span_stage put there, and nothing else
         const SpanState::Stage &g = S->stage[slot];
@@ -328,10 +365,24 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     }
 
     // ---- stage 3: CIGAR gather, reference spans, overlap join (count)
-    if ((rc = ensure(c, S->cigar, n_units * 16)) != INQ_OK) return rc;
-    a.cigar = (uint32_t *)S->cigar.p;
+    if (defer) {  // behind the CIGARs and reads of the spans already deferred
+        if (A.n_units + n_units >= 0xffffffffull || A.n_reads + n_valid >= 0xfffffff0ull) {
+            if (stats) stats->front_status = FS_TOO_BIG;
+            return INQ_ERR_BAM;
+        }
+        if ((rc = ensure_keep(c, A.cigar, (A.n_units + n_units) * 16, A.n_units * 16, s)) != INQ_OK) return rc;
+        if ((rc = ensure_keep(c, A.reads, (A.n_reads + n_valid) * sizeof(inq_read_t), A.n_reads * sizeof(inq_read_t), s)) != INQ_OK) return rc;
+        a.cigar = (uint32_t *)A.cigar.p + A.n_units * 4;
+        a.unit_base = (uint32_t)A.n_units;
+        a.read_base = (uint32_t)A.n_reads;
+    } else {
+        if ((rc = ensure(c, S->cigar, n_units * 16)) != INQ_OK) return rc;
+        a.cigar = (uint32_t *)S->cigar.p;
+    }
     a.n_cigar_units = n_units;
     launch_cigar_gather(a, n_valid, s);
+    if (defer && n_valid)  // the descriptors, CIGAR offsets already counted from the start of the accumulated buffer
+        HIP_TRY(c, hipMemcpyAsync((inq_read_t *)A.reads.p + A.n_reads, a.reads, n_valid * sizeof(inq_read_t), hipMemcpyDeviceToDevice, s));
     launch_scan_max_i64(a.endkey, a.pmax, n_valid, (uint64_t *)S->tmp.p, s);
     HIP_TRY(c, hipEventRecord(S->ev[3], s));
     launch_join_count(a, n_valid, s);
@@ -346,6 +397,48 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     if (n_pairs >= (1ull << 40)) return INQ_ERR_ARG;
 
     // ---- stage 4: pairs, then the locus kernels on the device-resident batch
+    auto fill_stats = [&]() {
+        if (!stats) return;
+        stats->n_records = n_rec;
+        stats->n_reads = n_valid;
+        stats->n_pairs = n_pairs;
+        stats->n_cigar_words = n_units * 4;
+        stats->inflated_bytes = u_bytes;
+        stats->max_reads = S->h->st.max_reads;
+        auto el = [&](int i, int j) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, S->ev[i], S->ev[j]);
+            return (double)ms;
+        };
+        stats->ms_upload = el(0, 1);
+        stats->ms_inflate = el(1, 2);
+        stats->ms_scan = el(2, 3);
+        stats->ms_join = el(3, 4);
+        stats->ms_call = defer ? 0.0 : el(4, 5);
+    };
+    if (defer) {
+        if (A.n_pairs + n_pairs >= (1ull << 40) || A.n_loci + nl >= 0xfffffff0ull) return INQ_ERR_ARG;
+        if ((rc = ensure_keep(c, A.pair_read, (A.n_pairs + n_pairs) * 4, A.n_pairs * 4, s)) != INQ_OK) return rc;
+        if ((rc = ensure_keep(c, A.off, (A.n_loci + nl + 1) * 8, (A.n_loci + 1) * 8, s)) != INQ_OK) return rc;
+        if ((rc = ensure_keep(c, A.lstart, (A.n_loci + nl) * 4, A.n_loci * 4, s)) != INQ_OK) return rc;
+        if ((rc = ensure_keep(c, A.lend, (A.n_loci + nl) * 4, A.n_loci * 4, s)) != INQ_OK) return rc;
+        a.pair_read = (uint32_t *)A.pair_read.p + A.n_pairs;
+        launch_join_fill(a, n_valid, s);
+        launch_offset_copy((uint64_t *)A.off.p + A.n_loci, a.locus_pair_off, nl + 1, A.n_pairs, s);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync((uint32_t *)A.lstart.p + A.n_loci, a.locus_start, nl * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync((uint32_t *)A.lend.p + A.n_loci, a.locus_end, nl * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipEventRecord(S->ev[4], s));
+        HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));  // the span's slot and the scan buffers are free again when this returns
+        fill_stats();
+        if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
+        if (A.n_spans == 0) A.minlen = sp->minlen, A.support = sp->support, A.unphased = sp->unphased, A.max_reads = 0;
+        A.max_reads = std::max<uint32_t>(A.max_reads, S->h->st.max_reads);
+        A.n_units += n_units, A.n_reads += n_valid, A.n_pairs += n_pairs, A.n_loci += nl, ++A.n_spans;
+        wall("appended to the deferred batch");
+        return INQ_OK;
+    }
     if ((rc = ensure(c, S->pair_read, n_pairs * 4)) != INQ_OK) return rc;
     a.pair_read = (uint32_t *)S->pair_read.p;
     launch_join_fill(a, n_valid, s);
@@ -390,33 +483,90 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     S->n_cigar_words = n_units * 4;
     S->n_pairs = n_pairs;
     S->n_loci = nl;
-    if (stats) {
-        stats->n_records = n_rec;
-        stats->n_reads = n_valid;
-        stats->n_pairs = n_pairs;
-        stats->n_cigar_words = n_units * 4;
-        stats->inflated_bytes = u_bytes;
-        stats->max_reads = S->h->st.max_reads;
-        float ms = 0.f;
-        auto el = [&](int i, int j) {
-            ms = 0.f;
-            (void)hipEventElapsedTime(&ms, S->ev[i], S->ev[j]);
-            return (double)ms;
-        };
-        stats->ms_upload = el(0, 1);
-        stats->ms_inflate = el(1, 2);
-        stats->ms_scan = el(2, 3);
-        stats->ms_join = el(3, 4);
-        stats->ms_call = el(4, 5);
-    }
+    S->last_from_acc = false;
+    fill_stats();
     r->n_tie_loci = S->h->ks.ties;
     if ((rc = front_fail(S->h->st)) != INQ_OK) return rc;
     return status_to_code(S->h->ks.err);
 }
 
+// The locus kernels over everything inq_call_span_deferred appended; rows in the order the loci were appended.
+int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_call) {
+    if (!c || !r) return INQ_ERR_ARG;
+    SpanState *S;
+    int rc;
+    if ((rc = span_state(c, &S)) != INQ_OK) return rc;
+    SpanState::Acc &A = S->acc;
+    r->n_tie_loci = 0;
+    if (ms_call) *ms_call = 0.0;
+    if (n_loci != A.n_loci) return INQ_ERR_ARG;
+    if (A.n_loci == 0) {
+        A = SpanState::Acc{A.cigar, A.reads, A.pair_read, A.off, A.lstart, A.lend};
+        return INQ_OK;
+    }
+    if (!r->phase1 || !r->phase2) return INQ_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t nl = A.n_loci;
+    if ((rc = ensure(c, S->p1, nl * 8)) != INQ_OK) return rc;
+    if ((rc = ensure(c, S->p2, nl * 8)) != INQ_OK) return rc;
+    if (S->h_rows_cap < 2 * nl) {
+        if (S->h_rows) (void)hipHostFree(S->h_rows);
+        S->h_rows = nullptr;
+        S->h_rows_cap = 0;
+        const size_t want = std::max<size_t>(2 * nl + nl / 2 + 1024, 1u << 16);
+        HIP_TRY(c, hipHostMalloc((void **)&S->h_rows, want * sizeof(double), hipHostMallocDefault));
+        S->h_rows_cap = want;
+    }
+    inq_batch_t db;
+    std::memset(&db, 0, sizeof db);
+    db.n_reads = A.n_reads;
+    db.n_cigar_words = A.n_units * 4;
+    db.n_pairs = A.n_pairs;
+    db.n_loci = nl;
+    db.cigar = (const uint32_t *)A.cigar.p;
+    db.reads = (const inq_read_t *)A.reads.p;
+    db.pair_read = (const uint32_t *)A.pair_read.p;
+    db.locus_pair_off = (const uint64_t *)A.off.p;
+    db.locus_start = (const uint32_t *)A.lstart.p;
+    db.locus_end = (const uint32_t *)A.lend.p;
+    db.minlen = A.minlen;
+    db.support = A.support;
+    db.unphased = A.unphased;
+    inq_result_t dr;
+    dr.phase1 = (double *)S->p1.p;
+    dr.phase2 = (double *)S->p2.p;
+    dr.pair_call = nullptr;
+    dr.pair_bits = nullptr;
+    dr.n_tie_loci = 0;
+    c->call_hint = std::max<uint32_t>(A.max_reads, 1u);
+    HIP_TRY(c, hipEventRecord(S->ev[4], s));
+    if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
+    HIP_TRY(c, hipEventRecord(S->ev[5], s));
+    HIP_TRY(c, hipStreamSynchronize(S->warm_stream));
+    HIP_TRY(c, hipMemcpyAsync(S->h_rows, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(S->h_rows + nl, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&S->h->ks, c->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemsetAsync(&c->d_status->err, 0, sizeof(unsigned int), s));
+    HIP_TRY(c, hipMemsetAsync(&c->d_status->ties, 0, sizeof(unsigned long long), s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    std::memcpy(r->phase1, S->h_rows, nl * 8);
+    std::memcpy(r->phase2, S->h_rows + nl, nl * 8);
+    if (ms_call) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, S->ev[4], S->ev[5]);
+        *ms_call = (double)ms;
+    }
+    S->n_reads = A.n_reads, S->n_cigar_words = A.n_units * 4, S->n_pairs = A.n_pairs, S->n_loci = nl;
+    S->last_from_acc = true;  // inq_span_fetch_batch reads the accumulated buffers (their contents stay until the next append)
+    r->n_tie_loci = S->h->ks.ties;
+    A = SpanState::Acc{A.cigar, A.reads, A.pair_read, A.off, A.lstart, A.lend};  // buffers kept, counters back to zero
+    return status_to_code(S->h->ks.err);
+}
+
 // Runs on whatever host thread calls it, on the copy stream; touches only stage[slot] (and ctx->last_err on failure).
 int span_stage_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
-    if (!c || !sp || slot < 0 || slot > 2) return INQ_ERR_ARG;
+    if (!c || !sp || slot < 0 || slot > 5) return INQ_ERR_ARG;
     const uint64_t nb = sp->n_blocks, na = sp->n_anchors;
     const uint64_t u_bytes = nb ? sp->blocks[nb - 1].out_off + sp->blocks[nb - 1].isize : 0;
     int rc = check_blocks(sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, true);
@@ -452,10 +602,11 @@ int fetch_batch_impl(inq_ctx *c, uint32_t *cigar, inq_read_t *reads, uint32_t *p
     SpanState *S = c->span;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (cigar && S->n_cigar_words) HIP_TRY(c, hipMemcpy(cigar, S->cigar.p, S->n_cigar_words * 4, hipMemcpyDeviceToHost));
-    if (reads && S->n_reads) HIP_TRY(c, hipMemcpy(reads, S->reads.p, S->n_reads * sizeof(inq_read_t), hipMemcpyDeviceToHost));
-    if (pair_read && S->n_pairs) HIP_TRY(c, hipMemcpy(pair_read, S->pair_read.p, S->n_pairs * 4, hipMemcpyDeviceToHost));
-    if (locus_pair_off && S->n_loci) HIP_TRY(c, hipMemcpy(locus_pair_off, S->locus_off.p, (S->n_loci + 1) * 8, hipMemcpyDeviceToHost));
+    const bool acc = S->last_from_acc;
+    if (cigar && S->n_cigar_words) HIP_TRY(c, hipMemcpy(cigar, acc ? S->acc.cigar.p : S->cigar.p, S->n_cigar_words * 4, hipMemcpyDeviceToHost));
+    if (reads && S->n_reads) HIP_TRY(c, hipMemcpy(reads, acc ? S->acc.reads.p : S->reads.p, S->n_reads * sizeof(inq_read_t), hipMemcpyDeviceToHost));
+    if (pair_read && S->n_pairs) HIP_TRY(c, hipMemcpy(pair_read, acc ? S->acc.pair_read.p : S->pair_read.p, S->n_pairs * 4, hipMemcpyDeviceToHost));
+    if (locus_pair_off && S->n_loci) HIP_TRY(c, hipMemcpy(locus_pair_off, acc ? S->acc.off.p : S->locus_off.p, (S->n_loci + 1) * 8, hipMemcpyDeviceToHost));
     return INQ_OK;
 }
 
@@ -503,6 +654,28 @@ int inq_call_span(inq_ctx_t *c, const inq_span_t *span, inq_result_t *result, in
         return INQ_ERR_HIP;
     }
 }
+
+int inq_call_span_deferred(inq_ctx_t *c, const inq_span_t *span, int slot, inq_span_stats_t *stats) {
+    try {
+        return call_span_impl(c, span, nullptr, stats, slot < 0 ? -1 : slot, true);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
+int inq_call_flush(inq_ctx_t *c, inq_result_t *result, uint64_t n_loci, double *ms_call) {
+    try {
+        return call_flush_impl(c, result, n_loci, ms_call);
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
+uint64_t inq_call_deferred_loci(const inq_ctx_t *c) { return c && c->span ? c->span->acc.n_loci : 0; }
 
 int inq_span_fetch_batch(inq_ctx_t *c, uint32_t *cigar, inq_read_t *reads, uint32_t *pair_read, uint64_t *locus_pair_off) {
     try {

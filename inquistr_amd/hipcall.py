@@ -49,6 +49,9 @@ ABI_SYMBOLS = (
     "inq_call_span",
     "inq_span_stage",
     "inq_call_span_staged",
+    "inq_call_span_deferred",
+    "inq_call_flush",
+    "inq_call_deferred_loci",
     "inq_span_fetch_batch",
     "inq_outlier_rows",
 )
@@ -206,6 +209,12 @@ def load(path: Optional[str] = None):
     L.inq_span_stage.argtypes = [vp, C.POINTER(SpanC), C.c_int]
     L.inq_call_span_staged.restype = C.c_int
     L.inq_call_span_staged.argtypes = [vp, C.POINTER(SpanC), C.c_int, C.POINTER(InqResultC), C.POINTER(SpanStatsC)]
+    L.inq_call_span_deferred.restype = C.c_int
+    L.inq_call_span_deferred.argtypes = [vp, C.POINTER(SpanC), C.c_int, C.POINTER(SpanStatsC)]
+    L.inq_call_flush.restype = C.c_int
+    L.inq_call_flush.argtypes = [vp, C.POINTER(InqResultC), C.c_uint64, C.POINTER(C.c_double)]
+    L.inq_call_deferred_loci.restype = C.c_uint64
+    L.inq_call_deferred_loci.argtypes = [vp]
     L.inq_outlier_rows.restype = C.c_int
     L.inq_outlier_rows.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32, vp, vp]
     L.inq_span_fetch_batch.restype = C.c_int
@@ -313,6 +322,44 @@ class Context:
         if rc != INQ_OK and check:
             self._raise(rc)
         return rc, p1, p2, int(res.n_tie_loci), stats
+
+    def call_span_deferred(self, comp, blocks, anchors, anchor_stop, locus_tid, locus_start, locus_end, minlen: int = 5, support: int = 3,
+                           unphased: bool = False, check: bool = True, stage_slot: Optional[int] = None):
+        """inq_call_span_deferred: appends the span's batch to the deferred one; returns (code, stats).  Rows: call_flush()."""
+        comp = np.frombuffer(comp, dtype=np.uint8)
+        blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK_DTYPE)
+        anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
+        stops = np.ascontiguousarray(anchor_stop, dtype=np.uint64)
+        lt = np.ascontiguousarray(locus_tid, dtype=np.int32)
+        ls = np.ascontiguousarray(locus_start, dtype=np.uint32)
+        le = np.ascontiguousarray(locus_end, dtype=np.uint32)
+        sp = SpanC(comp.ctypes.data, comp.size, blocks.ctypes.data, len(blocks), anchors.ctypes.data, stops.ctypes.data,
+                   len(anchors), lt.ctypes.data, ls.ctypes.data, le.ctypes.data, len(ls), minlen, support, 1 if unphased else 0, 0)
+        stats = SpanStatsC()
+        rc = INQ_OK
+        if stage_slot is not None:
+            rc = self._L.inq_span_stage(self._h, C.byref(sp), stage_slot)
+        if rc == INQ_OK:
+            rc = self._L.inq_call_span_deferred(self._h, C.byref(sp), -1 if stage_slot is None else stage_slot, C.byref(stats))
+        if rc != INQ_OK and check:
+            self._raise(rc)
+        return rc, stats
+
+    @property
+    def deferred_loci(self) -> int:
+        return int(self._L.inq_call_deferred_loci(self._h))
+
+    def call_flush(self, check: bool = True):
+        """inq_call_flush: (code, phase1, phase2, n_tie_loci, ms_call) for every locus deferred since the last flush."""
+        n = self.deferred_loci
+        p1 = np.full(n, np.nan)
+        p2 = np.full(n, np.nan)
+        res = InqResultC(p1.ctypes.data, p2.ctypes.data, None, None, 0)
+        ms = C.c_double(0.0)
+        rc = self._L.inq_call_flush(self._h, C.byref(res), n, C.byref(ms))
+        if rc != INQ_OK and check:
+            self._raise(rc)
+        return rc, p1, p2, int(res.n_tie_loci), float(ms.value)
 
     def span_fetch_batch(self, stats: "SpanStatsC", n_loci: int):
         """The batch the last call_span built on the device, as host arrays (cigar, reads, pair_read, locus_pair_off)."""

@@ -259,6 +259,38 @@ private:
     std::string err_;
 };
 
+// Span buffers that outlive one file: a cohort run (inq_session) hands the buffers of file k to file k + 2 instead of unmapping
+// and re-faulting a GB of pages per file.
+struct HostBufPool {
+    struct B {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+        bool pinned = false;
+    };
+    std::mutex mu;
+    std::vector<B> free_list;
+    bool take(size_t bytes, bool pinned, B *out) {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].cap >= bytes && free_list[i].pinned == pinned) {
+                *out = free_list[i];
+                free_list.erase(free_list.begin() + (long)i);
+                return true;
+            }
+        return false;
+    }
+    void give(const B &b) {
+        std::lock_guard<std::mutex> g(mu);
+        free_list.push_back(b);
+    }
+    ~HostBufPool() {
+        for (auto &b : free_list) {
+            if (b.pinned) inq_free_pinned(b.p);
+            else ::munmap(b.p, b.cap);
+        }
+    }
+};
+
 // Device front end, host half: a loader thread plans the spans, reads their compressed bytes (parallel pread;
 // into pageable memory by default: pinning a few hundred MB costs more than the staged copy it saves,
 // INQ_SPAN_PINNED=1 switches) and builds block tables and anchors, two spans ahead
@@ -277,11 +309,13 @@ public:
     // stage: called on the loader thread for every loaded span with the filled inq_span_t; returns true when the
     // span now sits in device slot `slot` (the upload then overlaps the caller's work on earlier spans)
     using StageFn = std::function<bool(const inq_span_t &, int slot)>;
+    // slot_base: 0 or 3, the set of device-side staging slots this pipeline uploads into; pool: where span buffers come from
+    // and go back to (may be null: mapped and unmapped by the pipeline)
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
-                 uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr)
+                 uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr)
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
-          stage_(std::move(stage)) {
-        for (int i = 0; i < 3; ++i) slots_[i].slot = i;
+          stage_(std::move(stage)), pool_(pool) {
+        for (int i = 0; i < 3; ++i) slots_[i].slot = slot_base + i;
         for (auto &it : slots_) free_.push_back(&it);
         th_ = std::thread([this] { run(); });
         if (stage_) up_ = std::thread([this] { run_uploads(); });  // span k uploads while span k + 1 is being read
@@ -335,7 +369,8 @@ public:
 private:
     void release_buf(Item &it) {
         if (it.buf) {
-            if (it.pinned) inq_free_pinned(it.buf);
+            if (pool_) pool_->give(HostBufPool::B{it.buf, it.cap, it.pinned});
+            else if (it.pinned) inq_free_pinned(it.buf);
             else ::munmap(it.buf, it.cap);
         }
         it.buf = nullptr;
@@ -344,6 +379,11 @@ private:
     bool fit(Item &it, size_t bytes) {
         if (bytes <= it.cap && it.buf) return true;
         release_buf(it);
+        HostBufPool::B got;
+        if (pool_ && pool_->take(bytes, pinned_, &got)) {
+            it.buf = got.p, it.cap = got.cap, it.pinned = got.pinned;
+            return true;
+        }
         const size_t want = bytes + bytes / 4 + (1u << 20);
         void *p = nullptr;
         if (pinned_ && inq_alloc_pinned(want, &p) == INQ_OK) it.pinned = true;
@@ -459,6 +499,7 @@ private:
     int n_threads_;
     bool pinned_;
     StageFn stage_;
+    HostBufPool *pool_ = nullptr;
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[3];
     std::vector<Item *> free_;
@@ -628,8 +669,35 @@ struct CallView {
     bool unphased;
 };
 
+// what a session adds to one call: a pipeline that was started ahead of it (its loader has been reading and uploading while the
+// previous file was being called), the buffer pool, the set of device staging slots
+struct SessionHooks {
+    SpanPipeline *early_pipe = nullptr;
+    HostBufPool *pool = nullptr;
+    int slot_base = 0;
+    int front = 0;  // 0 = decide here, 1 = host sweep, 2 = device spans (decided when the pipeline was started)
+};
+
+static int span_io_threads(const inq_call_args_t *args) {
+    // -t counts the reference's calling workers; here the host only copies file bytes, which a few pread
+    // streams do best whatever -t says (bounded by the machine)
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (int)std::min<uint64_t>(std::max<uint64_t>(args->threads, 8), std::min<uint64_t>(hw, 32));
+}
+
+static SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamFile &bam, const std::vector<RepeatInterval> &targets,
+                                         AsyncCtx &actx, int slot_base, HostBufPool *pool) {
+    const char *pin_env = std::getenv("INQ_SPAN_PINNED");
+    // the loader uploads every span it has read (waiting for the context the first time), so that the upload of span k+1
+    // overlaps the inflate of span k
+    return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
+                            [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; },
+                            slot_base, pool);
+}
+
 static int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,
-                            std::vector<double> &p2, char *errbuf, size_t errcap, double *t_front, double *t_dev) {
+                            std::vector<double> &p2, char *errbuf, size_t errcap, double *t_front, double *t_dev,
+                            const SessionHooks &hooks = SessionHooks()) {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const int timing = std::getenv("INQ_TIMING") ? (std::getenv("INQ_TIMING")[0] == '2' ? 2 : 1) : 0;
@@ -637,13 +705,8 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
     bool &leak_all = actx.leak;
     inq_ctx_t *&ctx = actx.ctx;
     int &hrc = actx.hrc;
-    // -t counts the reference's calling workers; here the host only copies file bytes, which a few pread
-    // streams do best whatever -t says (bounded by the machine)
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int n_io = (int)std::min<uint64_t>(std::max<uint64_t>(args->threads, 8), std::min<uint64_t>(hw, 32));
     std::vector<double> b1, b2;
     {
-        const char *pin_env = std::getenv("INQ_SPAN_PINNED");
         // the CLI sets INQ_FAST_EXIT: it is about to leave the process, so the span buffers (unmapping a GB
         // of touched pages takes ~0.1 s) and the device context are left to the operating system
         const char *fast_env = std::getenv("INQ_FAST_EXIT");
@@ -651,16 +714,48 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
         struct PipeHolder {
             SpanPipeline *p;
             const bool &leak;
+            bool owned;
             ~PipeHolder() {
-                if (!leak) delete p;
+                if (owned && !leak) delete p;
             }
-        } holder{new SpanPipeline(args->bam, V.bam, V.targets, span_bytes_from_env(), n_io, pin_env ? pin_env[0] == '1' : false,
-                                  // the loader uploads every span it has read (waiting for the context the first time), so
-                                  // that the upload of span k+1 overlaps the inflate of span k
-                                  [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; }),
-                 leak_all};
+        } holder{hooks.early_pipe ? hooks.early_pipe : start_span_pipeline(args, V.bam, V.targets, actx, hooks.slot_base, hooks.pool), leak_all,
+                 hooks.early_pipe == nullptr};
         SpanPipeline &pipe = *holder.p;
         bool joined = false;
+        // loci whose batches wait on the device (inq_call_span_deferred), in the order they were appended
+        constexpr size_t kFlushLoci = 40000;            // a launch of the locus kernels reaches ~6 TB/s from here on
+        constexpr uint64_t kFlushWords = 1ull << 31;    // ... or 8 GB of gathered CIGARs
+        std::vector<uint32_t> pending;
+        uint64_t pending_words = 0;
+        auto flush = [&]() -> int {
+            if (pending.empty()) return INQ_EXIT_OK;
+            const auto f0 = clk::now();
+            b1.assign(pending.size(), NAN);
+            b2.assign(pending.size(), NAN);
+            inq_result_t res;
+            std::memset(&res, 0, sizeof res);
+            res.phase1 = b1.data();
+            res.phase2 = b2.data();
+            double ms_call = 0;
+            int rc2 = inq_call_flush(ctx, &res, pending.size(), &ms_call);
+            *t_dev += secs(f0, clk::now());
+            if (timing == 2)
+                std::fprintf(stderr, "[inq call] @%.1f %zu loci, %.1f MB of CIGARs: locus kernels %.3f ms | wall %.2f ms\n", stamp_ms(), pending.size(),
+                             pending_words * 4 / 1e6, ms_call, secs(f0, clk::now()) * 1e3);
+            if (rc2 != INQ_OK) {
+                std::string m = std::string("device call failed: ") + inq_strerror(rc2);
+                if (rc2 == INQ_ERR_HIP) m += std::string(" [") + inq_last_error(ctx) + "]";
+                set_err(errbuf, errcap, m);
+                return (rc2 == INQ_ERR_HIP || rc2 == INQ_ERR_NOMEM || rc2 == INQ_ERR_NO_DEVICE) ? INQ_EXIT_ERROR : INQ_EXIT_PANIC;
+            }
+            for (size_t j = 0; j < pending.size(); ++j) {
+                p1[pending[j]] = b1[j];
+                p2[pending[j]] = b2[j];
+            }
+            pending.clear();
+            pending_words = 0;
+            return INQ_EXIT_OK;
+        };
         for (;;) {
             SpanPipeline::Item *it = nullptr;
             std::string ferr;
@@ -686,22 +781,18 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
             sp.minlen = V.minlen;
             sp.support = V.support;
             sp.unphased = V.unphased ? 1u : 0u;
-            b1.assign(sp.n_loci, NAN);
-            b2.assign(sp.n_loci, NAN);
-            inq_result_t res;
-            std::memset(&res, 0, sizeof res);
-            res.phase1 = b1.data();
-            res.phase2 = b2.data();
+            // the span's batch is appended to the one on the device; the locus kernels run once enough loci wait (a span of
+            // SEQ-bearing records holds a few hundred loci, a launch wants tens of thousands) or the file is through
             inq_span_stats_t stt;
-            int rc2 = it->staged ? inq_call_span_staged(ctx, &sp, it->slot, &res, &stt) : inq_call_span(ctx, &sp, &res, &stt);
+            int rc2 = inq_call_span_deferred(ctx, &sp, it->staged ? it->slot : -1, &stt);
             *t_dev += secs(tb, clk::now());
             if (timing == 2)
                 std::fprintf(stderr,
                              "[inq span] @%.1f waited %.2f ms | loci %llu comp %.1f MB -> %.1f MB, %llu records, %llu pairs | upload %.2f inflate %.2f scan %.2f "
-                             "join %.2f call %.2f ms | wall %.2f ms\n",
+                             "join %.2f ms | wall %.2f ms\n",
                              stamp_ms(), secs(ta, tb) * 1e3, (unsigned long long)sp.n_loci, sp.comp_bytes / 1e6, stt.inflated_bytes / 1e6,
                              (unsigned long long)stt.n_records, (unsigned long long)stt.n_pairs, stt.ms_upload, stt.ms_inflate,
-                             stt.ms_scan, stt.ms_join, stt.ms_call, secs(tb, clk::now()) * 1e3);
+                             stt.ms_scan, stt.ms_join, secs(tb, clk::now()) * 1e3);
             if (rc2 != INQ_OK) {
                 std::string m = std::string("device call failed: ") + inq_strerror(rc2);
                 if (rc2 == INQ_ERR_HIP) m += std::string(" [") + inq_last_error(ctx) + "]";
@@ -711,13 +802,20 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
                 set_err(errbuf, errcap, m);
                 return (rc2 == INQ_ERR_HIP || rc2 == INQ_ERR_NOMEM || rc2 == INQ_ERR_NO_DEVICE) ? INQ_EXIT_ERROR : INQ_EXIT_PANIC;
             }
-            for (uint64_t j = 0; j < sp.n_loci; ++j) {
-                p1[it->plan.locus_index[j]] = b1[j];
-                p2[it->plan.locus_index[j]] = b2[j];
-            }
+            pending.insert(pending.end(), it->plan.locus_index.begin(), it->plan.locus_index.end());
+            pending_words += stt.n_cigar_words;
             pipe.release(it);
+            if (pending.size() >= kFlushLoci || pending_words >= kFlushWords) {
+                int frc = flush();
+                if (frc != INQ_EXIT_OK) return frc;
+            }
+            continue;
         }
         if (!joined) actx.wait();
+        if (hrc == INQ_OK) {
+            int frc = flush();
+            if (frc != INQ_EXIT_OK) return frc;
+        }
         leak_all = fast_exit;  // only after a clean run: error paths tear down normally
         if (timing) std::fprintf(stderr, "[inq timing] spans done at %.3fs after the start of the device path\n", secs(t_begin, clk::now()));
     }
@@ -742,7 +840,7 @@ struct RowsOut {
 
 // the call on an opened BAM + parsed targets, on a device context that may outlive it (a session calls many BAMs on one)
 static int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepared &P, int out_fd, char *errbuf, size_t errcap,
-                             const RowsOut &rows, std::chrono::steady_clock::time_point t_start) {
+                             const RowsOut &rows, std::chrono::steady_clock::time_point t_start, const SessionHooks &hooks = SessionHooks()) {
     using clk = std::chrono::steady_clock;
     const bool timing = std::getenv("INQ_TIMING") != nullptr;
     double t_front = 0, t_dev = 0;
@@ -769,10 +867,10 @@ static int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepar
     };
 
     const auto t_open = clk::now();
-    const bool device_front = use_device_front(args, V.bam, V.targets);
+    const bool device_front = hooks.front ? hooks.front == 2 : use_device_front(args, V.bam, V.targets);
     if (device_front) {
         const auto t_choice = clk::now();
-        int drc = run_device_front(args, V, actx, p1, p2, errbuf, errcap, &t_front, &t_dev);
+        int drc = run_device_front(args, V, actx, p1, p2, errbuf, errcap, &t_front, &t_dev, hooks);
         if (drc != INQ_EXIT_OK) return drc;
         const auto t_run = clk::now();
         drc = emit();
@@ -1327,6 +1425,132 @@ int inq_run_write_inq(inq_run_t *r, const double *phase1, const double *phase2, 
     INQ_GUARD(write_rows(r->args->a.threads, r->P.targets, r->P.sample, phase1, phase2, out_fd, errbuf, errcap), errbuf, errcap)
 }
 void inq_run_close(inq_run_t *r) { delete r; }
+
+// ---- a session: many BAMs on ONE device context (a cohort is called sample by sample with the same BED, then combined:
+// src/combine.rs).  The HIP runtime's start-up (0.1 - 0.3 s, the whole cost of a 1 GB file) is paid once; span buffers are
+// reused; and while file k is being called, file k + 1 is opened, its targets parsed, its spans planned, read and uploaded
+// into the other set of device staging slots.  Each file's output is byte for byte that of its own `inquistr call`.
+struct inq_session {
+    AsyncCtx actx;
+    HostBufPool pool;
+};
+
+namespace {
+struct StagedFile {
+    std::unique_ptr<OwnedArgs> args;
+    Prepared P;
+    int rc = INQ_EXIT_OK;
+    std::string msg;
+    std::unique_ptr<SpanPipeline> pipe;
+    int slot_base = 0, front = 0;
+    std::chrono::steady_clock::time_point t_start;
+};
+
+void stage_file(inq_session *S, const inq_call_args_t *a, int slot_base, StagedFile &out) {
+    out.t_start = std::chrono::steady_clock::now();
+    try {
+        out.args.reset(new OwnedArgs(*a));
+        out.slot_base = slot_base;
+        out.rc = prepare(&out.args->a, out.P, out.msg);
+        if (out.rc != INQ_EXIT_OK) return;
+        out.front = use_device_front(&out.args->a, *out.P.bam, out.P.targets) ? 2 : 1;
+        if (out.front == 2) out.pipe.reset(start_span_pipeline(&out.args->a, *out.P.bam, out.P.targets, S->actx, slot_base, &S->pool));
+    } catch (const std::exception &e) {
+        out.rc = INQ_EXIT_ERROR;
+        out.msg = std::string("internal error: ") + e.what();
+    }
+}
+
+int run_staged(inq_session *S, StagedFile &f, int out_fd, char *errbuf, size_t errcap) {
+    if (f.rc != INQ_EXIT_OK) {
+        set_err(errbuf, errcap, f.msg);
+        return f.rc;
+    }
+    SessionHooks hooks;
+    hooks.early_pipe = f.pipe.get();
+    hooks.pool = &S->pool;
+    hooks.slot_base = f.slot_base;
+    hooks.front = f.front;
+    const bool keep_leak = S->actx.leak;
+    int rc = genotype_prepared(&f.args->a, S->actx, f.P, out_fd, errbuf, errcap, RowsOut(), f.t_start, hooks);
+    S->actx.leak = keep_leak;  // the context belongs to the session, whatever the single-call path decided
+    f.pipe.reset();            // joins the loader, hands the span buffers back to the pool
+    return rc;
+}
+}  // namespace
+
+int inq_session_open(int32_t device, inq_session_t **out) {
+    if (!out) return INQ_EXIT_ERROR;
+    *out = nullptr;
+    try {
+        inq_session *S = new inq_session();
+        S->actx.start(device);  // returns at once: the runtime starts on its own thread
+        *out = S;
+        return INQ_EXIT_OK;
+    } catch (...) {
+        return INQ_EXIT_ERROR;
+    }
+}
+
+static int inq_session_call_impl(inq_session_t *S, const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
+    if (!S || !args) return INQ_EXIT_ERROR;
+    StagedFile f;
+    stage_file(S, args, 0, f);
+    return run_staged(S, f, out_fd, errbuf, errcap);
+}
+int inq_session_call(inq_session_t *S, const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_session_call_impl(S, args, out_fd, errbuf, errcap), errbuf, errcap)
+}
+
+static int inq_session_call_many_impl(inq_session_t *S, const inq_call_args_t *args, size_t n, const int *out_fds, int *statuses, char *errbuf,
+                                      size_t errcap) {
+    if (!S || (n && (!args || !out_fds))) return INQ_EXIT_ERROR;
+    const bool timing = std::getenv("INQ_TIMING") != nullptr;
+    std::vector<StagedFile> st(n);
+    int worst = INQ_EXIT_OK;
+    bool have_msg = false;
+    if (n) stage_file(S, &args[0], 0, st[0]);
+    for (size_t k = 0; k < n; ++k) {
+        // file k + 1 is staged (opened, planned, read, uploaded into the other set of device slots) while file k is called
+        std::future<void> next;
+        if (k + 1 < n) next = std::async(std::launch::async, [&, k] { stage_file(S, &args[k + 1], 3 * (int)((k + 1) & 1), st[k + 1]); });
+        char msg[1024] = {0};
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc;
+        try {
+            rc = run_staged(S, st[k], out_fds[k], msg, sizeof msg);
+        } catch (const std::exception &e) {
+            rc = INQ_EXIT_ERROR;
+            std::snprintf(msg, sizeof msg, "internal error: %s", e.what());
+        }
+        if (timing)
+            std::fprintf(stderr, "[inq session] @%.1f file %zu (%s): status %d, %.1f ms since the previous file finished\n", stamp_ms(), k,
+                         args[k].bam ? args[k].bam : "?", rc, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (statuses) statuses[k] = rc;
+        if (rc != INQ_EXIT_OK) {
+            if (!have_msg) set_err(errbuf, errcap, std::string(args[k].bam ? args[k].bam : "?") + ": " + msg), have_msg = true;
+            if (worst == INQ_EXIT_OK || rc == INQ_EXIT_PANIC) worst = rc;
+        }
+        StagedFile done;
+        std::swap(done, st[k]);  // header, index, targets of file k go now, not at the end of the cohort
+        if (next.valid()) next.get();
+    }
+    return worst;
+}
+int inq_session_call_many(inq_session_t *S, const inq_call_args_t *args, size_t n, const int *out_fds, int *statuses, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_session_call_many_impl(S, args, n, out_fds, statuses, errbuf, errcap), errbuf, errcap)
+}
+
+void inq_session_close(inq_session_t *S) {
+    if (!S) return;
+    const char *fast_env = std::getenv("INQ_FAST_EXIT");
+    S->actx.leak = fast_env && fast_env[0] == '1';  // the CLI is about to leave the process (see run_device_front)
+    if (S->actx.leak) {
+        S->actx.wait();
+        S->pool.free_list.clear();  // left to the operating system as well
+    }
+    delete S;
+}
 
 // ---- spans: the host half of the device front end, on its own (no GPU involved) ----
 static int inq_spans_open_impl(const inq_call_args_t *args, uint64_t max_comp_bytes, inq_spans_t **out, char *errbuf, size_t errcap) {

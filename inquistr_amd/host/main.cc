@@ -1,9 +1,13 @@
 // main.cc — `inquistr call`: the CLI surface of the reference's `call` subcommand (src/main.rs:27-64),
 // same flags and defaults.  Other subcommands of the reference are out of scope.
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/inquistr_host.h"
 
@@ -86,12 +90,85 @@ int main(int argc, char **argv) {
         if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
         return rc;
     }
+    if (argc >= 2 && std::strcmp(argv[1], "cohort") == 0) {
+        // Not a subcommand of the reference: the loop a user writes around `inquiSTR call` for a cohort (one call per BAM with the
+        // same targets, then `combine`), run in ONE process so that the HIP runtime starts once.  Every <out-dir>/<sample>.inq is
+        // byte for byte what `inquistr call <BAM> ...` prints.
+        inq_call_args_t base;
+        std::memset(&base, 0, sizeof base);
+        base.minlen = 5, base.support = 3, base.threads = 1;
+        std::string out_dir, combined;
+        std::vector<std::string> bams;
+        for (int i = 2; i < argc; ++i) {
+            const std::string k = argv[i];
+            auto val = [&]() -> const char * {
+                if (i + 1 >= argc) {
+                    std::fprintf(stderr, "error: a value is required for '%s' but none was supplied\n", argv[i]);
+                    std::exit(2);
+                }
+                return argv[++i];
+            };
+            if (k == "-r" || k == "--region") base.region = val();
+            else if (k == "-R" || k == "--region-file" || k == "--region_file") base.region_file = val();
+            else if (k == "-m" || k == "--minlen") base.minlen = (uint32_t)std::strtoul(val(), nullptr, 10);
+            else if (k == "-s" || k == "--support") base.support = std::strtoull(val(), nullptr, 10);
+            else if (k == "-t" || k == "--threads") base.threads = std::strtoull(val(), nullptr, 10);
+            else if (k == "-u" || k == "--unphased") base.unphased = 1;
+            else if (k == "--device") base.device = (int32_t)std::strtol(val(), nullptr, 10);
+            else if (k == "-o" || k == "--out-dir") out_dir = val();
+            else if (k == "--combined") combined = val();
+            else if (k.size() > 1 && k[0] == '-') {
+                std::fprintf(stderr, "error: unexpected argument '%s' found\n", k.c_str());
+                return 2;
+            } else bams.push_back(k);
+        }
+        if (bams.empty() || out_dir.empty()) {
+            std::fputs("Usage: inquistr cohort [-r REGION | -R BED] [-m N] [-s N] [-t N] [-u] [--device N] --out-dir DIR [--combined FILE] <BAM>...\n", stderr);
+            return 2;
+        }
+        ::setenv("INQ_FAST_EXIT", "1", 0);
+        inq_session_t *S = nullptr;
+        if (inq_session_open(base.device, &S) != 0) return 1;
+        std::vector<inq_call_args_t> args(bams.size(), base);
+        std::vector<std::string> outs(bams.size());
+        std::vector<int> fds(bams.size(), -1), st(bams.size(), 0);
+        for (size_t k = 0; k < bams.size(); ++k) {
+            args[k].bam = bams[k].c_str();
+            char name[4096];
+            inq_host_sample_name(bams[k].c_str(), name, sizeof name);
+            outs[k] = out_dir + "/" + name + ".inq";
+            fds[k] = ::open(outs[k].c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fds[k] < 0) {
+                std::fprintf(stderr, "cannot write %s\n", outs[k].c_str());
+                return 1;
+            }
+        }
+        char err[2048] = {0};
+        int rc = inq_session_call_many(S, args.data(), args.size(), fds.data(), st.data(), err, sizeof err);
+        for (int fd : fds) ::close(fd);
+        for (size_t k = 0; k < bams.size(); ++k)
+            if (st[k] != 0) std::fprintf(stderr, "%s: exit status %d\n", bams[k].c_str(), st[k]);
+        if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
+        if (rc == 0 && !combined.empty()) {
+            int cfd = ::open(combined.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            std::vector<const char *> files;
+            for (auto &o : outs) files.push_back(o.c_str());
+            rc = cfd < 0 ? 1 : inq_combine(files.data(), files.size(), cfd, err, sizeof err);
+            if (cfd >= 0) ::close(cfd);
+            if (rc != 0) std::fprintf(stderr, "%s\n", err);
+        }
+        std::fflush(nullptr);
+        const char *fast = std::getenv("INQ_FAST_EXIT");
+        if (fast && fast[0] == '1') std::_Exit(rc);
+        inq_session_close(S);
+        return rc;
+    }
     if (argc < 2 || std::strcmp(argv[1], "call") != 0) {
         if (argc >= 2 && (!std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help"))) {
             std::puts("Tool to genotype STRs from long reads (MI355X build: `call` only)\n\nUsage: inquistr call [OPTIONS] <BAM>");
             return 0;
         }
-        std::fputs("error: this build provides the `call`, `combine` and `outlier` subcommands only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
+        std::fputs("error: this build provides the `call`, `combine`, `outlier` (and `cohort`: many `call`s in one process) subcommands only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
         return 2;
     }
     if (argc == 2) {  // arg_required_else_help

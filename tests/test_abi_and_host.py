@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     L = hipcall.load()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.inq_abi_version() == 3
+    assert L.inq_abi_version() == 4
     assert b"no CPU fallback" in L.inq_strerror(B.INQ_ERR_NO_DEVICE)
 
 

@@ -98,3 +98,82 @@ def test_one_process_per_gpu_rehearsal(tmp_path, frontend):
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert out.read_text() == single.read_text() and out.read_text().count("\n") == 4001
+
+
+@pytest.mark.parametrize("frontend", ["device", "host", None])
+def test_session_many_bams_equal_separate_calls(tmp_path, frontend):
+    """inq_session_call_many (one HIP context for a cohort; file k + 1 staged while file k is called) against one
+    inq_genotype_repeats per BAM: byte for byte the same .inq per file, a failing file in the middle does not disturb the
+    others, and `combine` of the session's outputs equals `combine` of the separate ones (src/combine.rs:27-59)."""
+    from tools import make_synth_bam
+
+    names, bed = [], None
+    for k, (wl, n) in enumerate([("phased10k", 700), ("phased10k", 350), ("expansion50k", 90), ("phased10k", 1200)]):
+        prefix = str(tmp_path / f"s{k}")
+        make_synth_bam.write_native(wl, n, prefix, threads=4)
+        names.append(prefix)
+    beds = [p + ".bed" for p in names]
+    missing = str(tmp_path / "missing.bam")
+    order = [names[0] + ".bam", names[1] + ".bam", missing, names[2] + ".bam", names[3] + ".bam"]
+    # every file against the SHORTEST bed (loci 0 .. 89 exist in all four files: same coordinates, generator positions)
+    bed = beds[2]
+    sep = []
+    for b in order:
+        if b == missing:
+            sep.append(None)
+            continue
+        o = tmp_path / (os.path.basename(b) + ".sep.inq")
+        with open(o, "w") as f:
+            call.genotype_repeats(b, None, bed, 5, 3, 4, False, None, None, out=f, frontend=frontend)
+        sep.append(o.read_text())
+    outs = [open(tmp_path / f"sess{k}.inq", "w") for k in range(len(order))]
+    with call.Session(0) as S:
+        st = S.call_many(order, outs, region_file=bed, threads=4, frontend=frontend)
+        assert st == [0, 0, 1, 0, 0], (st, S.last_message)
+        assert "missing.bam" in S.last_message
+        # the session stays usable: one more call on the same context
+        again = tmp_path / "again.inq"
+        with open(again, "w") as f:
+            S.call(order[0], region_file=bed, threads=4, out=f, frontend=frontend)
+    for o in outs:
+        o.close()
+    for k, b in enumerate(order):
+        if sep[k] is not None:
+            assert (tmp_path / f"sess{k}.inq").read_text() == sep[k], b
+    assert again.read_text() == sep[0]
+    # combine of the cohort
+    good = [k for k in range(len(order)) if sep[k] is not None]
+    a, b = tmp_path / "comb_sess.inq", tmp_path / "comb_sep.inq"
+    for dst, files in ((a, [str(tmp_path / f"sess{k}.inq") for k in good]),
+                       (b, [str(tmp_path / (os.path.basename(order[k]) + ".sep.inq")) for k in good])):
+        with open(dst, "w") as f:
+            call.combine(files, out=f)
+    assert a.read_text() == b.read_text() and a.read_text().count("\n") == 91
+
+
+def test_cohort_command_equals_call_per_bam(tmp_path):
+    """`inquistr cohort` (many `call`s in one process) writes, per BAM, what `inquistr call` prints, and --combined what
+    `inquistr combine` of those prints."""
+    from tools import make_synth_bam
+
+    prefixes = []
+    for k in range(3):
+        prefix = str(tmp_path / f"c{k}")
+        make_synth_bam.write_native("unphased100k", 500 + 100 * k, prefix, threads=4)
+        prefixes.append(prefix)
+    bed = prefixes[0] + ".bed"
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    r = subprocess.run([call.CLI_PATH, "cohort", "-R", bed, "-u", "-t", "4", "--out-dir", str(outdir), "--combined", str(tmp_path / "all.inq")]
+                       + [p + ".bam" for p in prefixes], capture_output=True, text=True, env=dict(os.environ, INQ_FRONTEND="device"))
+    assert r.returncode == 0, r.stderr
+    texts = []
+    for k, p in enumerate(prefixes):
+        one = subprocess.run([call.CLI_PATH, "call", p + ".bam", "-R", bed, "-u", "-t", "4"], capture_output=True, text=True,
+                             env=dict(os.environ, INQ_FRONTEND="device"))
+        assert one.returncode == 0, one.stderr
+        assert (outdir / f"c{k}.inq").read_text() == one.stdout
+        (tmp_path / f"one{k}.inq").write_text(one.stdout)
+        texts.append(str(tmp_path / f"one{k}.inq"))
+    comb = subprocess.run([call.CLI_PATH, "combine"] + texts, capture_output=True, text=True)
+    assert comb.returncode == 0 and (tmp_path / "all.inq").read_text() == comb.stdout

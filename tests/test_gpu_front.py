@@ -254,6 +254,76 @@ def test_call_span_matches_oracle_and_host_emulation(ctx, tmp_path, monkeypatch,
     sp.close()
 
 
+@pytest.mark.parametrize("seed,unphased,span_bytes,gap,flush_every", [(1, False, 3_000, None, 0), (2, True, 20_000, None, 3), (3, False, 3_000, None, 2),
+                                                                      (6, True, 30_000, 0, 0), (7, False, 1, None, 5)])
+def test_deferred_spans_equal_span_by_span_calls(ctx, tmp_path, monkeypatch, seed, unphased, span_bytes, gap, flush_every):
+    """inq_call_span_deferred + inq_call_flush (the locus kernels once over the batches of several spans: what the CLI does so
+    that a launch holds enough loci) against inq_call_span span by span: the same rows, locus for locus, and - fetched back -
+    the concatenation of the spans' batches; staged and unstaged spans mixed; buffers growing while they hold earlier spans."""
+    from inquistr_amd import call
+    from tests import gen
+    from tests.test_host_frontend import _expected, _make_case
+    from tools import bamio
+
+    if gap is not None:
+        monkeypatch.setenv("INQ_SPAN_GAP_BYTES", str(gap))
+    minlen, support = 5, [3, 1, 2, 3][seed % 4]
+    bam, bed, loci, recs = _make_case(tmp_path, seed, ultra_long=(seed == 3), block=bamio.BLOCK if gap is None else 1500)
+    sp = call.Spans(bam, region_file=bed, minlen=minlen, support=support, threads=2, unphased=unphased, max_comp_bytes=span_bytes)
+    spans = list(sp.spans())
+    sp.close()
+    assert len(spans) >= 2
+    args = lambda s: (s["comp"], s["blocks"], s["anchors"], s["anchor_stop"], s["locus_tid"], s["locus_start"], s["locus_end"], minlen, support, unphased)
+    one1, one2 = np.full(len(loci), np.nan), np.full(len(loci), np.nan)
+    per_span = []
+    for s_ in spans:
+        rc, p1, p2, ties, stats = ctx.call_span(*args(s_))
+        one1[s_["locus_index"]], one2[s_["locus_index"]] = p1, p2
+        per_span.append((ctx.span_fetch_batch(stats, len(s_["locus_index"])), len(s_["locus_index"])))
+    got1, got2 = np.full(len(loci), np.nan), np.full(len(loci), np.nan)
+    waiting, batch_of = [], []
+
+    def flush():
+        n = ctx.deferred_loci
+        assert n == sum(len(spans[k]["locus_index"]) for k in waiting)
+        rc, p1, p2, ties, ms = ctx.call_flush()
+        assert rc == 0 and len(p1) == n and ctx.deferred_loci == 0
+        idx = np.concatenate([spans[k]["locus_index"] for k in waiting]) if waiting else np.zeros(0, dtype=np.int64)
+        got1[idx], got2[idx] = p1, p2
+        # the accumulated batch = the spans' batches one behind the other (offsets rebased)
+        class St:  # sizes of the accumulated batch for span_fetch_batch
+            n_cigar_words = sum(len(per_span[k][0][0]) for k in waiting)
+            n_reads = sum(len(per_span[k][0][1]) for k in waiting)
+            n_pairs = sum(len(per_span[k][0][2]) for k in waiting)
+        if n:
+            dev = ctx.span_fetch_batch(St, n)
+            j = 0
+            for k in waiting:
+                for jj in range(per_span[k][1]):
+                    assert _locus_view(dev, j) == _locus_view(per_span[k][0], jj), (seed, k, jj)
+                    j += 1
+        waiting.clear()
+
+    for k, s_ in enumerate(spans):
+        rc, stats = ctx.call_span_deferred(*args(s_), stage_slot=(k % 3) if k % 2 else None)
+        assert rc == 0
+        waiting.append(k)
+        if flush_every and (k + 1) % flush_every == 0:
+            flush()
+    flush()
+    flush()  # nothing waits: an empty flush is fine
+    assert gen.same_f64(got1, one1) and gen.same_f64(got2, one2)
+    want1, want2 = _expected(loci, recs, unphased, minlen, support)
+    assert gen.same_f64(got1, want1) and gen.same_f64(got2, want2)
+    # parameters must not change inside a batch
+    ctx.call_span_deferred(*args(spans[0]))
+    bad = list(args(spans[1]))
+    bad[7] = minlen + 1
+    rc, _ = ctx.call_span_deferred(*bad, check=False)
+    assert rc == hipcall.INQ_ERR_ARG
+    ctx.call_flush()
+
+
 @pytest.mark.parametrize("seed,unphased,threads", [(11, False, 1), (12, True, 4)])
 def test_device_front_end_text_equals_host_front_end(tmp_path, seed, unphased, threads):
     from inquistr_amd import call
