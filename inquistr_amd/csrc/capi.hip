@@ -2,6 +2,8 @@
 // HIP only: there is no CPU fallback; without a gfx950 device every entry fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -78,7 +80,18 @@ int inq_ctx_create(int device_id, inq_ctx_t **out) {
     if (!out) return INQ_ERR_ARG;
     *out = nullptr;
     int n = 0;
+    // INQ_TIMING=2: where the start-up goes (the runtime's own initialisation is most of a short run)
+    const char *tenv = std::getenv("INQ_TIMING");
+    const bool verbose = tenv && tenv[0] == '2';
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[inq ctx] %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return INQ_ERR_NO_DEVICE;
+    lap("hipGetDeviceCount (runtime init)");
     if (device_id < 0 || device_id >= n) return INQ_ERR_ARG;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return INQ_ERR_HIP;
@@ -91,17 +104,22 @@ int inq_ctx_create(int device_id, inq_ctx_t **out) {
         inq_ctx_destroy(c);
         return code;
     };
+    lap("device properties");
     if (hipSetDevice(device_id) != hipSuccess) return fail(INQ_ERR_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(INQ_ERR_HIP);
+    lap("hipSetDevice + first stream");
     if (hipMalloc((void **)&c->d_status, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_NOMEM);
     if (hipMemset(c->d_status, 0, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_HIP);
     if (hipHostMalloc((void **)&c->h_status, sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) return fail(INQ_ERR_NOMEM);
+    lap("status buffers");
     if (span_state_init(c) != INQ_OK) return fail(INQ_ERR_HIP);
+    lap("span state (events, streams)");
     // load the code objects while the caller is still busy opening its input
     preload_locus(c->stream);
     preload_inflate(c->stream);
     preload_scan(c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(INQ_ERR_HIP);
+    lap("code objects (3 empty launches)");
     *out = c;
     return INQ_OK;
 }
