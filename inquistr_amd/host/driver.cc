@@ -312,9 +312,10 @@ public:
     // slot_base: 0 or 3, the set of device-side staging slots this pipeline uploads into; pool: where span buffers come from
     // and go back to (may be null: mapped and unmapped by the pipeline)
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
-                 uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr)
+                 uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr,
+                 std::function<void()> gate = nullptr)
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
-          stage_(std::move(stage)), pool_(pool) {
+          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)) {
         for (int i = 0; i < 3; ++i) slots_[i].slot = slot_base + i;
         for (auto &it : slots_) free_.push_back(&it);
         th_ = std::thread([this] { run(); });
@@ -418,6 +419,10 @@ private:
         // span k + 1 is planned (index searches for some 25 000 loci: ~4 ms) on a helper thread while span k is being read
         SpanPlan ahead;
         bool have = planner_.next(ahead);
+        // The first read waits for the device context: sixteen pread streams faulting in fresh span buffers while the HIP
+        // runtime starts up (both live on the address space's mapping lock) stretched its start-up from ~100 ms to 190 - 290 ms
+        // (profiles/r03_results/loader_vs_runtime_startup.txt); reading 268 MB takes 7 ms once the runtime is up.
+        if (have && gate_) gate_();
         while (have) {
             Item *it = nullptr;
             {
@@ -500,6 +505,7 @@ private:
     bool pinned_;
     StageFn stage_;
     HostBufPool *pool_ = nullptr;
+    std::function<void()> gate_;
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[3];
     std::vector<Item *> free_;
@@ -692,7 +698,7 @@ static SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamF
     // overlaps the inflate of span k
     return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
                             [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; },
-                            slot_base, pool);
+                            slot_base, pool, std::getenv("INQ_EARLY_READ") ? std::function<void()>() : std::function<void()>([&actx] { (void)actx.wait(); }));
 }
 
 static int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,
@@ -723,7 +729,7 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
         SpanPipeline &pipe = *holder.p;
         bool joined = false;
         // loci whose batches wait on the device (inq_call_span_deferred), in the order they were appended
-        constexpr size_t kFlushLoci = 40000;            // a launch of the locus kernels reaches ~6 TB/s from here on
+        constexpr size_t kFlushLoci = 100000;           // a launch of the locus kernels reaches its full rate from here on (0.70 of peak at 53 000 loci in the CLI's trace)
         constexpr uint64_t kFlushWords = 1ull << 31;    // ... or 8 GB of gathered CIGARs
         std::vector<uint32_t> pending;
         uint64_t pending_words = 0;
