@@ -168,6 +168,34 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                                     and res["gpu_cli_host_front"]["inq_identical"])
         for m in "BAC":
             res[f"speedup_vs_{m}"] = res["gpu_cli_device_front"]["loci_per_s"] / res[f"cpu_{m}"]["loci_per_s"]
+        # a cohort: the same command for several BAMs in ONE process (`inquistr cohort` = inq_session_call_many: one HIP context,
+        # file k + 1 staged while file k is called).  The HIP runtime's start-up - 0.1 to 0.4 s from run to run, most of a single
+        # file's time at this size - is paid once; what an added file costs is (t(n files) - t(1 file)) / (n - 1).
+        try:
+            n_co = 5
+            links = []
+            for k in range(n_co):
+                ln = f"{prefix}.co{k}.bam"
+                for ext in ("", ".bai"):
+                    if os.path.exists(ln + ext):
+                        os.unlink(ln + ext)
+                    os.link(prefix + ".bam" + ext, ln + ext)
+                links.append(ln)
+            outdir = os.path.join(tmp, "cohort_out")
+            os.makedirs(outdir, exist_ok=True)
+            co = [cli, "cohort", "-R", prefix + ".bed", "-t", str(threads), "--out-dir", outdir] + un
+            env_d = dict(os.environ, INQ_FRONTEND="device")
+            t1 = statistics.median(run(co + links[:1], env_d)[0] for _ in range(3))
+            tn = statistics.median(run(co + links, env_d)[0] for _ in range(3))
+            per = max((tn - t1) / (n_co - 1), 1e-9)
+            body = out_dev.split(b"\n", 1)[1]
+            same = all(open(os.path.join(outdir, os.path.basename(ln)[: -len(".bam")] + ".inq"), "rb").read().split(b"\n", 1)[1] == body for ln in links)
+            res["cohort"] = {"files": n_co, "seconds_1_file": t1, "seconds_n_files": tn, "seconds_per_added_file": per,
+                             "loci_per_s_per_added_file": loci / per, "speedup_vs_B_per_added_file": (loci / per) / res["cpu_B"]["loci_per_s"],
+                             "rows_identical_to_single_calls": bool(same),
+                             "note": "inquistr cohort (many calls in one process, one device context); medians of 3 whole-process wall times; the files are hard links of the one BAM (every program here reads from the page cache)"}
+        except Exception as e:  # noqa: BLE001
+            res["cohort"] = {"error": f"{type(e).__name__}: {e}"}
         if "cpu_B_all_cores" in res:
             res["inq_identical"] = bool(res["inq_identical"] and res["cpu_B_all_cores"]["inq_identical"])
             res["speedup_vs_B_all_cores"] = res["gpu_cli_device_front"]["loci_per_s"] / res["cpu_B_all_cores"]["loci_per_s"]

@@ -120,6 +120,7 @@ struct WgLds {
     // segment's second half with the bytes produced before it (position | bytes << 16, kNoMid = the chain ended before)
     uint16_t start_sh[T];
     uint32_t mid_sh[T];
+    uint16_t ntok_sh[T], midtok_sh[T];  // tokens the segment's chain left behind (kTokOverflow: none usable), of which in front of mid
     uint16_t sorted[kMaxLit + kMaxDist];  // symbols by (code length, value): literal/length, then distance
     uint32_t limit[2][16], base[2][16];
     // block-uniform state
@@ -130,6 +131,15 @@ struct WgLds {
 // root values: < 32768 a byte of an earlier stretch (deflate distances are <= 32768), 32768 .. 32768 + kRoundCap a byte of
 // this stretch, >= kRootLit a literal (low byte)
 constexpr uint32_t kRootLit = 0xff00u;
+// tokens (the symbols of a segment as its last counting pass decoded them, kept in global memory for the commit): a literal is
+// kTokLit | byte, a match length << 16 | distance - 1.  Segment s of block b keeps its i-th token at
+// tokens[((b * kTokCap + i) * T + s]: the lanes of a wave, all at the same i, store and load 256 contiguous bytes.
+#ifndef INQ_WG_TOKCAP
+#define INQ_WG_TOKCAP 64
+#endif
+constexpr uint32_t kTokCap = INQ_WG_TOKCAP;  // a segment with more symbols (256 bits of codes under 4 bits) is decoded again by the commit
+constexpr uint32_t kTokLit = 0x80000000u;
+constexpr uint32_t kTokOverflow = 0xffffu;
 constexpr uint32_t kNoMid = 0xffffffffu;
 constexpr uint32_t kStopped = 0x80000000u;  // in end_bit: the chain met EOB or a pattern that is no code
 constexpr uint32_t kStopEob = 0x40000000u;  // ... and it was EOB
@@ -224,16 +234,69 @@ __device__ __forceinline__ uint32_t canon_entry(const WgLds<T> &L, int tbl, uint
     return idx < (uint32_t)kMaxDist ? dist_entry(L.sorted[kMaxLit + idx], len) : kNoCode;
 }
 
+// Roots of the `len` bytes of a match at distance `dist`, written by the lane that owns bytes [own, lane_end) of the stretch
+// (all positions relative to the stretch's first byte); p = position of the match's first byte.
+template <int T>
+__device__ __forceinline__ void root_match(WgLds<T> &L, uint32_t p, uint32_t own, uint32_t lane_end, uint32_t len, uint32_t dist) {
+    // the lane's own bytes are rooted already (it walks them in order; LDS operations of a wave execute in
+    // order); a source in front of the lane's stretch stays a pointer for the jumping sweeps.  Roots go four
+    // at a time (8 bytes); a group may write beyond the match's end as long as it stays inside the lane's own
+    // bytes: the symbols behind it write those entries again, later.
+    const int32_t sp0 = (int32_t)(p - dist);  // may lie in front of the stretch (negative)
+    auto put4 = [&](uint32_t at, uint64_t w, uint32_t cnt) {
+        if (at + 4u <= lane_end) __builtin_memcpy(&L.root[at], &w, 8);
+        else
+            for (uint32_t j = 0; j < cnt && j < 4u; ++j, w >>= 16) L.root[at + j] = (uint16_t)w;
+    };
+    if (sp0 + (int32_t)len <= (int32_t)own) {
+        // the whole source lies in front of this lane's stretch: the roots are consecutive pointers
+        const uint32_t v = (uint32_t)(sp0 + 32768);
+        for (uint32_t k = 0; k < len; k += 4u) {
+            const uint32_t a = (v + k) | ((v + k + 1u) << 16), b2 = (v + k + 2u) | ((v + k + 3u) << 16);
+            put4(p + k, (uint64_t)a | ((uint64_t)b2 << 32), len - k);
+        }
+    } else if (sp0 >= (int32_t)own) {
+        // the whole source lies in the lane's own stretch, already rooted: copy roots (a group never reads what
+        // it writes; later groups may read what earlier ones wrote: LDS is in order).  A period below four
+        // (runs) gives the first group from the period's entries and the rest from a multiple of it.
+        uint32_t back = dist, k = 0;
+        if (dist < 4u) {
+            uint64_t w;
+            __builtin_memcpy(&w, &L.root[(uint32_t)sp0], 8);  // entries sp0 .. sp0 + 3 <= p + 2: inside the match (len >= 3)
+            const uint64_t e0 = w & 0xffffu, e1 = (w >> 16) & 0xffffu, e2 = (w >> 32) & 0xffffu;
+            const uint64_t g = dist == 1u ? e0 * 0x0001000100010001ull
+                               : dist == 2u ? (e0 | e1 << 16) * 0x0000000100000001ull
+                                            : (e0 | e1 << 16 | e2 << 32 | e0 << 48);
+            put4(p, g, len);
+            back = dist == 3u ? 6u : 4u;
+            k = 4u;
+        }
+        for (; k < len; k += 4u) {
+            uint64_t w;
+            __builtin_memcpy(&w, &L.root[p + k - back], 8);
+            put4(p + k, w, len - k);
+        }
+    } else {  // the source straddles the start of the lane's stretch
+        for (uint32_t k = 0; k < len; ++k) {
+            const int32_t sp = sp0 + (int32_t)k;
+            L.root[p + k] = sp >= (int32_t)own ? L.root[(uint32_t)sp] : (uint16_t)(sp + 32768);
+        }
+    }
+}
+
 // Decodes the symbols that START in [start, seg_end) of one lane's segment.  MODE 0: counts only.  MODE 1 (commit):
 // literals go to out[o...] and every byte gets its root (r0 = first output byte of the round).  MODE 2 (a lone lane
 // whose output exceeds the round's root array): literals and matches go straight to the output, in order.
 // Returns the position behind the last decoded symbol (| kStopped / kStopEob).  `bad` collects INQ_INFLATE_* bits.
+// MODE 0 with tok != null also leaves the symbols behind as tokens (tok = this segment's column of the block's token scratch,
+// stride T words): *ntok = how many the chain produced (only the first kTokCap are stored), *mid_tok = how many before `mid`.
 template <int T, int MODE>
 __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, uint32_t seg_end, uint32_t &nbytes, uint8_t *out, uint32_t o,
-                                                   uint32_t r0, uint32_t &bad, uint32_t *mid = nullptr) {
+                                                   uint32_t r0, uint32_t &bad, uint32_t *mid = nullptr, uint32_t *tok = nullptr,
+                                                   uint32_t *ntok = nullptr, uint32_t *mid_tok = nullptr) {
     SegBits b;
     b.init(L.stage, start);
-    uint32_t nb = 0, stop = 0;
+    uint32_t nb = 0, stop = 0, nt = 0;
     const uint32_t lane_end = MODE == 1 ? o - r0 + nbytes : 0u;  // MODE 1: nbytes comes in as the job's counted bytes
     // MODE 0 walks the segment's two halves one after the other and notes where the chain enters the second
     if (MODE == 0) *mid = kNoMid;
@@ -242,6 +305,7 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
     if (MODE == 0 && half == 1) {
         if (stop) break;
         *mid = b.pos | (nb << 16);
+        if (tok) *mid_tok = nt;
     }
     while (b.pos < lim) {
         const uint32_t bits = b.peek();
@@ -261,6 +325,10 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
         if (!(e & (E_LEN << 4))) {
             if (MODE == 2) out[o + nb] = (uint8_t)(e >> 16);
             if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));  // the byte itself: stored by the gather, coalesced
+            if (MODE == 0 && tok) {
+                if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
+                ++nt;
+            }
             ++nb;
             continue;
         }
@@ -278,6 +346,10 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
         const uint32_t dxb = (d >> 8) & 15u;
         const uint32_t dist = (d >> 16) + __builtin_amdgcn_ubfe(dbits, dn, dxb);
         b.consume(dn + dxb);
+        if (MODE == 0 && tok) {
+            if (nt < kTokCap) tok[nt * T] = (len << 16) | (dist - 1u);
+            ++nt;
+        }
         if (MODE) {
             if (dist > o + nb) {
                 bad |= INQ_INFLATE_BAD_DISTANCE;
@@ -285,52 +357,7 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
                 break;
             }
             if (MODE == 1) {
-                // the lane's own bytes are rooted already (it walks them in order; LDS operations of a wave execute in
-                // order); a source in front of the lane's stretch stays a pointer for the jumping sweeps.  Roots go four
-                // at a time (8 bytes); a group may write beyond the match's end as long as it stays inside the lane's own
-                // bytes: the symbols behind it write those entries again, later.
-                const uint32_t p = o + nb - r0;  // relative to the stretch
-                const uint32_t own = o - r0;
-                const int32_t sp0 = (int32_t)(p - dist);  // may lie in front of the stretch (negative)
-                auto put4 = [&](uint32_t at, uint64_t w, uint32_t cnt) {
-                    if (at + 4u <= lane_end) __builtin_memcpy(&L.root[at], &w, 8);
-                    else
-                        for (uint32_t j = 0; j < cnt && j < 4u; ++j, w >>= 16) L.root[at + j] = (uint16_t)w;
-                };
-                if (sp0 + (int32_t)len <= (int32_t)own) {
-                    // the whole source lies in front of this lane's stretch: the roots are consecutive pointers
-                    const uint32_t v = (uint32_t)(sp0 + 32768);
-                    for (uint32_t k = 0; k < len; k += 4u) {
-                        const uint32_t a = (v + k) | ((v + k + 1u) << 16), b2 = (v + k + 2u) | ((v + k + 3u) << 16);
-                        put4(p + k, (uint64_t)a | ((uint64_t)b2 << 32), len - k);
-                    }
-                } else if (sp0 >= (int32_t)own) {
-                    // the whole source lies in the lane's own stretch, already rooted: copy roots (a group never reads what
-                    // it writes; later groups may read what earlier ones wrote: LDS is in order).  A period below four
-                    // (runs) gives the first group from the period's entries and the rest from a multiple of it.
-                    uint32_t back = dist, k = 0;
-                    if (dist < 4u) {
-                        uint64_t w;
-                        __builtin_memcpy(&w, &L.root[(uint32_t)sp0], 8);  // entries sp0 .. sp0 + 3 <= p + 2: inside the match (len >= 3)
-                        const uint64_t e0 = w & 0xffffu, e1 = (w >> 16) & 0xffffu, e2 = (w >> 32) & 0xffffu;
-                        const uint64_t g = dist == 1u ? e0 * 0x0001000100010001ull
-                                           : dist == 2u ? (e0 | e1 << 16) * 0x0000000100000001ull
-                                                        : (e0 | e1 << 16 | e2 << 32 | e0 << 48);
-                        put4(p, g, len);
-                        back = dist == 3u ? 6u : 4u;
-                        k = 4u;
-                    }
-                    for (; k < len; k += 4u) {
-                        uint64_t w;
-                        __builtin_memcpy(&w, &L.root[p + k - back], 8);
-                        put4(p + k, w, len - k);
-                    }
-                } else {  // the source straddles the start of the lane's stretch
-                    for (uint32_t k = 0; k < len; ++k) {
-                        const int32_t sp = sp0 + (int32_t)k;
-                        L.root[p + k] = sp >= (int32_t)own ? L.root[(uint32_t)sp] : (uint16_t)(sp + 32768);
-                    }
-                }
+                root_match<T>(L, o + nb - r0, o - r0, lane_end, len, dist);
             } else {
                 copy_match(out + o + nb, dist, len);
             }
@@ -339,7 +366,37 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
     }
     }
     nbytes = nb;
+    if (MODE == 0 && tok) *ntok = nt;
     return b.pos | stop;
+}
+
+// The commit of a job from its tokens: no Huffman decode, no bit cursor.  tok = the segment's token column, tokens [i0, i1);
+// the job's bytes start at output position o (the round's first byte at r0 is the stretch's origin) and are `nbytes` long.
+template <int T>
+__device__ __forceinline__ void commit_tokens(WgLds<T> &L, const uint32_t *tok, uint32_t i0, uint32_t i1, uint32_t o, uint32_t r0, uint32_t nbytes,
+                                              uint32_t &bad) {
+    const uint32_t own = o - r0, lane_end = own + nbytes;
+    uint32_t p = own;
+    // four tokens in flight ahead of the one being written out (the loads are independent of everything the loop computes)
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    auto fetch = [&](uint32_t i) -> uint32_t { return tok[(i < i1 ? i : i1 - 1u) * T]; };
+    if (i0 < i1) q0 = fetch(i0), q1 = fetch(i0 + 1u), q2 = fetch(i0 + 2u), q3 = fetch(i0 + 3u);
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t t = q0;
+        q0 = q1, q1 = q2, q2 = q3, q3 = fetch(i + 4u);
+        if (t & kTokLit) {
+            L.root[p] = (uint16_t)(kRootLit | (t & 0xffu));
+            ++p;
+            continue;
+        }
+        const uint32_t len = t >> 16, dist = (t & 0xffffu) + 1u;
+        if (dist > o - own + p || p + len > lane_end) {  // (o - own = r0: the bytes in front of the stretch; a token is what this kernel wrote, the second test only keeps LDS writes inside the job)
+            bad |= INQ_INFLATE_BAD_DISTANCE;
+            break;
+        }
+        root_match<T>(L, p, own, lane_end, len, dist);
+        p += len;
+    }
 }
 
 // ---- workgroup-wide helpers (T lanes, T / 64 waves); every lane must call them
@@ -745,8 +802,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             __syncthreads();
             const uint32_t seg_end = ((uint32_t)tid + 1u) * kSegBits;
             uint32_t start = tid == 0 ? (P & 31u) : (uint32_t)tid * kSegBits;
-            uint32_t nbytes = 0, bad = 0, mid = kNoMid;
-            uint32_t end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid);
+            uint32_t nbytes = 0, bad = 0, mid = kNoMid, ntok = 0, mid_tok = 0;
+            uint32_t *const tok = a.tokens ? a.tokens + (bi * kTokCap) * (uint64_t)T + (uint32_t)tid : nullptr;
+            uint32_t end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
             DBG_N(1);
             DBG_N(2);
             // ---- until every chain starts where its left neighbour's ended (lanes behind the first stop do not matter)
@@ -766,7 +824,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 }
                 if (mismatch) {
                     start = left & 0x3fffffffu;
-                    end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid);
+                    end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
                 }
                 DBG_N(2);
                 __syncthreads();  // end_bit[] read by everyone before it is rewritten
@@ -778,6 +836,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             L.off_sh[tid] = off_b;
             L.start_sh[tid] = (uint16_t)start;
             L.mid_sh[tid] = mid;
+            L.ntok_sh[tid] = (uint16_t)(tok && ntok <= kTokCap ? ntok : kTokOverflow);
+            L.midtok_sh[tid] = (uint16_t)mid_tok;
             if (tid == 0) L.off_sh[T] = tot_b;
             if (tid == (int)ncommit - 1) {  // the last chain of the round: where the next round starts, and why this one ended
                 const uint32_t stop = end & (kStopped | kStopEob);
@@ -823,6 +883,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                         else if (!second) js = s0, je = m & 0xffffu, jo = ob, jn = m >> 16;
                         else js = m & 0xffffu, je = send, jo = ob + (m >> 16), jn = oe - ob - (m >> 16);
                         if (m == kNoMid && second) continue;
+                        const uint32_t nt_seg = L.ntok_sh[seg];
+                        if (nt_seg != kTokOverflow) {  // the symbols are there already: write their roots
+                            const uint32_t mt = L.midtok_sh[seg];
+                            const uint32_t i0 = (m != kNoMid && second) ? mt : 0u, i1 = (m != kNoMid && !second) ? mt : nt_seg;
+                            commit_tokens<T>(L, a.tokens + (bi * kTokCap) * (uint64_t)T + seg, i0, i1, out0 + jo, r0, jn, cbad);
+                            continue;
+                        }
                         uint32_t nb2 = jn;
                         (void)decode_segment<T, 1>(L, js, je, nb2, out, out0 + jo, r0, cbad);
                     }
@@ -933,6 +1000,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
     }
 #endif
 }
+
+#ifndef INQ_WG_T
+#define INQ_WG_T 128
+#endif
+uint64_t inflate_token_words(uint64_t n_blocks) { return n_blocks * (uint64_t)kTokCap * INQ_WG_T; }
 
 void launch_bgzf_inflate_wg(const InflateArgs &a, hipStream_t s) {
     if (!a.n_blocks) return;

@@ -20,7 +20,11 @@ struct InflateArgs {
     uint32_t debug_flags;    // timing experiments only: 1 = drop literal stores, 2 = drop match copies, 4 = block_status receives shader kilo-cycles
     uint32_t verify_crc;     // also check every block against the CRC32 of its trailer (comp holds whole blocks)
     uint32_t algo;           // 0 = one workgroup per block (bgzf_inflate_wg.hip), 1 = one lane per block (bgzf_inflate.hip), 2 = by block count
+    // workgroup kernel: scratch for the symbols of a round as decoded by the counting passes (inflate_token_words(n_blocks)
+    // u32), so that the commit does not decode them again; null = the commit decodes (round 2's form)
+    uint32_t *tokens;
 };
+uint64_t inflate_token_words(uint64_t n_blocks);
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s);
 void launch_bgzf_inflate_wg(const InflateArgs &a, hipStream_t s);  // the inflate alone, no CRC pass
 

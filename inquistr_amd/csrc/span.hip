@@ -17,6 +17,7 @@
 namespace inq {
 
 struct SpanState {
+    DevBuf tok;  // the workgroup inflate's token scratch
     DevBuf comp, blocks, u, block_status, anchors, anchor_cnt, anchor_base, rec_off, reads, info, key, endkey, pmax, cig_off, cigar,
         anchor_stop, ltid, lstart, lend, locus_cnt, locus_off, pair_read, p1, p2, tmp;
     FrontStatus *d_st = nullptr;
@@ -65,7 +66,7 @@ void span_state_destroy(SpanState *S) {
     if (!S) return;
     for (DevBuf *b : {&S->comp, &S->blocks, &S->u, &S->block_status, &S->anchors, &S->anchor_cnt, &S->anchor_base, &S->rec_off,
                       &S->reads, &S->info, &S->key, &S->endkey, &S->pmax, &S->cig_off, &S->cigar, &S->anchor_stop, &S->ltid, &S->lstart, &S->lend, &S->locus_cnt,
-                      &S->locus_off, &S->pair_read, &S->p1, &S->p2, &S->tmp})
+                      &S->locus_off, &S->pair_read, &S->p1, &S->p2, &S->tmp, &S->tok})
         if (b->p) (void)hipFree(b->p);
     for (auto &g : S->stage)
         for (DevBuf *b : {&g.comp, &g.blocks, &g.anchors, &g.anchor_stop})
@@ -187,6 +188,11 @@ int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t c
     if (const char *dbg = std::getenv("INQ_INFLATE_DEBUG")) ia.debug_flags = (uint32_t)std::atoi(dbg);
 #endif
     ia.algo = c->inflate_algo;
+    ia.tokens = nullptr;
+    if (ia.algo != 1u && c->inflate_tokens) {
+        if ((rc = ensure(c, S->tok, inflate_token_words(n_blocks) * 4)) != INQ_OK) return rc;
+        ia.tokens = (uint32_t *)S->tok.p;
+    }
     launch_bgzf_inflate(ia, s);
     HIP_TRY(c, hipGetLastError());
     return INQ_OK;

@@ -419,9 +419,10 @@ private:
         // span k + 1 is planned (index searches for some 25 000 loci: ~4 ms) on a helper thread while span k is being read
         SpanPlan ahead;
         bool have = planner_.next(ahead);
-        // The first read waits for the device context: sixteen pread streams faulting in fresh span buffers while the HIP
-        // runtime starts up (both live on the address space's mapping lock) stretched its start-up from ~100 ms to 190 - 290 ms
-        // (profiles/r03_results/loader_vs_runtime_startup.txt); reading 268 MB takes 7 ms once the runtime is up.
+        // INQ_GATE_READS=1: the first read waits for the device context.  Tried because the runtime's start-up looked longer
+        // while the loader was reading (two boxes, 102 vs 221 ms); five runs each way on a third box showed the start-up
+        // varying between 108 and 431 ms with and without early reads alike (profiles/r03_results/loader_gate_ab.txt): it
+        // is hipInit itself that varies (57 - 224 ms), so reads start at once - the spans are there when the context is.
         if (have && gate_) gate_();
         while (have) {
             Item *it = nullptr;
@@ -698,7 +699,7 @@ static SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamF
     // overlaps the inflate of span k
     return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
                             [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; },
-                            slot_base, pool, std::getenv("INQ_EARLY_READ") ? std::function<void()>() : std::function<void()>([&actx] { (void)actx.wait(); }));
+                            slot_base, pool, std::getenv("INQ_GATE_READS") ? std::function<void()>([&actx] { (void)actx.wait(); }) : std::function<void()>());
 }
 
 static int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,

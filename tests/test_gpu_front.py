@@ -12,11 +12,13 @@ from inquistr_amd import hipcall
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["inflate_wg", "inflate_lane"])
+@pytest.fixture(scope="module", params=[(0, 1), (0, 0), (1, 0)], ids=["inflate_wg", "inflate_wg_commit_decodes", "inflate_lane"])
 def ctx(request):
-    """Both inflate kernels (workgroup per block / lane per block) go through every test of this file."""
+    """Both inflate kernels (workgroup per block - with its commit fed from the counting passes' tokens, and decoding again as in
+    round 2 - / lane per block) go through every test of this file."""
     c = hipcall.Context(0)
-    c.set_option("inflate_algo", request.param)
+    c.set_option("inflate_algo", request.param[0])
+    c.set_option("inflate_tokens", request.param[1])
     yield c
     c.close()
 
