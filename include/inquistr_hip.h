@@ -174,8 +174,9 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * "verify_crc" = 0 skips the CRC32 check of the device front end (default 1);
  * "inflate_algo" = 0 inflates with one workgroup per BGZF block (no latency floor, 0.54-0.82 ms per 1000 blocks), 1 with one
  * lane per block (36-56 ms for up to ~65 000 blocks), 2 (default) = the quicker one, which is 0 at every size measured;
- * "inflate_tokens" = 1 (default): the workgroup inflate keeps the symbols its counting passes decode (32 KB of device scratch per
- * BGZF block) so that its commit step does not decode them again, 0 = it decodes again (round 2's form);
+ * "inflate_tokens" = 1: the workgroup inflate keeps the symbols its counting passes decode (32 KB of device scratch per BGZF
+ * block) so that its commit step does not decode them again; 0 (default) = it decodes again (the stores cost what the second
+ * decode did: +3 % on CIGAR-only blocks, -2 ... -5 % on sequence / quality bytes);
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);

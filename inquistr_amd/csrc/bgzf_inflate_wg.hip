@@ -53,12 +53,17 @@ namespace {
 #define INQ_WG_DISTBITS 8
 #endif
 constexpr int kLitBits = INQ_WG_LITBITS, kDistBits = INQ_WG_DISTBITS;
+#ifndef INQ_WG_LITPAIR
+#define INQ_WG_LITPAIR 1  // a literal behind a literal is decoded from the same peek
+#endif
+#ifndef INQ_WG_LITFIRST
+#define INQ_WG_LITFIRST 0
+#endif
 #ifndef INQ_WG_SEGBITS
 #define INQ_WG_SEGBITS 256
 #endif
 constexpr uint32_t kSegBits = INQ_WG_SEGBITS;  // compressed bits per lane and round (a multiple of 32, > the longest symbol's 48)
 constexpr int kMaxLit = 288, kMaxDist = 32;
-constexpr int kPosCap = 32;  // symbol starts of a lane's first chain kept in LDS for re-synchronisation
 
 constexpr uint32_t E_LIT = 0u, E_LEN = 1u, E_EOB = 2u, E_LONG = 3u;
 // table entry: bits 0-3 code length (0 = not a code), 4-5 type, 6 = everything the decode loop leaves its fast path for
@@ -114,9 +119,6 @@ struct WgLds {
             uint8_t cl_lut[128];  // 7 bits of the stream -> code-length symbol | code length << 5 (0 = not a code)
             uint8_t cl_len[20];
             uint8_t last_sh[T];  // header: the last code length a lane's symbols leave behind (kNoLast = all of them copy their predecessor)
-            // counting: where the first kPosCap symbols of a lane's FIRST chain start (bits behind its segment's first bit), [i][lane]:
-            // a lane that has to begin again further left or right decodes only until it meets that chain (fixup_segment)
-            uint8_t pos8[kPosCap][T];
         };
     };
     uint32_t off_sh[T + 1];  // per lane: first output byte of its chain, relative to the round's; [T] = the round's bytes
@@ -124,10 +126,7 @@ struct WgLds {
     // segment's second half with the bytes produced before it (position | bytes << 16, kNoMid = the chain ended before)
     uint16_t start_sh[T];
     uint32_t mid_sh[T];
-    // tokens of the segment's chain for the commit: how many (kTokOverflow: not usable, decode again), how many of them in front
-    // of mid, and how they are pieced together: the first ntpre from the lane's second token column (a prefix decoded again from
-    // the true start), the rest from the first column starting at its token jskip
-    uint8_t ntok_sh[T], midtok_sh[T], ntpre_sh[T], jskip_sh[T];
+    uint16_t ntok_sh[T], midtok_sh[T];  // tokens the segment's chain left behind (kTokOverflow: none usable), of which in front of mid
     uint16_t sorted[kMaxLit + kMaxDist];  // symbols by (code length, value): literal/length, then distance
     uint32_t limit[2][16], base[2][16];
     // block-uniform state
@@ -146,8 +145,7 @@ constexpr uint32_t kRootLit = 0xff00u;
 #endif
 constexpr uint32_t kTokCap = INQ_WG_TOKCAP;  // a segment with more symbols (256 bits of codes under 4 bits) is decoded again by the commit
 constexpr uint32_t kTokLit = 0x80000000u;
-constexpr uint32_t kTokOverflow = 0xffu;
-static_assert(2 * kTokCap < kTokOverflow, "a pieced-together chain (a prefix + the rest of the first chain) is counted in a byte");
+constexpr uint32_t kTokOverflow = 0xffffu;
 constexpr uint32_t kNoMid = 0xffffffffu;
 constexpr uint32_t kStopped = 0x80000000u;  // in end_bit: the chain met EOB or a pattern that is no code
 constexpr uint32_t kStopEob = 0x40000000u;  // ... and it was EOB
@@ -317,9 +315,16 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
     }
     while (b.pos < lim) {
         const uint32_t bits = b.peek();
-        const uint32_t p0 = b.pos;
         uint32_t e = L.lut_ll[bits & ((1u << kLitBits) - 1u)];
+#if INQ_WG_LITFIRST
+        // a plain literal - the table's most frequent answer in sequence / quality bytes - is recognised by ONE test; everything
+        // else (a length, or one of the three rare cases behind kSpecial) takes the second
+        bool lit = !(e & (kSpecial | (E_LEN << 4)));
+        if (!lit && (e & kSpecial)) {
+#else
+        bool lit;
         if (e & kSpecial) {  // one test keeps the three rare cases out of the loop's fast path
+#endif
             if (e == kLongEntry) e = canon_entry<T>(L, 0, __brev(bits) >> 17, kLitBits + 1);
             if (e & kSpecial) {
                 if (e & 15u) {  // end of block (a code has a length; "not a code" has none)
@@ -328,20 +333,59 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
                 } else stop = kStopped;
                 break;
             }
+#if INQ_WG_LITFIRST
+            lit = !(e & (E_LEN << 4));
+#endif
         }
+#if !INQ_WG_LITFIRST
+        lit = !(e & (E_LEN << 4));
+#endif
         const uint32_t n = e & 15u, xb = (e >> 8) & 15u;  // a literal has no extra bits
+#if INQ_WG_LITPAIR
+        if (lit) {
+            // a literal: look at the symbol behind it in the bits already peeked (>= 32 - 15 of them are left) - when that is a
+            // plain literal too (the common case in base-quality and sequence bytes, what a BAM mostly is) and starts in front of
+            // the limit, both go out with one move of the cursor and one turn of the loop.  Measured (20 000 blocks, zlib level
+            // 1 / 6): quality-like bytes 17.4 -> 13.5 / 16.1 -> 12.2 ms, nanopore-like 14.0 -> 12.1 / 13.8 -> 11.3, packed bases
+            // 11.9 -> 10.9 / 11.2 -> 10.8, CIGAR-only blocks 11.4 -> 11.95 / 8.1 -> 8.15 (the look is wasted when a match
+            // follows).  A third literal from the same peek and a "only behind a literal" predictor both lost
+            // (profiles/r03_results/inflate_literal_runs_five_builds.txt).
+            const uint32_t e2 = L.lut_ll[(bits >> n) & ((1u << kLitBits) - 1u)];
+            const bool two = !(e2 & (kSpecial | (E_LEN << 4))) && b.pos + n < lim;
+            b.consume(n + (two ? (e2 & 15u) : 0u));
+            if (MODE == 2) {
+                out[o + nb] = (uint8_t)(e >> 16);
+                if (two) out[o + nb + 1u] = (uint8_t)(e2 >> 16);
+            }
+            if (MODE == 1) {  // the bytes themselves: stored by the gather, coalesced
+                L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));
+                if (two) L.root[o + nb + 1u - r0] = (uint16_t)(kRootLit | (e2 >> 16));
+            }
+            if (MODE == 0 && tok) {
+                if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
+                ++nt;
+                if (two) {
+                    if (nt < kTokCap) tok[nt * T] = kTokLit | (e2 >> 16);
+                    ++nt;
+                }
+            }
+            nb += two ? 2u : 1u;
+            continue;
+        }
         b.consume(n + xb);
-        if (!(e & (E_LEN << 4))) {
+#else
+        b.consume(n + xb);
+        if (lit) {
             if (MODE == 2) out[o + nb] = (uint8_t)(e >> 16);
             if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));  // the byte itself: stored by the gather, coalesced
             if (MODE == 0 && tok) {
                 if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
-                if (nt < (uint32_t)kPosCap) L.pos8[nt][threadIdx.x] = (uint8_t)(p0 - (seg_end - kSegBits));
                 ++nt;
             }
             ++nb;
             continue;
         }
+#endif
         const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(bits, n, xb);
         const uint32_t dbits = b.peek();
         uint32_t d = L.lut_d[dbits & ((1u << kDistBits) - 1u)];
@@ -358,7 +402,6 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
         b.consume(dn + dxb);
         if (MODE == 0 && tok) {
             if (nt < kTokCap) tok[nt * T] = (len << 16) | (dist - 1u);
-            if (nt < (uint32_t)kPosCap) L.pos8[nt][threadIdx.x] = (uint8_t)(p0 - (seg_end - kSegBits));
             ++nt;
         }
         if (MODE) {
@@ -381,128 +424,27 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
     return b.pos | stop;
 }
 
-// A lane whose chain has to begin somewhere else than it did (its left neighbour's chain ended at `from`) does NOT decode its
-// segment again: a Huffman decoder started at a different bit falls in step with the old chain after a few symbols, and from
-// there on the old chain's symbols - counted, and kept as tokens - are the true ones.  This walks from `from`, symbol by symbol,
-// next to the starts of the lane's FIRST chain (L.pos8, ascending) until both stand on the same bit, leaving the symbols of the
-// prefix in the lane's second token column (tokB).  Out: nt_pre / nb_pre = tokens and bytes of the prefix, j = tokens of the first
-// chain in front of the meeting point (none of them is true), synced = the chains met (else the walk ran to the segment's end
-// by itself: j = all, the returned value is the new end | stop flags), and the walk's own entry into the segment's second half
-// (mid / mid_tok; kNoMid if it met the old chain before).  first: {ntok1, end1} of the first chain.
+// The commit of a job from its tokens: no Huffman decode, no bit cursor.  tok = the segment's token column, tokens [i0, i1);
+// the job's bytes start at output position o (the round's first byte at r0 is the stretch's origin) and are `nbytes` long.
 template <int T>
-__device__ __forceinline__ uint32_t fixup_segment(WgLds<T> &L, uint32_t from, uint32_t seg_end, uint32_t ntok1, uint32_t end1, uint32_t *tokB,
-                                                  uint32_t &nt_pre, uint32_t &nb_pre, uint32_t &j, bool &synced, uint32_t &mid, uint32_t &mid_tok,
-                                                  uint32_t &bad) {
-    const uint32_t seg_lo = seg_end - kSegBits, half = seg_end - kSegBits / 2u;
-    const uint32_t tid = threadIdx.x;
-    constexpr uint32_t kNever = 0xffffffffu;
-    SegBits b;
-    b.init(L.stage, from);
-    uint32_t nt = 0, nb = 0, ja = 0, stop = 0;
-    const uint32_t n_known = ntok1 < (uint32_t)kPosCap ? ntok1 : (uint32_t)kPosCap;
-    // where the first chain stands after its last symbol, if all its starts are known and it did not stop there
-    const uint32_t a_tail = (ntok1 <= (uint32_t)kPosCap && !(end1 & kStopped)) ? (end1 & 0x3fffffffu) : kNever;
-    uint32_t a_pos = n_known ? seg_lo + L.pos8[0][tid] : a_tail;
-    synced = false;
-    mid = kNoMid;
-    mid_tok = 0;
-    for (;;) {
-        if (a_pos < b.pos) {  // the first chain is behind: its next start
-            ++ja;
-            a_pos = ja < n_known ? seg_lo + L.pos8[ja][tid] : (ja == ntok1 ? a_tail : kNever);
-            continue;
-        }
-        if (mid == kNoMid && b.pos >= half) mid = b.pos | (nb << 16), mid_tok = nt;
-        if (a_pos == b.pos) {
-            synced = true;
-            break;
-        }
-        if (b.pos >= seg_end) break;
-        // one symbol, as decode_segment<T, 0> reads it
-        const uint32_t bits = b.peek();
-        uint32_t e = L.lut_ll[bits & ((1u << kLitBits) - 1u)];
-        if (e & kSpecial) {
-            if (e == kLongEntry) e = canon_entry<T>(L, 0, __brev(bits) >> 17, kLitBits + 1);
-            if (e & kSpecial) {
-                if (e & 15u) {
-                    b.consume(e & 15u);
-                    stop = kStopped | kStopEob;
-                } else stop = kStopped;
-                break;
-            }
-        }
-        const uint32_t n = e & 15u, xb = (e >> 8) & 15u;
-        b.consume(n + xb);
-        if (!(e & (E_LEN << 4))) {
-            if (nt < kTokCap) tokB[nt * T] = kTokLit | (e >> 16);
-            ++nt;
-            ++nb;
-            continue;
-        }
-        const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(bits, n, xb);
-        const uint32_t dbits = b.peek();
-        uint32_t d = L.lut_d[dbits & ((1u << kDistBits) - 1u)];
-        if (d & kSpecial) {
-            if (d == kLongEntry) d = canon_entry<T>(L, 1, __brev(dbits) >> 17, kDistBits + 1);
-            if (d & kSpecial) {
-                stop = kStopped;
-                break;
-            }
-        }
-        const uint32_t dn = d & 15u, dxb = (d >> 8) & 15u;
-        const uint32_t dist = (d >> 16) + __builtin_amdgcn_ubfe(dbits, dn, dxb);
-        b.consume(dn + dxb);
-        if (nt < kTokCap) tokB[nt * T] = (len << 16) | (dist - 1u);
-        ++nt;
-        nb += len;
-    }
-    (void)bad;
-    nt_pre = nt;
-    nb_pre = nb;
-    j = synced ? ja : ntok1;
-    return b.pos | stop;
-}
-
-// bytes the first j tokens of a column stand for
-template <int T>
-__device__ __forceinline__ uint32_t token_bytes(const uint32_t *tok, uint32_t j) {
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < j; ++i) {
-        const uint32_t t = tok[i * T];
-        sum += (t & kTokLit) ? 1u : (t >> 16);
-    }
-    return sum;
-}
-
-// The commit of a job from its tokens: no Huffman decode, no bit cursor.  The chain's tokens are pieced together from the
-// segment's two columns: the first nt_pre from tokB, token i >= nt_pre from tokA[i - nt_pre + jskip]; the job takes [i0, i1) of
-// them.  Its bytes start at output position o (the round's first byte at r0 is the stretch's origin) and are `nbytes` long.
-template <int T>
-__device__ __forceinline__ void commit_tokens(WgLds<T> &L, const uint32_t *tokA, const uint32_t *tokB, uint32_t nt_pre, uint32_t jskip, uint32_t i0,
-                                              uint32_t i1, uint32_t o, uint32_t r0, uint32_t nbytes, uint32_t &bad) {
+__device__ __forceinline__ void commit_tokens(WgLds<T> &L, const uint32_t *tok, uint32_t i0, uint32_t i1, uint32_t o, uint32_t r0, uint32_t nbytes,
+                                              uint32_t &bad) {
     const uint32_t own = o - r0, lane_end = own + nbytes;
     uint32_t p = own;
     // four tokens in flight ahead of the one being written out (the loads are independent of everything the loop computes)
     uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    auto fetch = [&](uint32_t i) -> uint32_t {
-        const uint32_t k = i < i1 ? i : i1 - 1u;
-        return k < nt_pre ? tokB[k * T] : tokA[(k - nt_pre + jskip) * T];
-    };
+    auto fetch = [&](uint32_t i) -> uint32_t { return tok[(i < i1 ? i : i1 - 1u) * T]; };
     if (i0 < i1) q0 = fetch(i0), q1 = fetch(i0 + 1u), q2 = fetch(i0 + 2u), q3 = fetch(i0 + 3u);
     for (uint32_t i = i0; i < i1; ++i) {
         const uint32_t t = q0;
         q0 = q1, q1 = q2, q2 = q3, q3 = fetch(i + 4u);
         if (t & kTokLit) {
-            if (p >= lane_end) {
-                bad |= INQ_INFLATE_BAD_DISTANCE;
-                break;
-            }
             L.root[p] = (uint16_t)(kRootLit | (t & 0xffu));
             ++p;
             continue;
         }
         const uint32_t len = t >> 16, dist = (t & 0xffffu) + 1u;
-        if (dist > r0 + p || p + len > lane_end) {  // (a token is what this kernel wrote; the second test only keeps LDS writes inside the job whatever the scratch holds)
+        if (dist > o - own + p || p + len > lane_end) {  // (o - own = r0: the bytes in front of the stretch; a token is what this kernel wrote, the second test only keeps LDS writes inside the job)
             bad |= INQ_INFLATE_BAD_DISTANCE;
             break;
         }
@@ -915,14 +857,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             const uint32_t seg_end = ((uint32_t)tid + 1u) * kSegBits;
             uint32_t start = tid == 0 ? (P & 31u) : (uint32_t)tid * kSegBits;
             uint32_t nbytes = 0, bad = 0, mid = kNoMid, ntok = 0, mid_tok = 0;
-            // the segment's two token columns: A = the symbols of the lane's first chain, B = a prefix decoded again (fixup_segment)
-            uint32_t *const tok = a.tokens ? a.tokens + (bi * 2u * kTokCap) * (uint64_t)T + (uint32_t)tid : nullptr;
-            uint32_t *const tokB = tok ? tok + (uint64_t)kTokCap * T : nullptr;
+            uint32_t *const tok = a.tokens ? a.tokens + (bi * kTokCap) * (uint64_t)T + (uint32_t)tid : nullptr;
             uint32_t end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
-            // the first chain, kept: later starts are pieced together from it
-            const uint32_t end1 = end, nbytes1 = nbytes, ntok1 = ntok, mid1 = mid, midtok1 = mid_tok;
-            uint32_t nt_pre = 0, jskip = 0;
-            bool tok_ok = tok != nullptr && ntok1 <= kTokCap;
             DBG_N(1);
             DBG_N(2);
             // ---- until every chain starts where its left neighbour's ended (lanes behind the first stop do not matter)
@@ -942,34 +878,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 }
                 if (mismatch) {
                     start = left & 0x3fffffffu;
-                    if (tok) {
-                        // only as far as the first chain: from where the two meet, its count and its tokens stand
-                        uint32_t nb_pre, fmid, fmid_tok;
-                        bool synced;
-                        const uint32_t fend = fixup_segment<T>(L, start, seg_end, ntok1, end1, tokB, nt_pre, nb_pre, jskip, synced, fmid, fmid_tok, bad);
-                        if (synced) {
-                            const bool usable = ntok1 <= kTokCap;  // (all of the first chain's tokens are there)
-                            const uint32_t skipped = token_bytes<T>(tok, jskip < kTokCap ? jskip : kTokCap);
-                            end = end1;
-                            nbytes = nb_pre + nbytes1 - (usable ? skipped : 0u);
-                            ntok = nt_pre + ntok1 - jskip;
-                            if (fmid != kNoMid) mid = fmid, mid_tok = fmid_tok;  // the walk entered the second half by itself
-                            else if (mid1 != kNoMid) mid = (mid1 & 0xffffu) | ((nb_pre + (mid1 >> 16) - skipped) << 16), mid_tok = nt_pre + midtok1 - jskip;
-                            else mid = kNoMid, mid_tok = 0;
-                            tok_ok = usable && nt_pre <= kTokCap;
-                            if (!usable) {  // more symbols than the column holds: the bytes in front of the meeting point are not known - count again
-                                end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, nullptr, nullptr, nullptr);
-                            }
-                        } else {
-                            end = fend;
-                            nbytes = nb_pre;
-                            ntok = nt_pre;
-                            mid = fmid, mid_tok = fmid_tok;
-                            tok_ok = nt_pre <= kTokCap;
-                        }
-                    } else {
-                        end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, nullptr, nullptr, nullptr);
-                    }
+                    end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
                 }
                 DBG_N(2);
                 __syncthreads();  // end_bit[] read by everyone before it is rewritten
@@ -981,10 +890,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             L.off_sh[tid] = off_b;
             L.start_sh[tid] = (uint16_t)start;
             L.mid_sh[tid] = mid;
-            L.ntok_sh[tid] = (uint8_t)(tok_ok ? ntok : kTokOverflow);
-            L.midtok_sh[tid] = (uint8_t)mid_tok;
-            L.ntpre_sh[tid] = (uint8_t)nt_pre;
-            L.jskip_sh[tid] = (uint8_t)jskip;
+            L.ntok_sh[tid] = (uint16_t)(tok && ntok <= kTokCap ? ntok : kTokOverflow);
+            L.midtok_sh[tid] = (uint16_t)mid_tok;
             if (tid == 0) L.off_sh[T] = tot_b;
             if (tid == (int)ncommit - 1) {  // the last chain of the round: where the next round starts, and why this one ended
                 const uint32_t stop = end & (kStopped | kStopEob);
@@ -1034,8 +941,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                         if (nt_seg != kTokOverflow) {  // the symbols are there already: write their roots
                             const uint32_t mt = L.midtok_sh[seg];
                             const uint32_t i0 = (m != kNoMid && second) ? mt : 0u, i1 = (m != kNoMid && !second) ? mt : nt_seg;
-                            const uint32_t *colA = a.tokens + (bi * 2u * kTokCap) * (uint64_t)T + seg;
-                            commit_tokens<T>(L, colA, colA + (uint64_t)kTokCap * T, L.ntpre_sh[seg], L.jskip_sh[seg], i0, i1, out0 + jo, r0, jn, cbad);
+                            commit_tokens<T>(L, a.tokens + (bi * kTokCap) * (uint64_t)T + seg, i0, i1, out0 + jo, r0, jn, cbad);
                             continue;
                         }
                         uint32_t nb2 = jn;
@@ -1152,7 +1058,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
 #ifndef INQ_WG_T
 #define INQ_WG_T 128
 #endif
-uint64_t inflate_token_words(uint64_t n_blocks) { return n_blocks * 2ull * kTokCap * INQ_WG_T; }  // two columns per segment
+uint64_t inflate_token_words(uint64_t n_blocks) { return n_blocks * (uint64_t)kTokCap * INQ_WG_T; }
 
 void launch_bgzf_inflate_wg(const InflateArgs &a, hipStream_t s) {
     if (!a.n_blocks) return;

@@ -40,7 +40,9 @@ struct inq_ctx {
     int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
     bool timing = false;
     bool verify_crc = true;  // device front end: check inflated blocks against their CRC32
-    bool inflate_tokens = true;  // workgroup inflate: the counting passes leave the symbols behind for the commit (option "inflate_tokens")
+    // workgroup inflate: the counting passes leave the symbols behind for the commit (option "inflate_tokens").  Off: measured
+    // +3 % on CIGAR-only blocks, -2 ... -5 % on sequence / quality bytes, what a real BAM mostly is (profiles/r03_results/)
+    bool inflate_tokens = false;
     uint32_t inflate_algo = 2;  // 0 = workgroup per BGZF block, 1 = lane per block, 2 = the quicker one (0 since round 2)
     std::vector<inq::EvTriple> ev_pool;
     size_t ev_used = 0;

@@ -730,7 +730,8 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
         SpanPipeline &pipe = *holder.p;
         bool joined = false;
         // loci whose batches wait on the device (inq_call_span_deferred), in the order they were appended
-        constexpr size_t kFlushLoci = 100000;           // a launch of the locus kernels reaches its full rate from here on (0.70 of peak at 53 000 loci in the CLI's trace)
+        // a launch of the locus kernels reaches its full rate at ~10^5 loci (0.70 of peak at 53 000 loci in the CLI's trace)
+        const size_t kFlushLoci = std::getenv("INQ_FLUSH_LOCI") ? (size_t)std::max(1l, std::atol(std::getenv("INQ_FLUSH_LOCI"))) : 100000;
         constexpr uint64_t kFlushWords = 1ull << 31;    // ... or 8 GB of gathered CIGARs
         std::vector<uint32_t> pending;
         uint64_t pending_words = 0;

@@ -127,3 +127,34 @@ def test_whole_command_fails_loudly_without_gpu(tmp_path, frontend):
         call.genotype_repeats(bam, None, bed, 5, 3, 2, False, None, None, out=f, frontend=frontend)
     assert e.value.status == 1 and "no CPU fallback" in e.value.message
     assert (tmp_path / "o.inq").read_text() == ""
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_session_and_run_fail_loudly_without_gpu(tmp_path):
+    """The round-3 entries (many BAMs on one context: inq_session_*; a prepared run: inq_run_rows) have no CPU path either: every
+    file of a cohort ends with status 1, nothing is written; the parts that need no GPU (split, output stage) still work."""
+    from inquistr_amd import call
+    from tests.test_host_frontend import _make_case
+
+    bam, bed, loci, recs = _make_case(tmp_path, 4, n_loci=12)
+    outs = [open(tmp_path / f"s{k}.inq", "w") for k in range(3)]
+    with call.Session(0) as S:
+        st = S.call_many([bam, str(tmp_path / "missing.bam"), bam], outs, region_file=bed, threads=2)
+        assert st == [1, 1, 1] and "no CPU fallback" in S.last_message
+        with pytest.raises(call.CallError) as e, open(tmp_path / "one.inq", "w") as f:
+            S.call(bam, region_file=bed, out=f)
+        assert e.value.status == 1
+    for o in outs:
+        o.close()
+    assert all((tmp_path / f"s{k}.inq").read_text() == "" for k in range(3))
+    run = call.Run(bam, None, bed, threads=2, sample_name="S")
+    order, cuts = run.partition(3)
+    assert sorted(order.tolist()) == list(range(run.n_targets)) and cuts[0] == 0 and cuts[-1] == run.n_targets
+    with pytest.raises(call.CallError) as e:
+        run.rows(order[:4])
+    assert e.value.status == 1
+    with open(tmp_path / "rows.inq", "w") as f:  # the output stage alone: NaN rows in -t 2 order
+        run.write_inq(np.full(run.n_targets, np.nan), np.full(run.n_targets, np.nan), f)
+    text = (tmp_path / "rows.inq").read_text().splitlines()
+    assert text[0] == "chromosome\tbegin\tend\tS_H1\tS_H2" and len(text) == run.n_targets + 1 and text[1].endswith("\tNaN\tNaN")
+    run.close()
