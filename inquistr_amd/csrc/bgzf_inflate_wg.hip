@@ -57,7 +57,7 @@ constexpr int kLitBits = INQ_WG_LITBITS, kDistBits = INQ_WG_DISTBITS;
 #define INQ_WG_LITPAIR 1  // a literal behind a literal is decoded from the same peek
 #endif
 #ifndef INQ_WG_LITFIRST
-#define INQ_WG_LITFIRST 0
+#define INQ_WG_LITFIRST 1
 #endif
 #ifndef INQ_WG_SEGBITS
 #define INQ_WG_SEGBITS 256

@@ -2,6 +2,7 @@
 // plus the C ABI of include/inquistr_host.h.
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -259,6 +260,37 @@ private:
     std::string err_;
 };
 
+// The NUMA node the GPU's PCIe slot hangs off, found without the HIP runtime (the first span buffers are filled while it still
+// starts): the device-th render node this process may open.  A span buffer is read by the GPU's DMA engine; on the two-socket
+// hosts measured an upload from the other socket's memory takes 5.6 - 5.9 ms per 268 MB instead of 4.9 ms, which is the
+// difference between an upload-bound and a device-bound span loop on SEQ-bearing files (profiles/r03_results/loader_numa_binding.txt).
+// INQ_NUMA_NODE=n overrides, -1 switches the placement off.
+static int gpu_numa_node(int device) {
+    if (const char *e = std::getenv("INQ_NUMA_NODE")) return std::atoi(e);
+    int seen = 0;
+    for (int minor = 128; minor < 128 + 64; ++minor) {
+        char dev[64], path[128];
+        std::snprintf(dev, sizeof dev, "/dev/dri/renderD%d", minor);
+        if (::access(dev, R_OK | W_OK) != 0) continue;
+        if (seen++ != device) continue;
+        std::snprintf(path, sizeof path, "/sys/class/drm/renderD%d/device/numa_node", minor);
+        FILE *f = std::fopen(path, "r");
+        if (!f) return -1;
+        int node = -1;
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+        return node;
+    }
+    return -1;
+}
+
+static void prefer_numa_node(void *p, size_t len, int node) {
+    if (node < 0 || node >= 1024) return;
+    unsigned long mask[16] = {0};
+    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+    (void)::syscall(SYS_mbind, p, len, 1 /* MPOL_PREFERRED */, mask, sizeof mask * 8, 0);  // best effort: placement only
+}
+
 // Span buffers that outlive one file: a cohort run (inq_session) hands the buffers of file k to file k + 2 instead of unmapping
 // and re-faulting a GB of pages per file.
 struct HostBufPool {
@@ -313,9 +345,9 @@ public:
     // and go back to (may be null: mapped and unmapped by the pipeline)
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
                  uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr,
-                 std::function<void()> gate = nullptr)
+                 std::function<void()> gate = nullptr, int numa_node = -1)
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
-          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)) {
+          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), numa_node_(numa_node) {
         for (int i = 0; i < 3; ++i) slots_[i].slot = slot_base + i;
         for (auto &it : slots_) free_.push_back(&it);
         th_ = std::thread([this] { run(); });
@@ -395,7 +427,10 @@ private:
             const size_t len = (want + huge - 1) / huge * huge;
             p = ::mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (p == MAP_FAILED) p = nullptr;
-            else (void)::madvise(p, len, MADV_HUGEPAGE);
+            else {
+                (void)::madvise(p, len, MADV_HUGEPAGE);
+                prefer_numa_node(p, len, numa_node_);
+            }
             it.pinned = false;
             it.buf = (uint8_t *)p;
             it.cap = p ? len : 0;
@@ -507,6 +542,7 @@ private:
     StageFn stage_;
     HostBufPool *pool_ = nullptr;
     std::function<void()> gate_;
+    int numa_node_ = -1;
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[3];
     std::vector<Item *> free_;
@@ -699,7 +735,8 @@ static SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamF
     // overlaps the inflate of span k
     return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
                             [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; },
-                            slot_base, pool, std::getenv("INQ_GATE_READS") ? std::function<void()>([&actx] { (void)actx.wait(); }) : std::function<void()>());
+                            slot_base, pool, std::getenv("INQ_GATE_READS") ? std::function<void()>([&actx] { (void)actx.wait(); }) : std::function<void()>(),
+                            gpu_numa_node(args->device));
 }
 
 static int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,
@@ -730,8 +767,10 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
         SpanPipeline &pipe = *holder.p;
         bool joined = false;
         // loci whose batches wait on the device (inq_call_span_deferred), in the order they were appended
-        // a launch of the locus kernels reaches its full rate at ~10^5 loci (0.70 of peak at 53 000 loci in the CLI's trace)
-        const size_t kFlushLoci = std::getenv("INQ_FLUSH_LOCI") ? (size_t)std::max(1l, std::atol(std::getenv("INQ_FLUSH_LOCI"))) : 100000;
+        // 50 000 loci per launch of the locus kernels: 0.69 of the HBM peak in the CLI's trace (53 500 loci, 240 us), 0.73 at
+        // 107 000 (452 us) against 0.83 for the same kernel in bench.py's steady loop - a launch here comes cold behind the
+        // gather that has just written its CIGARs - and twice the device memory to tear down at exit for 100 000
+        const size_t kFlushLoci = std::getenv("INQ_FLUSH_LOCI") ? (size_t)std::max(1l, std::atol(std::getenv("INQ_FLUSH_LOCI"))) : 50000;
         constexpr uint64_t kFlushWords = 1ull << 31;    // ... or 8 GB of gathered CIGARs
         std::vector<uint32_t> pending;
         uint64_t pending_words = 0;

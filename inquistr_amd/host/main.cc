@@ -11,39 +11,6 @@
 
 #include "../../include/inquistr_host.h"
 
-#include <sched.h>
-#include <sys/syscall.h>
-
-// INQ_NUMA_NODE=n (experiment knob): run on the CPUs of NUMA node n and take memory from it - the span buffers the loader fills
-// are read by the GPU's DMA engine over PCIe, which hangs off one socket.
-static void bind_numa_from_env() {
-    const char *e = std::getenv("INQ_NUMA_NODE");
-    if (!e || !*e) return;
-    const int node = std::atoi(e);
-    char path[128];
-    std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-    FILE *f = std::fopen(path, "r");
-    if (!f) return;
-    char buf[4096] = {0};
-    if (!std::fgets(buf, sizeof buf, f)) buf[0] = 0;
-    std::fclose(f);
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    for (char *p = buf; *p;) {  // "0-63,128-191"
-        char *q;
-        long a = std::strtol(p, &q, 10), b = a;
-        if (q == p) break;
-        if (*q == '-') b = std::strtol(q + 1, &q, 10);
-        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, &set);
-        p = (*q == ',') ? q + 1 : q;
-        if (*q != ',') break;
-    }
-    (void)sched_setaffinity(0, sizeof set, &set);
-    unsigned long mask[16] = {0};
-    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-    (void)syscall(SYS_set_mempolicy, 2 /* MPOL_BIND */, mask, sizeof mask * 8);
-}
-
 static void usage(FILE *f) {
     std::fputs(
         "Call lengths\n\nUsage: inquistr call [OPTIONS] <BAM>\n\nArguments:\n  <BAM>  bam file to call STRs in\n\nOptions:\n"
@@ -61,7 +28,6 @@ static void usage(FILE *f) {
 }
 
 int main(int argc, char **argv) {
-    bind_numa_from_env();
     if (argc >= 2 && std::strcmp(argv[1], "combine") == 0) {  // src/main.rs:65-71: one or more .inq files
         if (argc < 3) {
             std::fputs("error: the following required arguments were not provided:\n  <CALLS>...\n\nUsage: inquistr combine <CALLS>...\n", stderr);
