@@ -188,10 +188,17 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
             t1 = statistics.median(run(co + links[:1], env_d)[0] for _ in range(3))
             tn = statistics.median(run(co + links, env_d)[0] for _ in range(3))
             per = max((tn - t1) / (n_co - 1), 1e-9)
+            # the library's own clock between two files of the cohort (stderr of one more run): what a file costs once the
+            # context is there, without the process's start and its exit (tearing down GBs of mappings: tenths of a second)
+            r = subprocess.run(co + links, capture_output=True, env=dict(env_d, INQ_TIMING="1"))
+            import re as _re
+
+            inner = [float(x) for x in _re.findall(r"\[inq session\].*?([\d.]+) ms since the previous file finished", r.stderr.decode())]
             body = out_dev.split(b"\n", 1)[1]
             same = all(open(os.path.join(outdir, os.path.basename(ln)[: -len(".bam")] + ".inq"), "rb").read().split(b"\n", 1)[1] == body for ln in links)
             res["cohort"] = {"files": n_co, "seconds_1_file": t1, "seconds_n_files": tn, "seconds_per_added_file": per,
                              "loci_per_s_per_added_file": loci / per, "speedup_vs_B_per_added_file": (loci / per) / res["cpu_B"]["loci_per_s"],
+                             "ms_per_file_inside_the_session": inner[1:], "loci_per_s_inside_the_session": (loci / (statistics.median(inner[1:]) / 1e3)) if len(inner) > 1 else None,
                              "rows_identical_to_single_calls": bool(same),
                              "note": "inquistr cohort (many calls in one process, one device context); medians of 3 whole-process wall times; the files are hard links of the one BAM (every program here reads from the page cache)"}
         except Exception as e:  # noqa: BLE001

@@ -308,6 +308,9 @@ const char *inq_strerror(int code);
 const char *inq_backend_name(const inq_ctx_t *ctx); /* "hip:gfx950:<device name>" */
 const char *inq_last_error(const inq_ctx_t *ctx);   /* detail of the last INQ_ERR_HIP */
 int inq_abi_version(void);
+/* NUMA node of the host the context's GPU hangs off (its PCI address through sysfs), -1 if unknown: a host buffer the GPU's
+ * copy engine reads is best placed there (268 MB from the other socket: 5.6 - 6.1 ms instead of 4.9 ms on the boxes measured). */
+int inq_ctx_numa_node(const inq_ctx_t *ctx);
 
 #ifdef __cplusplus
 }

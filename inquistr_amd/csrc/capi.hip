@@ -143,6 +143,22 @@ void inq_ctx_destroy(inq_ctx_t *c) {
     delete c;
 }
 
+int inq_ctx_numa_node(const inq_ctx_t *c) {
+    if (!c) return -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) != hipSuccess) return -1;
+    for (char *q = bus; *q; ++q)
+        if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');  // sysfs spells the address in lower case
+    char path[160];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+    return node;
+}
+
 const char *inq_backend_name(const inq_ctx_t *c) { return c ? c->backend.c_str() : "none"; }
 const char *inq_last_error(const inq_ctx_t *c) { return c ? c->last_err.c_str() : ""; }
 

@@ -45,6 +45,7 @@ ABI_SYMBOLS = (
     "inq_backend_name",
     "inq_last_error",
     "inq_abi_version",
+    "inq_ctx_numa_node",
     "inq_bgzf_inflate",
     "inq_call_span",
     "inq_span_stage",
@@ -201,6 +202,8 @@ def load(path: Optional[str] = None):
     L.inq_last_error.argtypes = [vp]
     L.inq_abi_version.restype = C.c_int
     L.inq_abi_version.argtypes = []
+    L.inq_ctx_numa_node.restype = C.c_int
+    L.inq_ctx_numa_node.argtypes = [vp]
     L.inq_bgzf_inflate.restype = C.c_int
     L.inq_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp]
     L.inq_call_span.restype = C.c_int

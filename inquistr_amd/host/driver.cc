@@ -260,29 +260,12 @@ private:
     std::string err_;
 };
 
-// The NUMA node the GPU's PCIe slot hangs off, found without the HIP runtime (the first span buffers are filled while it still
-// starts): the device-th render node this process may open.  A span buffer is read by the GPU's DMA engine; on the two-socket
-// hosts measured an upload from the other socket's memory takes 5.6 - 5.9 ms per 268 MB instead of 4.9 ms, which is the
-// difference between an upload-bound and a device-bound span loop on SEQ-bearing files (profiles/r03_results/loader_numa_binding.txt).
-// INQ_NUMA_NODE=n overrides, -1 switches the placement off.
-static int gpu_numa_node(int device) {
-    if (const char *e = std::getenv("INQ_NUMA_NODE")) return std::atoi(e);
-    int seen = 0;
-    for (int minor = 128; minor < 128 + 64; ++minor) {
-        char dev[64], path[128];
-        std::snprintf(dev, sizeof dev, "/dev/dri/renderD%d", minor);
-        if (::access(dev, R_OK | W_OK) != 0) continue;
-        if (seen++ != device) continue;
-        std::snprintf(path, sizeof path, "/sys/class/drm/renderD%d/device/numa_node", minor);
-        FILE *f = std::fopen(path, "r");
-        if (!f) return -1;
-        int node = -1;
-        if (std::fscanf(f, "%d", &node) != 1) node = -1;
-        std::fclose(f);
-        return node;
-    }
-    return -1;
-}
+// A span buffer is read by the GPU's DMA engine; on the two-socket hosts measured an upload from the other socket's memory takes
+// 5.6 - 6.1 ms per 268 MB instead of 4.9 ms, which is the difference between an upload-bound and a device-bound span loop on
+// SEQ-bearing files (profiles/r03_results/loader_numa_binding.txt).  The node is the context's (inq_ctx_numa_node: the device's
+// PCI address through sysfs), known once the runtime is up; buffers mapped before that are mapped again when their slot comes
+// round.  INQ_NUMA_NODE=n overrides, -1 switches the placement off.
+constexpr int kNumaUnknown = -2;
 
 static void prefer_numa_node(void *p, size_t len, int node) {
     if (node < 0 || node >= 1024) return;
@@ -298,6 +281,7 @@ struct HostBufPool {
         uint8_t *p = nullptr;
         size_t cap = 0;
         bool pinned = false;
+        int node = -1;  // NUMA node the mapping prefers, -1 = none
     };
     std::mutex mu;
     std::vector<B> free_list;
@@ -335,6 +319,7 @@ public:
         uint8_t *buf = nullptr;
         size_t cap = 0;
         bool pinned = false;
+        int node = -1;       // NUMA node the buffer was mapped for
         int slot = 0;        // index of this item: also its device-side staging slot
         bool staged = false; // the loader already uploaded it (inq_span_stage)
     };
@@ -345,9 +330,9 @@ public:
     // and go back to (may be null: mapped and unmapped by the pipeline)
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
                  uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr,
-                 std::function<void()> gate = nullptr, int numa_node = -1)
+                 std::function<void()> gate = nullptr, std::function<int()> numa_query = nullptr)
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
-          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), numa_node_(numa_node) {
+          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), numa_query_(std::move(numa_query)) {
         for (int i = 0; i < 3; ++i) slots_[i].slot = slot_base + i;
         for (auto &it : slots_) free_.push_back(&it);
         th_ = std::thread([this] { run(); });
@@ -402,7 +387,7 @@ public:
 private:
     void release_buf(Item &it) {
         if (it.buf) {
-            if (pool_) pool_->give(HostBufPool::B{it.buf, it.cap, it.pinned});
+            if (pool_ && (it.pinned || it.node >= 0 || !numa_query_ || numa_query_() < 0)) pool_->give(HostBufPool::B{it.buf, it.cap, it.pinned, it.node});
             else if (it.pinned) inq_free_pinned(it.buf);
             else ::munmap(it.buf, it.cap);
         }
@@ -410,12 +395,16 @@ private:
         it.cap = 0;
     }
     bool fit(Item &it, size_t bytes) {
+        const int node = numa_query_ ? numa_query_() : -1;
+        // a buffer mapped before the GPU's node was known is given up for one on that node (the slot has been uploaded by now)
+        if (it.buf && !it.pinned && node >= 0 && it.node != node) release_buf(it);
         if (bytes <= it.cap && it.buf) return true;
         release_buf(it);
         HostBufPool::B got;
         if (pool_ && pool_->take(bytes, pinned_, &got)) {
-            it.buf = got.p, it.cap = got.cap, it.pinned = got.pinned;
-            return true;
+            it.buf = got.p, it.cap = got.cap, it.pinned = got.pinned, it.node = got.node;
+            if (!(node >= 0 && !it.pinned && it.node != node)) return true;
+            release_buf(it);  // from before the node was known: not taken
         }
         const size_t want = bytes + bytes / 4 + (1u << 20);
         void *p = nullptr;
@@ -429,7 +418,8 @@ private:
             if (p == MAP_FAILED) p = nullptr;
             else {
                 (void)::madvise(p, len, MADV_HUGEPAGE);
-                prefer_numa_node(p, len, numa_node_);
+                prefer_numa_node(p, len, node);
+                it.node = node >= 0 ? node : -1;
             }
             it.pinned = false;
             it.buf = (uint8_t *)p;
@@ -542,7 +532,7 @@ private:
     StageFn stage_;
     HostBufPool *pool_ = nullptr;
     std::function<void()> gate_;
-    int numa_node_ = -1;
+    std::function<int()> numa_query_;  // the GPU's NUMA node, kNumaUnknown while the context is not there yet, -1 = do not place
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[3];
     std::vector<Item *> free_;
@@ -663,14 +653,18 @@ void inq_frontend_close(inq_frontend_t *fe) { delete fe; }
 struct AsyncCtx {
     inq_ctx_t *ctx = nullptr;
     int hrc = INQ_OK;
+    int numa_node = -1;
+    std::atomic<bool> ready{false};  // ctx / hrc / numa_node are final
     std::thread th;
     bool leak = false;  // set after a clean run when the process is about to exit (INQ_FAST_EXIT)
     void start(int device) {
         th = std::thread([this, device] {
             const double a = stamp_ms();
             hrc = inq_ctx_create(device, &ctx);
+            numa_node = hrc == INQ_OK ? inq_ctx_numa_node(ctx) : -1;
+            ready.store(true);
             const char *e = std::getenv("INQ_TIMING");
-            if (e && e[0] == '2') std::fprintf(stderr, "[inq ctx] @%.1f device context ready (inq_ctx_create %.1f ms)\n", stamp_ms(), stamp_ms() - a);
+            if (e && e[0] == '2') std::fprintf(stderr, "[inq ctx] @%.1f device context ready (inq_ctx_create %.1f ms), GPU on NUMA node %d\n", stamp_ms(), stamp_ms() - a, numa_node);
         });
     }
     std::mutex mu;
@@ -736,7 +730,10 @@ static SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamF
     return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
                             [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; },
                             slot_base, pool, std::getenv("INQ_GATE_READS") ? std::function<void()>([&actx] { (void)actx.wait(); }) : std::function<void()>(),
-                            gpu_numa_node(args->device));
+                            [&actx]() -> int {
+                                if (const char *e = std::getenv("INQ_NUMA_NODE")) return std::atoi(e);
+                                return actx.ready.load() ? actx.numa_node : kNumaUnknown;
+                            });
 }
 
 static int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,

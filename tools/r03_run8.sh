@@ -1,0 +1,32 @@
+#!/bin/bash
+# GPU box, round 3: the whole gpu suite on the final libraries, the default bench line, a 12.8 GB SEQ-bearing file end to end.
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r03i
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q > $OUT/gputest.log 2>&1; echo "pytest rc $?" | tee -a $OUT/gputest.log; tail -4 $OUT/gputest.log
+timeout -k 10 600 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc $?"; tail -c 400 $OUT/bench_default.json; echo
+CLI=$ROOT/inquistr_amd/lib/inquistr
+python3 tools/make_synth_bam.py unphased100k 40000 /tmp/seq40k native-seq > $OUT/gen.txt 2>&1; cat $OUT/gen.txt
+for i in 1 2 3 4 5; do
+  t0=$(date +%s.%N); INQ_FRONTEND=device INQ_TIMING=2 $CLI call /tmp/seq40k.bam -R /tmp/seq40k.bed -t 16 -u --sample-name S > /tmp/seq40k.inq 2> $OUT/seq13GB_run$i.err; t1=$(date +%s.%N)
+  python3 -c "print('seq 12.8 GB run $i: process wall %.3f s' % ($t1 - $t0))" | tee -a $OUT/seq13GB_walls.txt
+  grep "timing\] device" $OUT/seq13GB_run$i.err | cut -c1-230 | tee -a $OUT/seq13GB_walls.txt
+  python3 - $OUT/seq13GB_run$i.err <<'PY' | tee -a $OUT/seq13GB_walls.txt
+import re,sys,statistics as s
+t=open(sys.argv[1]).read()
+up=[float(m.group(1)) for m in re.finditer(r'upload ([\d.]+) ms for', t)]
+rd=[float(m.group(1)) for m in re.finditer(r'read\+tables ([\d.]+) ms', t)]
+sp=[(float(m.group(1)),float(m.group(2)),float(m.group(3)),float(m.group(4))) for m in re.finditer(r'inq span\] @([\d.]+) waited ([\d.]+) ms \| loci \d+ comp ([\d.]+) MB.*\| wall ([\d.]+) ms', t)]
+loop=sp[-1][0]-sp[0][0]+sp[0][3]; waited=sum(x[1] for x in sp[1:]); comp=sum(x[2] for x in sp)
+print('   %d spans, %.1f MB: span loop %.1f ms (from the first span call to the last) = %.1f GB/s of compressed bytes; waiting for the loader behind the first span %.1f ms = %.1f %% of the loop; uploads median %.2f ms, reads median %.2f ms, span calls median %.2f ms' % (len(sp), comp, loop, comp/loop, waited, 100*waited/loop, s.median(up[3:]), s.median(rd[3:]), s.median(x[3] for x in sp[1:])))
+PY
+done
+for thr in 16; do
+  t0=$(date +%s.%N); $ROOT/oracle/ref_shaped_call /tmp/seq40k.bam /tmp/seq40k.bed B $thr 1 5 3 S > /tmp/seq40k_B.inq; t1=$(date +%s.%N)
+  python3 -c "print('seq 12.8 GB CPU B $thr threads: %.3f s' % ($t1 - $t0))" | tee -a $OUT/seq13GB_walls.txt
+done
+cmp /tmp/seq40k.inq /tmp/seq40k_B.inq && echo "seq 12.8 GB: .inq == CPU B" | tee -a $OUT/seq13GB_walls.txt
+ls $OUT | wc -l
