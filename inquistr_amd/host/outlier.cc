@@ -2,6 +2,9 @@
 // hands the numbers of all loci to the GPU in one matrix (inq_outlier_rows) and prints the loci with
 // outlying samples.  Text in, text out; the arithmetic is not here.
 #include <zlib.h>
+#include <sys/mman.h>
+#include <fcntl.h>
+#include <chrono>
 
 #include <cstdint>
 #include <cstdio>
@@ -10,6 +13,8 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <limits>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -70,6 +75,32 @@ void split_tabs(const std::string &s, std::vector<std::pair<size_t, size_t>> &ou
 
 // Rust's `str::parse::<f32>`: [+-]? ( inf | infinity | nan | digits [. digits] [e [+-] digits] ), nothing around it
 bool parse_f32(const char *s, size_t n, float *out) {
+    // What a combined .inq holds - integers, halves, NaN (src/call.rs:57-65, 518-520) - without strtof: up to six digits with
+    // nothing, ".0" or ".5" behind them are exact in f32 (< 2^23), so any correctly rounding parser returns this value.
+    {
+        size_t k = 0;
+        const bool neg = n && s[0] == '-';
+        if (neg) k = 1;
+        if (n - k == 3 && s[k] == 'N' && s[k + 1] == 'a' && s[k + 2] == 'N' && !neg) {
+            *out = std::numeric_limits<float>::quiet_NaN();
+            return true;
+        }
+        uint32_t v = 0;
+        size_t d = 0;
+        while (k < n && d < 7 && (unsigned)(s[k] - '0') < 10u) v = v * 10u + (uint32_t)(s[k] - '0'), ++k, ++d;
+        if (d >= 1 && d <= 6) {
+            float f = (float)v;
+            bool ok = k == n;
+            if (!ok && n - k == 2 && s[k] == '.' && (s[k + 1] == '0' || s[k + 1] == '5')) {
+                if (s[k + 1] == '5') f += 0.5f;
+                ok = true;
+            }
+            if (ok) {
+                *out = neg ? -f : f;
+                return true;
+            }
+        }
+    }
     size_t i = 0;
     if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
     auto word = [&](const char *w) {
@@ -171,9 +202,42 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
         }
     } ctx_guard{ctx, ctx_thread};
     // the whole text in memory, then lines parsed by several threads: the numbers are what the command spends its
-    // time on (40 million of them in a 200 000 x 200 cohort), the GPU part is milliseconds
+    // time on (40 million of them in a 200 000 x 200 cohort), the GPU part is milliseconds.  A plain file is mapped (no copy:
+    // the page cache is the buffer; round 2 pulled 139 MB through gzread, 0.1 s on one thread), a gzip file inflated.
+    using clk = std::chrono::steady_clock;
+    const bool timing = std::getenv("INQ_TIMING") != nullptr;
+    const auto t_begin = clk::now();
+    auto lap = [&](const char *what) {
+        if (timing) std::fprintf(stderr, "[inq outlier] %-22s at %7.1f ms\n", what, std::chrono::duration<double, std::milli>(clk::now() - t_begin).count());
+    };
     std::string text;
+    const char *tdata = nullptr;
+    size_t tsize = 0;
+    struct Mapping {
+        void *p = MAP_FAILED;
+        size_t len = 0;
+        ~Mapping() {
+            if (p != MAP_FAILED) ::munmap(p, len);
+        }
+    } mapping;
     {
+        int fd = ::open(a->combined, O_RDONLY);
+        unsigned char magic[2] = {0, 0};
+        struct stat st;
+        const bool plain = fd >= 0 && ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && ::pread(fd, magic, 2, 0) == 2 &&
+                           !(magic[0] == 0x1f && magic[1] == 0x8b);
+        if (plain) {
+            mapping.len = (size_t)st.st_size;
+            mapping.p = ::mmap(nullptr, mapping.len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (mapping.p != MAP_FAILED) {
+                (void)::madvise(mapping.p, mapping.len, MADV_WILLNEED);
+                tdata = (const char *)mapping.p;
+                tsize = mapping.len;
+            }
+        }
+        if (fd >= 0) ::close(fd);
+    }
+    if (!tdata) {
         Lines in;
         if (!in.open(a->combined)) {
             set_err(errbuf, errcap, "Problem opening file");
@@ -186,22 +250,51 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
             set_err(errbuf, errcap, "Problem reading file");
             return INQ_EXIT_PANIC;
         }
+        tdata = text.data();
+        tsize = text.size();
     }
-    // BufRead::lines(): split on '\n' (a trailing '\r' goes too); no line after a final newline
+    lap("text in memory");
+    // BufRead::lines(): split on '\n' (a trailing '\r' goes too); no line after a final newline.  The newlines are found by
+    // several threads, each over its own stretch of the text.
     std::vector<std::pair<size_t, size_t>> lines;  // (offset, length)
-    for (size_t p = 0; p < text.size();) {
-        const char *nl = (const char *)std::memchr(text.data() + p, '\n', text.size() - p);
-        size_t e = nl ? (size_t)(nl - text.data()) : text.size();
-        size_t len = e - p;
-        if (len && text[p + len - 1] == '\r') --len;
-        lines.emplace_back(p, len);
-        p = e + 1;
+    {
+        const unsigned hw0 = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const size_t parts = std::max<size_t>(1, std::min<size_t>(hw0, tsize / (4u << 20) + 1));
+        std::vector<std::vector<size_t>> nl(parts);  // positions of '\n' per stretch
+        std::vector<std::thread> th;
+        auto scan = [&](size_t t) {
+            const size_t lo = tsize * t / parts, hi = tsize * (t + 1) / parts;
+            nl[t].reserve((hi - lo) / 256 + 16);
+            for (size_t p = lo; p < hi;) {
+                const char *q = (const char *)std::memchr(tdata + p, '\n', hi - p);
+                if (!q) break;
+                nl[t].push_back((size_t)(q - tdata));
+                p = (size_t)(q - tdata) + 1;
+            }
+        };
+        for (size_t t = 1; t < parts; ++t) th.emplace_back(scan, t);
+        scan(0);
+        for (auto &x : th) x.join();
+        size_t total = 1;
+        for (auto &v : nl) total += v.size();
+        lines.reserve(total);
+        size_t p = 0;
+        auto push = [&](size_t e) {
+            size_t len = e - p;
+            if (len && tdata[p + len - 1] == '\r') --len;
+            lines.emplace_back(p, len);
+            p = e + 1;
+        };
+        for (auto &v : nl)
+            for (size_t e : v) push(e);
+        if (p < tsize) push(tsize);
     }
+    lap("lines found");
     if (lines.empty()) {  // lines.next().unwrap(), src/outlier.rs:36
         set_err(errbuf, errcap, "called `Option::unwrap()` on a `None` value (empty combined file)");
         return INQ_EXIT_PANIC;
     }
-    std::string line = text.substr(lines[0].first, lines[0].second);
+    std::string line(tdata + lines[0].first, lines[0].second);
     std::vector<std::pair<size_t, size_t>> fld;
     split_tabs(line, fld);
     std::vector<std::string> samples;
@@ -233,7 +326,7 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
     parallel([&](size_t t) {  // pass A: fields per line
         auto [lo, hi] = chunk(t);
         for (size_t i = lo; i < hi; ++i) {
-            const char *p = text.data() + lines[i + 1].first;
+            const char *p = tdata + lines[i + 1].first;
             size_t tabs = 0;
             for (size_t k = 0; k < lines[i + 1].second; ++k) tabs += p[k] == '\t';
             if (tabs < 2) {  // splitline[2], :43
@@ -249,13 +342,15 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
         if (bad_a[t] < first_bad) first_bad = bad_a[t], late_panic = "index out of bounds: a line with fewer than three fields";
     size_t stride = 0;
     for (size_t i = 0; i < first_bad; ++i) stride = std::max<size_t>(stride, row_len[i]);
-    std::vector<float> mat(first_bad * stride, 0.0f);
+    // not zero-filled: a row's values beyond row_len are never read (inq_outlier_rows), and 160 MB of zeros is time
+    std::unique_ptr<float[]> mat_mem(new float[std::max<size_t>(first_bad * stride, 1)]);
+    float *const mat = mat_mem.get();
     std::vector<size_t> bad_b(n_thr, (size_t)-1);
     parallel([&](size_t t) {  // pass B: the numbers
         auto [lo, hi] = chunk(t);
         hi = std::min(hi, first_bad);
         for (size_t i = lo; i < hi; ++i) {
-            const char *p = text.data() + lines[i + 1].first, *end = p + lines[i + 1].second;
+            const char *p = tdata + lines[i + 1].first, *end = p + lines[i + 1].second;
             int field = 0;
             const char *f0 = p;
             for (const char *q = p;; ++q) {
@@ -275,7 +370,7 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
         if (bad_b[t] < first_bad) first_bad = bad_b[t], late_panic = "Failed to parse number";
     row_len.resize(first_bad);
     auto coords_of = [&](size_t i) {  // chrom, begin, end as they stand in the file
-        const char *p = text.data() + lines[i + 1].first;
+        const char *p = tdata + lines[i + 1].first;
         size_t k = 0, tabs = 0;
         for (; k < lines[i + 1].second; ++k)
             if (p[k] == '\t' && ++tabs == 3) break;
@@ -284,12 +379,14 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
     const size_t n_rows = first_bad;
     std::vector<uint8_t> flags(n_rows * stride, 0), keep(n_rows, 0);
 
+    lap("numbers parsed");
     ctx_thread.join();
+    lap("device context there");
     if (hrc != INQ_OK) {
         set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
         return INQ_EXIT_ERROR;
     }
-    hrc = inq_outlier_rows(ctx, mat.data(), row_len.data(), n_rows, (uint32_t)stride, a->method, a->minsize, a->zscore,
+    hrc = inq_outlier_rows(ctx, mat, row_len.data(), n_rows, (uint32_t)stride, a->method, a->minsize, a->zscore,
                            mincluster, flags.data(), keep.data());
     std::string detail = hrc == INQ_ERR_HIP ? inq_last_error(ctx) : "";
     if (hrc != INQ_OK) {
@@ -297,6 +394,7 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
         return INQ_EXIT_ERROR;
     }
 
+    lap("kernels done");
     std::string out = "chrom\tbegin\tend\toutliers\n";  // :37
     for (size_t i = 0; i < n_rows; ++i) {
         switch (keep[i]) {
