@@ -56,10 +56,6 @@ constexpr int kLitBits = INQ_WG_LITBITS, kDistBits = INQ_WG_DISTBITS;
 #ifndef INQ_WG_LITPAIR
 #define INQ_WG_LITPAIR 1  // a literal behind a literal is decoded from the same peek
 #endif
-#ifndef INQ_WG_PAIRMASS
-#define INQ_WG_PAIRMASS 13800  // of 32768: CIGAR-only records 11 600 - 12 900 (pairs lose 4.6 %), packed bases 14 800 - 15 900 (pairs gain 8 %), quality bytes 30 000
-#endif
-constexpr uint32_t kPairMass = INQ_WG_PAIRMASS;
 #ifndef INQ_WG_LITFIRST
 #define INQ_WG_LITFIRST 1
 #endif
@@ -135,7 +131,6 @@ struct WgLds {
     uint32_t limit[2][16], base[2][16];
     // block-uniform state
     uint32_t P, out, status, last, type, eob, hlit, hdist, flag;
-    uint32_t lit_mass, pair;  // code space the 256 literals take (units of 2^-15); pair = look for a second literal behind a literal
     uint32_t red[T / 64], red2[T / 64];
 };
 
@@ -308,7 +303,6 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
     SegBits b;
     b.init(L.stage, start);
     uint32_t nb = 0, stop = 0, nt = 0;
-    const bool pair_mode = L.pair != 0u;  // block-uniform
     const uint32_t lane_end = MODE == 1 ? o - r0 + nbytes : 0u;  // MODE 1: nbytes comes in as the job's counted bytes
     // MODE 0 walks the segment's two halves one after the other and notes where the chain enters the second
     if (MODE == 0) *mid = kNoMid;
@@ -354,9 +348,10 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
             // the limit, both go out with one move of the cursor and one turn of the loop.  Measured (20 000 blocks, zlib level
             // 1 / 6): quality-like bytes 17.4 -> 13.5 / 16.1 -> 12.2 ms, nanopore-like 14.0 -> 12.1 / 13.8 -> 11.3, packed bases
             // 11.9 -> 10.9 / 11.2 -> 10.8, CIGAR-only blocks 11.4 -> 11.95 / 8.1 -> 8.15 (the look is wasted when a match
-            // follows).  A third literal from the same peek and a "only behind a literal" predictor both lost
-            // (profiles/r03_results/inflate_literal_runs_five_builds.txt).
-            const uint32_t e2 = pair_mode ? L.lut_ll[(bits >> n) & ((1u << kLitBits) - 1u)] : kSpecial;
+            // follows).  A third literal from the same peek, a "only behind a literal" predictor and a per-block switch (pairs
+            // only where literals hold most of the block's code space) all lost: any condition on the second look costs more
+            // than the look (profiles/r03_results/inflate_literal_runs_five_builds.txt, inflate_pairs_per_block_switch.txt).
+            const uint32_t e2 = L.lut_ll[(bits >> n) & ((1u << kLitBits) - 1u)];
             const bool two = !(e2 & (kSpecial | (E_LEN << 4))) && b.pos + n < lim;
             b.consume(n + (two ? (e2 & 15u) : 0u));
             if (MODE == 2) {
@@ -669,20 +664,12 @@ __device__ void header_lengths_wg(WgLds<T> &L, uint32_t hp, uint32_t stage_bit0,
 template <int T>
 __device__ void build_tables(WgLds<T> &L, int tid) {
     if (tid < 32) L.cnt[tid >> 4][tid & 15] = 0u;
-    if (tid == 0) L.lit_mass = 0u;
     __syncthreads();
-    uint32_t mass = 0;
     for (int s = tid; s < kMaxLit + kMaxDist; s += T) {
         const uint32_t n = L.lens[s];
         if (n) atomicAdd(&L.cnt[s >= kMaxLit][n], 1u);
-        if (n && s < 256) mass += 1u << (15u - n);
     }
-    if (mass) atomicAdd(&L.lit_mass, mass);
     __syncthreads();
-    // The code lengths say how often the encoder saw literals: their share of the code space (2^-length each) is their share of
-    // the symbols.  Where most symbols are matches (CIGAR-like records: literals hold under half of the code space) the second
-    // look behind a literal is mostly wasted (+4.6 % kernel time), elsewhere it is the kernel's biggest single gain.
-    if (tid == 0) L.pair = L.lit_mass >= kPairMass ? 1u : 0u;
     if (tid < 2) {  // limits, bases, insertion slots; zlib's inflate_table rejects over-subscribed sets and
         const int tbl = tid;  // incomplete ones with any code longer than one bit
         int left = 1, maxlen = 0;

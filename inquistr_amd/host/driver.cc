@@ -1,6 +1,8 @@
 // driver.cc — `call::genotype_repeats` (src/call.rs:76-159) on top of the front end and the HIP library,
 // plus the C ABI of include/inquistr_host.h.
 #include <sys/mman.h>
+#include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -260,12 +262,73 @@ private:
     std::string err_;
 };
 
-// A span buffer is read by the GPU's DMA engine; on the two-socket hosts measured an upload from the other socket's memory takes
-// 5.6 - 6.1 ms per 268 MB instead of 4.9 ms, which is the difference between an upload-bound and a device-bound span loop on
-// SEQ-bearing files (profiles/r03_results/loader_numa_binding.txt).  The node is the context's (inq_ctx_numa_node: the device's
-// PCI address through sysfs), known once the runtime is up; buffers mapped before that are mapped again when their slot comes
-// round.  INQ_NUMA_NODE=n overrides, -1 switches the placement off.
+// NUMA.  A span buffer is read by the GPU's copy engine over PCIe, which hangs off ONE socket; so are the staging chunks the
+// runtime copies pageable memory through.  With the whole process bound to the GPU's node an upload of 268 MB took 4.84 - 4.98 ms,
+// bound to the other node 5.5 - 5.7 ms, unbound 5.6 - 6.3 ms (profiles/r03_results/loader_numa_binding.txt); preferring the node for
+// the span buffers alone changed nothing (6.1 ms, l2_seq_12.8GB_buffers_only.txt): the runtime's own buffers must be local too.
+// So the threads that allocate - the one that starts the runtime, the loader, the uploader - prefer the GPU's node from their
+// first instruction (MPOL_PREFERRED: a hint, never a failure).  The node must be known before the runtime is up: it is read from
+// sysfs for the device-th render node this process can really open.  INQ_NUMA_NODE=n overrides, -1 switches it off;
+// INQ_NUMA_CPUS=1 also keeps those threads on the node's CPUs.
 constexpr int kNumaUnknown = -2;
+
+static int guess_gpu_numa_node(int device) {
+    static std::mutex mu;
+    static std::map<int, int> memo;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = memo.find(device);
+    if (it != memo.end()) return it->second;
+    int node = -1;
+    if (const char *e = std::getenv("INQ_NUMA_NODE")) node = std::atoi(e);
+    else {
+        int seen = 0;
+        for (int minor = 128; minor < 128 + 64 && node == -1; ++minor) {
+            char dev[64], path[128];
+            std::snprintf(dev, sizeof dev, "/dev/dri/renderD%d", minor);
+            const int fd = ::open(dev, O_RDWR | O_CLOEXEC);  // the device cgroup, not the permission bits, says which GPU is ours
+            if (fd < 0) continue;
+            ::close(fd);
+            if (seen++ != device) continue;
+            std::snprintf(path, sizeof path, "/sys/class/drm/renderD%d/device/numa_node", minor);
+            if (FILE *f = std::fopen(path, "r")) {
+                if (std::fscanf(f, "%d", &node) != 1) node = -1;
+                std::fclose(f);
+            }
+            break;
+        }
+    }
+    memo[device] = node;
+    return node;
+}
+
+static void prefer_gpu_node_for_this_thread(int device) {
+    const int node = guess_gpu_numa_node(device);
+    if (node < 0 || node >= 1024) return;
+    unsigned long mask[16] = {0};
+    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+    (void)::syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, sizeof mask * 8);
+    const char *c = std::getenv("INQ_NUMA_CPUS");
+    if (c && c[0] == '1') {
+        char path[128], buf[4096] = {0};
+        std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        FILE *f = std::fopen(path, "r");
+        if (!f) return;
+        if (!std::fgets(buf, sizeof buf, f)) buf[0] = 0;
+        std::fclose(f);
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        for (char *p = buf; *p;) {  // "0-63,128-191"
+            char *q;
+            long a = std::strtol(p, &q, 10), b = a;
+            if (q == p) break;
+            if (*q == '-') b = std::strtol(q + 1, &q, 10);
+            for (long k = a; k <= b && k < CPU_SETSIZE; ++k) CPU_SET((int)k, &set);
+            if (*q != ',') break;
+            p = q + 1;
+        }
+        if (CPU_COUNT(&set)) (void)sched_setaffinity(0, sizeof set, &set);
+    }
+}
 
 static void prefer_numa_node(void *p, size_t len, int node) {
     if (node < 0 || node >= 1024) return;
@@ -330,9 +393,9 @@ public:
     // and go back to (may be null: mapped and unmapped by the pipeline)
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
                  uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr,
-                 std::function<void()> gate = nullptr, std::function<int()> numa_query = nullptr)
+                 std::function<void()> gate = nullptr, std::function<int()> numa_query = nullptr, int device = 0)
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
-          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), numa_query_(std::move(numa_query)) {
+          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), numa_query_(std::move(numa_query)), device_(device) {
         for (int i = 0; i < 3; ++i) slots_[i].slot = slot_base + i;
         for (auto &it : slots_) free_.push_back(&it);
         th_ = std::thread([this] { run(); });
@@ -438,6 +501,7 @@ private:
         cv_loaded_.notify_all();
     }
     void run() {
+        prefer_gpu_node_for_this_thread(device_);
         SpanLoader loader;
         std::string e;
         if (!loader.open(path_, &e)) return fail(e);
@@ -497,6 +561,7 @@ private:
     }
     // uploads in file order, one span behind the reader
     void run_uploads() {
+        prefer_gpu_node_for_this_thread(device_);  // the runtime's staging chunks are allocated by the thread that first copies
         for (;;) {
             Item *it = nullptr;
             {
@@ -533,6 +598,7 @@ private:
     HostBufPool *pool_ = nullptr;
     std::function<void()> gate_;
     std::function<int()> numa_query_;  // the GPU's NUMA node, kNumaUnknown while the context is not there yet, -1 = do not place
+    int device_ = 0;
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[3];
     std::vector<Item *> free_;
@@ -659,6 +725,7 @@ struct AsyncCtx {
     bool leak = false;  // set after a clean run when the process is about to exit (INQ_FAST_EXIT)
     void start(int device) {
         th = std::thread([this, device] {
+            prefer_gpu_node_for_this_thread(device);  // what the runtime allocates while it starts
             const double a = stamp_ms();
             hrc = inq_ctx_create(device, &ctx);
             numa_node = hrc == INQ_OK ? inq_ctx_numa_node(ctx) : -1;
@@ -730,10 +797,11 @@ static SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamF
     return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
                             [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; },
                             slot_base, pool, std::getenv("INQ_GATE_READS") ? std::function<void()>([&actx] { (void)actx.wait(); }) : std::function<void()>(),
-                            [&actx]() -> int {
+                            [&actx, dev = args->device]() -> int {
                                 if (const char *e = std::getenv("INQ_NUMA_NODE")) return std::atoi(e);
-                                return actx.ready.load() ? actx.numa_node : kNumaUnknown;
-                            });
+                                return actx.ready.load() ? actx.numa_node : guess_gpu_numa_node(dev);
+                            },
+                            args->device);
 }
 
 static int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,
