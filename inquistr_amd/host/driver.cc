@@ -262,14 +262,16 @@ private:
     std::string err_;
 };
 
-// NUMA.  A span buffer is read by the GPU's copy engine over PCIe, which hangs off ONE socket; so are the staging chunks the
-// runtime copies pageable memory through.  With the whole process bound to the GPU's node an upload of 268 MB took 4.84 - 4.98 ms,
-// bound to the other node 5.5 - 5.7 ms, unbound 5.6 - 6.3 ms (profiles/r03_results/loader_numa_binding.txt); preferring the node for
-// the span buffers alone changed nothing (6.1 ms, l2_seq_12.8GB_buffers_only.txt): the runtime's own buffers must be local too.
-// So the threads that allocate - the one that starts the runtime, the loader, the uploader - prefer the GPU's node from their
-// first instruction (MPOL_PREFERRED: a hint, never a failure).  The node must be known before the runtime is up: it is read from
-// sysfs for the device-th render node this process can really open.  INQ_NUMA_NODE=n overrides, -1 switches it off;
-// INQ_NUMA_CPUS=1 also keeps those threads on the node's CPUs.
+// NUMA.  A span buffer is read by the GPU's copy engine over PCIe, which hangs off ONE socket, and a pageable upload passes
+// through the runtime on the thread that issues it.  On the two-socket hosts measured (profiles/r03_results/loader_numa_binding.txt,
+// l2_seq_12.8GB_numa_modes.txt) an upload of 268 MB takes 4.86 - 4.97 ms when the issuing thread runs on the GPU's node and its
+// memory comes from there, 5.5 - 6.3 ms otherwise - preferring the node for the memory alone (mbind of the span buffers, or
+// MPOL_PREFERRED for the threads) changed nothing: it is the CPU side of the copy that has to be near.  That is the difference
+// between an upload-bound and a device-bound span loop on SEQ-bearing files (loader wait 12 - 17 % -> 2 - 4 % of the loop, 39 - 41 ->
+// 43 - 46.5 GB/s of compressed bytes).  So the threads that read, upload and start the runtime run on the CPUs of the GPU's node
+// (cut with the mask they were given; left alone if that leaves nothing) and prefer its memory.  The node must be known before the
+// runtime is up: it is read from sysfs for the device-th render node this process can really open.  INQ_NUMA_NODE=n overrides,
+// -1 switches all of it off; INQ_NUMA_CPUS=0 keeps the memory preference but lets the threads run anywhere.
 constexpr int kNumaUnknown = -2;
 
 static int guess_gpu_numa_node(int device) {
@@ -308,25 +310,28 @@ static void prefer_gpu_node_for_this_thread(int device) {
     mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
     (void)::syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, sizeof mask * 8);
     const char *c = std::getenv("INQ_NUMA_CPUS");
-    if (c && c[0] == '1') {
+    if (!(c && c[0] == '0')) {
         char path[128], buf[4096] = {0};
         std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
         FILE *f = std::fopen(path, "r");
         if (!f) return;
         if (!std::fgets(buf, sizeof buf, f)) buf[0] = 0;
         std::fclose(f);
-        cpu_set_t set;
+        cpu_set_t set, have;
         CPU_ZERO(&set);
+        CPU_ZERO(&have);
+        if (sched_getaffinity(0, sizeof have, &have) != 0) return;
         for (char *p = buf; *p;) {  // "0-63,128-191"
             char *q;
             long a = std::strtol(p, &q, 10), b = a;
             if (q == p) break;
             if (*q == '-') b = std::strtol(q + 1, &q, 10);
-            for (long k = a; k <= b && k < CPU_SETSIZE; ++k) CPU_SET((int)k, &set);
+            for (long k = a; k <= b && k < CPU_SETSIZE; ++k)
+                if (CPU_ISSET((int)k, &have)) CPU_SET((int)k, &set);  // never beyond what the process was given
             if (*q != ',') break;
             p = q + 1;
         }
-        if (CPU_COUNT(&set)) (void)sched_setaffinity(0, sizeof set, &set);
+        if (CPU_COUNT(&set) >= 4) (void)sched_setaffinity(0, sizeof set, &set);
     }
 }
 

@@ -86,8 +86,12 @@ int main(int argc, char **argv) {
         }
         o.combined = combined;
         char err[1024] = {0};
+        ::setenv("INQ_FAST_EXIT", "1", 0);  // this process ends with the command: the device context is left to the operating system
         int rc = inq_outlier(&o, 1, err, sizeof err);
         if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
+        std::fflush(nullptr);
+        const char *fast = std::getenv("INQ_FAST_EXIT");  // the lines went out through write(2): skip the runtime's tear-down (0.15 - 0.2 s)
+        if (fast && fast[0] == '1') std::_Exit(rc);
         return rc;
     }
     if (argc >= 2 && std::strcmp(argv[1], "cohort") == 0) {

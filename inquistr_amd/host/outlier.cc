@@ -198,7 +198,8 @@ int outlier_impl(const inq_outlier_args_t *a, int out_fd, char *errbuf, size_t e
         std::thread &t;
         ~CtxGuard() {
             if (t.joinable()) t.join();
-            inq_ctx_destroy(c);
+            const char *fast = std::getenv("INQ_FAST_EXIT");  // set by the CLI, which is about to leave the process
+            if (!(fast && fast[0] == '1')) inq_ctx_destroy(c);
         }
     } ctx_guard{ctx, ctx_thread};
     // the whole text in memory, then lines parsed by several threads: the numbers are what the command spends its
