@@ -174,6 +174,9 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * "verify_crc" = 0 skips the CRC32 check of the device front end (default 1);
  * "inflate_algo" = 0 inflates with one workgroup per BGZF block (no latency floor, 0.54-0.82 ms per 1000 blocks), 1 with one
  * lane per block (36-56 ms for up to ~65 000 blocks), 2 (default) = the quicker one, which is 0 at every size measured;
+ * "inflate_lit_pairs" = 1 / 0: the workgroup inflate's symbol loop decodes a second literal from the same 32 bits as the first
+ * (+18 - 24 % on sequence / quality bytes) or not (CIGAR-only records lose 4.6 % to the wasted look); -1 (default) = decided per
+ * call from the code lengths in a few sampled block headers;
  * "inflate_tokens" = 1: the workgroup inflate keeps the symbols its counting passes decode (32 KB of device scratch per BGZF
  * block) so that its commit step does not decode them again; 0 (default) = it decodes again (the stores cost what the second
  * decode did: +3 % on CIGAR-only blocks, -2 ... -5 % on sequence / quality bytes);

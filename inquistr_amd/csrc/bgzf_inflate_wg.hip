@@ -53,9 +53,6 @@ namespace {
 #define INQ_WG_DISTBITS 8
 #endif
 constexpr int kLitBits = INQ_WG_LITBITS, kDistBits = INQ_WG_DISTBITS;
-#ifndef INQ_WG_LITPAIR
-#define INQ_WG_LITPAIR 1  // a literal behind a literal is decoded from the same peek
-#endif
 #ifndef INQ_WG_LITFIRST
 #define INQ_WG_LITFIRST 1
 #endif
@@ -296,7 +293,7 @@ __device__ __forceinline__ void root_match(WgLds<T> &L, uint32_t p, uint32_t own
 // Returns the position behind the last decoded symbol (| kStopped / kStopEob).  `bad` collects INQ_INFLATE_* bits.
 // MODE 0 with tok != null also leaves the symbols behind as tokens (tok = this segment's column of the block's token scratch,
 // stride T words): *ntok = how many the chain produced (only the first kTokCap are stored), *mid_tok = how many before `mid`.
-template <int T, int MODE>
+template <int T, int MODE, bool PAIR>
 __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, uint32_t seg_end, uint32_t &nbytes, uint8_t *out, uint32_t o,
                                                    uint32_t r0, uint32_t &bad, uint32_t *mid = nullptr, uint32_t *tok = nullptr,
                                                    uint32_t *ntok = nullptr, uint32_t *mid_tok = nullptr) {
@@ -341,52 +338,52 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
         lit = !(e & (E_LEN << 4));
 #endif
         const uint32_t n = e & 15u, xb = (e >> 8) & 15u;  // a literal has no extra bits
-#if INQ_WG_LITPAIR
-        if (lit) {
-            // a literal: look at the symbol behind it in the bits already peeked (>= 32 - 15 of them are left) - when that is a
-            // plain literal too (the common case in base-quality and sequence bytes, what a BAM mostly is) and starts in front of
-            // the limit, both go out with one move of the cursor and one turn of the loop.  Measured (20 000 blocks, zlib level
-            // 1 / 6): quality-like bytes 17.4 -> 13.5 / 16.1 -> 12.2 ms, nanopore-like 14.0 -> 12.1 / 13.8 -> 11.3, packed bases
-            // 11.9 -> 10.9 / 11.2 -> 10.8, CIGAR-only blocks 11.4 -> 11.95 / 8.1 -> 8.15 (the look is wasted when a match
-            // follows).  A third literal from the same peek, a "only behind a literal" predictor and a per-block switch (pairs
-            // only where literals hold most of the block's code space) all lost: any condition on the second look costs more
-            // than the look (profiles/r03_results/inflate_literal_runs_five_builds.txt, inflate_pairs_per_block_switch.txt).
-            const uint32_t e2 = L.lut_ll[(bits >> n) & ((1u << kLitBits) - 1u)];
-            const bool two = !(e2 & (kSpecial | (E_LEN << 4))) && b.pos + n < lim;
-            b.consume(n + (two ? (e2 & 15u) : 0u));
-            if (MODE == 2) {
-                out[o + nb] = (uint8_t)(e >> 16);
-                if (two) out[o + nb + 1u] = (uint8_t)(e2 >> 16);
+        if constexpr (PAIR) {
+            if (lit) {
+                // a literal: look at the symbol behind it in the bits already peeked (>= 32 - 15 of them are left) - when that is a
+                // plain literal too (the common case in base-quality and sequence bytes, what a BAM mostly is) and starts in front of
+                // the limit, both go out with one move of the cursor and one turn of the loop.  Measured (20 000 blocks, zlib level
+                // 1 / 6): quality-like bytes 17.4 -> 13.5 / 16.1 -> 12.2 ms, nanopore-like 14.0 -> 12.1 / 13.8 -> 11.3, packed bases
+                // 11.9 -> 10.9 / 11.2 -> 10.8, CIGAR-only blocks 11.4 -> 11.95 / 8.1 -> 8.15 (the look is wasted when a match
+                // follows).  A third literal from the same peek, a "only behind a literal" predictor and a per-block switch (pairs
+                // only where literals hold most of the block's code space) all lost: any condition on the second look costs more
+                // than the look (profiles/r03_results/inflate_literal_runs_five_builds.txt, inflate_pairs_per_block_switch.txt).
+                const uint32_t e2 = L.lut_ll[(bits >> n) & ((1u << kLitBits) - 1u)];
+                const bool two = !(e2 & (kSpecial | (E_LEN << 4))) && b.pos + n < lim;
+                b.consume(n + (two ? (e2 & 15u) : 0u));
+                if (MODE == 2) {
+                    out[o + nb] = (uint8_t)(e >> 16);
+                    if (two) out[o + nb + 1u] = (uint8_t)(e2 >> 16);
+                }
+                if (MODE == 1) {  // the bytes themselves: stored by the gather, coalesced
+                    L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));
+                    if (two) L.root[o + nb + 1u - r0] = (uint16_t)(kRootLit | (e2 >> 16));
+                }
+                if (MODE == 0 && tok) {
+                    if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
+                    ++nt;
+                    if (two) {
+                        if (nt < kTokCap) tok[nt * T] = kTokLit | (e2 >> 16);
+                        ++nt;
+                    }
+                }
+                nb += two ? 2u : 1u;
+                continue;
             }
-            if (MODE == 1) {  // the bytes themselves: stored by the gather, coalesced
-                L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));
-                if (two) L.root[o + nb + 1u - r0] = (uint16_t)(kRootLit | (e2 >> 16));
-            }
-            if (MODE == 0 && tok) {
-                if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
-                ++nt;
-                if (two) {
-                    if (nt < kTokCap) tok[nt * T] = kTokLit | (e2 >> 16);
+            b.consume(n + xb);
+        } else {
+            b.consume(n + xb);
+            if (lit) {
+                if (MODE == 2) out[o + nb] = (uint8_t)(e >> 16);
+                if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));  // the byte itself: stored by the gather, coalesced
+                if (MODE == 0 && tok) {
+                    if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
                     ++nt;
                 }
+                ++nb;
+                continue;
             }
-            nb += two ? 2u : 1u;
-            continue;
         }
-        b.consume(n + xb);
-#else
-        b.consume(n + xb);
-        if (lit) {
-            if (MODE == 2) out[o + nb] = (uint8_t)(e >> 16);
-            if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));  // the byte itself: stored by the gather, coalesced
-            if (MODE == 0 && tok) {
-                if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
-                ++nt;
-            }
-            ++nb;
-            continue;
-        }
-#endif
         const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(bits, n, xb);
         const uint32_t dbits = b.peek();
         uint32_t d = L.lut_d[dbits & ((1u << kDistBits) - 1u)];
@@ -740,7 +737,7 @@ __device__ __forceinline__ void stage_load(WgLds<T> &L, const uint8_t *payload, 
 #ifndef INQ_WG_WAVES
 #define INQ_WG_WAVES 4
 #endif
-template <int T>
+template <int T, bool PAIR>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES, INQ_WG_WAVES))) void bgzf_inflate_wg_kernel(InflateArgs a) {
     __shared__ WgLds<T> L;
     const int tid = (int)threadIdx.x;
@@ -859,7 +856,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             uint32_t start = tid == 0 ? (P & 31u) : (uint32_t)tid * kSegBits;
             uint32_t nbytes = 0, bad = 0, mid = kNoMid, ntok = 0, mid_tok = 0;
             uint32_t *const tok = a.tokens ? a.tokens + (bi * kTokCap) * (uint64_t)T + (uint32_t)tid : nullptr;
-            uint32_t end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
+            uint32_t end = decode_segment<T, 0, PAIR>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
             DBG_N(1);
             DBG_N(2);
             // ---- until every chain starts where its left neighbour's ended (lanes behind the first stop do not matter)
@@ -879,7 +876,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 }
                 if (mismatch) {
                     start = left & 0x3fffffffu;
-                    end = decode_segment<T, 0>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
+                    end = decode_segment<T, 0, PAIR>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
                 }
                 DBG_N(2);
                 __syncthreads();  // end_bit[] read by everyone before it is rewritten
@@ -923,7 +920,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 if (lone) {
                     if ((uint32_t)tid == k0) {
                         uint32_t nb2 = nbytes;
-                        (void)decode_segment<T, 2>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
+                        (void)decode_segment<T, 2, PAIR>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
                     }
                 } else {
                     // two jobs per segment, dealt over all lanes: the first half of its chain, and the rest from where the chain
@@ -946,7 +943,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                             continue;
                         }
                         uint32_t nb2 = jn;
-                        (void)decode_segment<T, 1>(L, js, je, nb2, out, out0 + jo, r0, cbad);
+                        (void)decode_segment<T, 1, PAIR>(L, js, je, nb2, out, out0 + jo, r0, cbad);
                     }
                 }
                 if (cbad) atomicOr(&L.status, cbad);
@@ -1067,7 +1064,12 @@ void launch_bgzf_inflate_wg(const InflateArgs &a, hipStream_t s) {
 #define INQ_WG_T 128
 #endif
     constexpr int T = INQ_WG_T;
-    hipLaunchKernelGGL((bgzf_inflate_wg_kernel<T>), dim3((uint32_t)a.n_blocks), dim3(T), 0, s, a);
+    // two forms of the symbol loop: a second literal decoded from the same peek (literal-heavy data: sequence / quality
+    // bytes, +18 - 24 %), or not (match-heavy data, CIGAR-only records: the second look costs 4.6 % there).  The caller says
+    // which (InflateArgs::lit_pairs, from the code lengths of a few sampled block headers: deflate_probe.h); any condition
+    // INSIDE the loop costs more than it saves.
+    if (a.lit_pairs) hipLaunchKernelGGL((bgzf_inflate_wg_kernel<T, true>), dim3((uint32_t)a.n_blocks), dim3(T), 0, s, a);
+    else hipLaunchKernelGGL((bgzf_inflate_wg_kernel<T, false>), dim3((uint32_t)a.n_blocks), dim3(T), 0, s, a);
 }
 
 }  // namespace inq

@@ -43,6 +43,7 @@ struct inq_ctx {
     // workgroup inflate: the counting passes leave the symbols behind for the commit (option "inflate_tokens").  Off: measured
     // +3 % on CIGAR-only blocks, -2 ... -5 % on sequence / quality bytes, what a real BAM mostly is (profiles/r03_results/)
     bool inflate_tokens = false;
+    int inflate_lit_pairs = -1;  // workgroup inflate's symbol loop: 1 = a second literal from the same peek, 0 = not, -1 = by the data (deflate_probe.h)
     uint32_t inflate_algo = 2;  // 0 = workgroup per BGZF block, 1 = lane per block, 2 = the quicker one (0 since round 2)
     std::vector<inq::EvTriple> ev_pool;
     size_t ev_used = 0;

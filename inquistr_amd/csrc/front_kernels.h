@@ -23,6 +23,7 @@ struct InflateArgs {
     // workgroup kernel: scratch for the symbols of a round as decoded by the counting passes (inflate_token_words(n_blocks)
     // u32), so that the commit does not decode them again; null = the commit decodes (round 2's form)
     uint32_t *tokens;
+    uint32_t lit_pairs;  // workgroup kernel: 1 = the symbol loop looks for a second literal behind a literal (literal-heavy data)
 };
 uint64_t inflate_token_words(uint64_t n_blocks);
 void launch_bgzf_inflate(const InflateArgs &a, hipStream_t s);

@@ -12,6 +12,7 @@
 #include <new>
 
 #include "ctx.h"
+#include "deflate_probe.h"
 #include "front_kernels.h"
 
 namespace inq {
@@ -188,6 +189,9 @@ int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t c
     if (const char *dbg = std::getenv("INQ_INFLATE_DEBUG")) ia.debug_flags = (uint32_t)std::atoi(dbg);
 #endif
     ia.algo = c->inflate_algo;
+    // literal-heavy or match-heavy?  (the host still has the compressed bytes: a few block headers are read; option
+    // "inflate_lit_pairs" = 0 / 1 forces a form, -1 = look)
+    ia.lit_pairs = c->inflate_lit_pairs < 0 ? inflate_wants_literal_pairs(comp, comp_bytes, blocks, n_blocks) : (c->inflate_lit_pairs ? 1u : 0u);
     ia.tokens = nullptr;
     if (ia.algo != 1u && c->inflate_tokens) {
         if ((rc = ensure(c, S->tok, inflate_token_words(n_blocks) * 4)) != INQ_OK) return rc;

@@ -12,13 +12,16 @@ from inquistr_amd import hipcall
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[(0, 1), (0, 0), (1, 0)], ids=["inflate_wg", "inflate_wg_commit_decodes", "inflate_lane"])
+@pytest.fixture(scope="module", params=[(0, 0, 1), (0, 1, 0), (0, 0, -1), (1, 0, -1)],
+                ids=["inflate_wg_literal_pairs", "inflate_wg_no_pairs_commit_from_tokens", "inflate_wg_form_by_the_data", "inflate_lane"])
 def ctx(request):
-    """Both inflate kernels (workgroup per block - with its commit fed from the counting passes' tokens, and decoding again as in
-    round 2 - / lane per block) go through every test of this file."""
+    """Both inflate kernels go through every test of this file: workgroup per block - its symbol loop with and without the second
+    literal per peek, its commit decoding again and fed from tokens, and the form chosen from the block headers as the product
+    does - and lane per block."""
     c = hipcall.Context(0)
     c.set_option("inflate_algo", request.param[0])
     c.set_option("inflate_tokens", request.param[1])
+    c.set_option("inflate_lit_pairs", request.param[2])
     yield c
     c.close()
 

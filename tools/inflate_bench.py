@@ -63,6 +63,8 @@ def main():
     out_bytes = int(blocks["isize"].sum())
     if os.environ.get("ALGO"):
         ctx.set_option("inflate_algo", int(os.environ["ALGO"]))
+    if os.environ.get("PAIRS"):
+        ctx.set_option("inflate_lit_pairs", int(os.environ["PAIRS"]))
     if os.environ.get("TOKENS"):
         ctx.set_option("inflate_tokens", int(os.environ["TOKENS"]))
     if os.environ.get("NOCRC"):

@@ -14,7 +14,7 @@ valid_rounds = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, rounds // 2)  #
 ctx = hipcall.Context(0)
 orig = random.Random
 for r in range(rounds):
-    seed = 9000 + r
+    seed = int(os.environ.get("INQ_SOAK_SEED", "9000")) + r
 
     class Seeded(orig):  # the test builds its own Random(2024): give it another stream each round
         def __init__(self, _ignored=None):
@@ -79,9 +79,11 @@ def _blocks(rng, n):
     return out
 
 
-for algo in (0, 1):
+for algo, tokens in ((0, 0), (0, 1), (1, 0)):  # workgroup kernel (commit decodes / commit from tokens), lane kernel
     ctx.set_option("inflate_algo", algo)
-    rng = orig(4242 + algo)
+    ctx.set_option("inflate_tokens", tokens)
+    ctx.set_option("inflate_lit_pairs", 1 - tokens)  # both forms of the symbol loop
+    rng = orig(int(os.environ.get("INQ_SOAK_SEED", "4242")) + algo + 10 * tokens)
     n_blocks = 0
     for r in range(valid_rounds):
         items = _blocks(rng, 1500)
@@ -92,5 +94,5 @@ for algo in (0, 1):
         assert rc == 0 and not status.any(), (algo, r, [hex(int(s)) for s in status if s][:5])
         assert out.tobytes() == b"".join(d for _, d in items), (algo, r)
         n_blocks += len(items)
-        print(f"  inflate_algo {algo} round {r}: {len(items)} blocks ok", flush=True)
-    print(f"inflate_algo {algo}: {n_blocks} valid blocks of nine shapes inflate to their input", flush=True)
+        print(f"  inflate_algo {algo} tokens {tokens} round {r}: {len(items)} blocks ok", flush=True)
+    print(f"inflate_algo {algo} tokens {tokens}: {n_blocks} valid blocks of nine shapes inflate to their input", flush=True)
