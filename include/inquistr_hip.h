@@ -284,6 +284,7 @@ int inq_call_span_staged(inq_ctx_t *ctx, const inq_span_t *span, int slot, inq_r
 int inq_call_span_deferred(inq_ctx_t *ctx, const inq_span_t *span, int slot /* -1: not staged */, inq_span_stats_t *stats);
 int inq_call_flush(inq_ctx_t *ctx, inq_result_t *result, uint64_t n_loci, double *ms_call);
 uint64_t inq_call_deferred_loci(const inq_ctx_t *ctx); /* loci appended since the last flush */
+void inq_call_discard(inq_ctx_t *ctx); /* forgets what was appended (a run that failed between two flushes; a flush, failed or not, does it too) */
 
 /* Test / debug: copies the batch the last inq_call_span (or inq_call_flush) built on the device into caller-allocated HOST
  * arrays sized from that call's stats: cigar[n_cigar_words], reads[n_reads], pair_read[n_pairs],

@@ -550,6 +550,12 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
     dr.pair_bits = nullptr;
     dr.n_tie_loci = 0;
     c->call_hint = std::max<uint32_t>(A.max_reads, 1u);
+    // whatever happens from here on, the batch is spent: a failed flush must not leave its spans for the next file of a session
+    struct Spent {
+        SpanState::Acc &a;
+        ~Spent() { a = SpanState::Acc{a.cigar, a.reads, a.pair_read, a.off, a.lstart, a.lend}; }
+    } spent{A};
+    const uint64_t n_reads_all = A.n_reads, n_units_all = A.n_units, n_pairs_all = A.n_pairs;
     HIP_TRY(c, hipEventRecord(S->ev[4], s));
     if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(S->ev[5], s));
@@ -567,11 +573,10 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
         (void)hipEventElapsedTime(&ms, S->ev[4], S->ev[5]);
         *ms_call = (double)ms;
     }
-    S->n_reads = A.n_reads, S->n_cigar_words = A.n_units * 4, S->n_pairs = A.n_pairs, S->n_loci = nl;
+    S->n_reads = n_reads_all, S->n_cigar_words = n_units_all * 4, S->n_pairs = n_pairs_all, S->n_loci = nl;
     S->last_from_acc = true;  // inq_span_fetch_batch reads the accumulated buffers (their contents stay until the next append)
     r->n_tie_loci = S->h->ks.ties;
-    A = SpanState::Acc{A.cigar, A.reads, A.pair_read, A.off, A.lstart, A.lend};  // buffers kept, counters back to zero
-    return status_to_code(S->h->ks.err);
+    return status_to_code(S->h->ks.err);  // (`spent` puts the counters back to zero, the buffers stay)
 }
 
 // Runs on whatever host thread calls it, on the copy stream; touches only stage[slot] (and ctx->last_err on failure).
@@ -686,6 +691,12 @@ int inq_call_flush(inq_ctx_t *c, inq_result_t *result, uint64_t n_loci, double *
 }
 
 uint64_t inq_call_deferred_loci(const inq_ctx_t *c) { return c && c->span ? c->span->acc.n_loci : 0; }
+
+void inq_call_discard(inq_ctx_t *c) {
+    if (!c || !c->span) return;
+    SpanState::Acc &A = c->span->acc;
+    A = SpanState::Acc{A.cigar, A.reads, A.pair_read, A.off, A.lstart, A.lend};
+}
 
 int inq_span_fetch_batch(inq_ctx_t *c, uint32_t *cigar, inq_read_t *reads, uint32_t *pair_read, uint64_t *locus_pair_off) {
     try {

@@ -53,6 +53,7 @@ ABI_SYMBOLS = (
     "inq_call_span_deferred",
     "inq_call_flush",
     "inq_call_deferred_loci",
+    "inq_call_discard",
     "inq_span_fetch_batch",
     "inq_outlier_rows",
 )
@@ -218,6 +219,8 @@ def load(path: Optional[str] = None):
     L.inq_call_flush.argtypes = [vp, C.POINTER(InqResultC), C.c_uint64, C.POINTER(C.c_double)]
     L.inq_call_deferred_loci.restype = C.c_uint64
     L.inq_call_deferred_loci.argtypes = [vp]
+    L.inq_call_discard.restype = None
+    L.inq_call_discard.argtypes = [vp]
     L.inq_outlier_rows.restype = C.c_int
     L.inq_outlier_rows.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32, vp, vp]
     L.inq_span_fetch_batch.restype = C.c_int
@@ -347,6 +350,9 @@ class Context:
         if rc != INQ_OK and check:
             self._raise(rc)
         return rc, stats
+
+    def call_discard(self) -> None:
+        self._L.inq_call_discard(self._h)
 
     @property
     def deferred_loci(self) -> int:

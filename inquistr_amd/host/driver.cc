@@ -888,6 +888,7 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
             if (!joined) {
                 actx.wait();
                 joined = true;
+                if (hrc == INQ_OK) inq_call_discard(ctx);  // a session's context: nothing of a file that failed half-way stays behind
             }
             if (hrc != INQ_OK) {
                 set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));

@@ -177,3 +177,51 @@ def test_cohort_command_equals_call_per_bam(tmp_path):
         texts.append(str(tmp_path / f"one{k}.inq"))
     comb = subprocess.run([call.CLI_PATH, "combine"] + texts, capture_output=True, text=True)
     assert comb.returncode == 0 and (tmp_path / "all.inq").read_text() == comb.stdout
+
+
+@pytest.mark.parametrize("frontend", ["device", "host"])
+def test_session_survives_a_file_that_fails_on_the_device(tmp_path, frontend):
+    """A file whose failure is only seen on the GPU - a record the reference panics on (HP typed `s`, phased mode: get_phase,
+    src/call.rs:482-491), behind spans that were already appended to the device-resident batch - ends with status 101; the files
+    behind it on the same context are not disturbed (nothing of the failed file's batch stays behind)."""
+    from tools import bamio
+
+    def write(path, bad_at=None, n=60):
+        w = bamio.BamWriter(path, [("chr1", 3_000_000)], block=3000)
+        for k in range(n):
+            pos = 10_000 + 20_000 * k
+            for r in range(8):
+                hp = ("s", 1) if (bad_at == k and r == 3) else ("C", 1 + r % 2)
+                w.add(f"r{k}_{r}", 0, 0, pos - 300, 60, [("M", 400), ("I", 9 + k % 5), ("M", 400)], [("HP", hp[0], hp[1])])
+        w.close()
+
+    good1, bad, good2 = str(tmp_path / "g1.bam"), str(tmp_path / "bad.bam"), str(tmp_path / "g2.bam")
+    write(good1)
+    write(bad, bad_at=45)
+    write(good2, n=50)
+    bed = str(tmp_path / "loci.bed")
+    with open(bed, "w") as f:
+        f.write("".join(f"chr1\t{10_000 + 20_000 * k}\t{10_050 + 20_000 * k}\n" for k in range(60)))
+    env_before = dict(os.environ)
+    os.environ["INQ_SPAN_MB"] = "0"
+    os.environ["INQ_SPAN_GAP_BYTES"] = "0"  # every locus its own segment; with INQ_FLUSH_LOCI the failing span comes behind a flush
+    os.environ["INQ_FLUSH_LOCI"] = "7"
+    try:
+        want = {}
+        for b in (good1, good2):
+            o = tmp_path / (os.path.basename(b) + ".sep")
+            with open(o, "w") as f:
+                call.genotype_repeats(b, None, bed, 5, 3, 2, False, None, None, out=f, frontend=frontend)
+            want[b] = o.read_text()
+        outs = [open(tmp_path / f"o{k}.inq", "w") for k in range(4)]
+        with call.Session(0) as S:
+            st = S.call_many([good1, bad, good2, good1], outs, region_file=bed, threads=2, frontend=frontend)
+        for o in outs:
+            o.close()
+        assert st == [0, 101, 0, 0], (st, S.last_message)
+        assert (tmp_path / "o0.inq").read_text() == want[good1] and (tmp_path / "o3.inq").read_text() == want[good1]
+        assert (tmp_path / "o2.inq").read_text() == want[good2]
+        assert (tmp_path / "o1.inq").read_text() == ""  # the reference panics before it prints with -t >= 2 (rows are collected first)
+    finally:
+        os.environ.clear()
+        os.environ.update(env_before)
