@@ -178,8 +178,9 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * (+18 - 24 % on sequence / quality bytes) or not (CIGAR-only records lose 4.6 % to the wasted look); -1 (default) = decided per
  * call from the code lengths in a few sampled block headers;
  * "inflate_tokens" = 1: the workgroup inflate keeps the symbols its counting passes decode (32 KB of device scratch per BGZF
- * block) so that its commit step does not decode them again; 0 (default) = it decodes again (the stores cost what the second
- * decode did: +3 % on CIGAR-only blocks, -2 ... -5 % on sequence / quality bytes);
+ * block) so that its commit step does not decode them again (+3 - 4 % on match-heavy blocks, -2 ... -5 % on sequence / quality
+ * bytes: the stores cost what the second decode did), 0 = it decodes again, -1 (default) = on for spans whose sampled block
+ * headers say match-heavy;
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);

@@ -475,7 +475,7 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
         return INQ_OK;
     }
     if (std::strcmp(key, "inflate_tokens") == 0) {
-        c->inflate_tokens = value != 0;
+        c->inflate_tokens = value < 0 ? -1 : (value != 0);
         return INQ_OK;
     }
     if (std::strcmp(key, "nt_loads") == 0) {

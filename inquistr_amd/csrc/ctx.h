@@ -40,9 +40,10 @@ struct inq_ctx {
     int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
     bool timing = false;
     bool verify_crc = true;  // device front end: check inflated blocks against their CRC32
-    // workgroup inflate: the counting passes leave the symbols behind for the commit (option "inflate_tokens").  Off: measured
-    // +3 % on CIGAR-only blocks, -2 ... -5 % on sequence / quality bytes, what a real BAM mostly is (profiles/r03_results/)
-    bool inflate_tokens = false;
+    // workgroup inflate: the counting passes leave the symbols behind for the commit (option "inflate_tokens"): +3 ... 4 % on
+    // match-heavy blocks (CIGAR-only records), -2 ... -5 % on sequence / quality bytes (profiles/r03_results/): -1 = on where the
+    // sampled block headers say match-heavy (the same look that picks the symbol loop's form), 0 / 1 = off / on
+    int inflate_tokens = -1;
     int inflate_lit_pairs = -1;  // workgroup inflate's symbol loop: 1 = a second literal from the same peek, 0 = not, -1 = by the data (deflate_probe.h)
     uint32_t inflate_algo = 2;  // 0 = workgroup per BGZF block, 1 = lane per block, 2 = the quicker one (0 since round 2)
     std::vector<inq::EvTriple> ev_pool;

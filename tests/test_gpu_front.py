@@ -12,7 +12,7 @@ from inquistr_amd import hipcall
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[(0, 0, 1), (0, 1, 0), (0, 0, -1), (1, 0, -1)],
+@pytest.fixture(scope="module", params=[(0, 0, 1), (0, 1, 0), (0, -1, -1), (1, 0, -1)],
                 ids=["inflate_wg_literal_pairs", "inflate_wg_no_pairs_commit_from_tokens", "inflate_wg_form_by_the_data", "inflate_lane"])
 def ctx(request):
     """Both inflate kernels go through every test of this file: workgroup per block - its symbol loop with and without the second
