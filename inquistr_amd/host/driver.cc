@@ -935,6 +935,24 @@ static int run_device_front(const inq_call_args_t *args, const CallView &V, Asyn
             if (frc != INQ_EXIT_OK) return frc;
         }
         leak_all = fast_exit;  // only after a clean run: error paths tear down normally
+        if (const char *probe = std::getenv("INQ_EXIT_PROBE")) {
+            // experiment: what does the process's exit pay for?  1 = unmap the span buffers here (the pipeline's destructor) and
+            // time it, 2 = also destroy the device context (every hipFree) and time that; then the fast exit as usual
+            const auto e0 = clk::now();
+            leak_all = false;
+            if (holder.owned) {
+                delete holder.p;
+                holder.owned = false;
+            }
+            const auto e1 = clk::now();
+            std::fprintf(stderr, "[inq exit probe] span pipeline torn down (loader joined, host buffers unmapped): %.2f ms\n", secs(e0, e1) * 1e3);
+            if (probe[0] == '2') {
+                inq_ctx_destroy(ctx);
+                ctx = nullptr;
+                std::fprintf(stderr, "[inq exit probe] device context destroyed: %.2f ms\n", secs(e1, clk::now()) * 1e3);
+            }
+            leak_all = true;
+        }
         if (timing) std::fprintf(stderr, "[inq timing] spans done at %.3fs after the start of the device path\n", secs(t_begin, clk::now()));
     }
     if (timing) std::fprintf(stderr, "[inq timing] loader joined at %.3fs\n", secs(t_begin, clk::now()));
