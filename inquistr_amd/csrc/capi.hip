@@ -485,6 +485,15 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     return INQ_ERR_ARG;
 }
 
+int inq_pin_host(void *p, size_t bytes) {
+    if (!p || !bytes) return INQ_ERR_ARG;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? INQ_OK : INQ_ERR_HIP;
+}
+
+void inq_unpin_host(void *p) {
+    if (p) (void)hipHostUnregister(p);
+}
+
 int inq_alloc_pinned(size_t bytes, void **out) {
     if (!out) return INQ_ERR_ARG;
     *out = nullptr;

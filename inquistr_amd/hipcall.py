@@ -41,6 +41,8 @@ ABI_SYMBOLS = (
     "inq_ctx_set_option",
     "inq_alloc_pinned",
     "inq_free_pinned",
+    "inq_pin_host",
+    "inq_unpin_host",
     "inq_strerror",
     "inq_backend_name",
     "inq_last_error",
@@ -195,6 +197,10 @@ def load(path: Optional[str] = None):
     L.inq_alloc_pinned.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.inq_free_pinned.restype = None
     L.inq_free_pinned.argtypes = [vp]
+    L.inq_pin_host.restype = C.c_int
+    L.inq_pin_host.argtypes = [vp, C.c_size_t]
+    L.inq_unpin_host.restype = None
+    L.inq_unpin_host.argtypes = [vp]
     L.inq_strerror.restype = C.c_char_p
     L.inq_strerror.argtypes = [C.c_int]
     L.inq_backend_name.restype = C.c_char_p

@@ -388,6 +388,7 @@ public:
         size_t cap = 0;
         bool pinned = false;
         int node = -1;       // NUMA node the buffer was mapped for
+        bool registered = false;  // page-locked in place (inq_pin_host) by the uploader
         int slot = 0;        // index of this item: also its device-side staging slot
         bool staged = false; // the loader already uploaded it (inq_span_stage)
     };
@@ -398,9 +399,11 @@ public:
     // and go back to (may be null: mapped and unmapped by the pipeline)
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
                  uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr,
-                 std::function<void()> gate = nullptr, std::function<int()> numa_query = nullptr, int device = 0)
+                 std::function<void()> gate = nullptr, std::function<int()> numa_query = nullptr, int device = 0,
+                 std::function<void()> runtime_gate = nullptr)
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
-          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), numa_query_(std::move(numa_query)), device_(device) {
+          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), gate_registered_(std::move(runtime_gate)),
+          numa_query_(std::move(numa_query)), device_(device) {
         for (int i = 0; i < 3; ++i) slots_[i].slot = slot_base + i;
         for (auto &it : slots_) free_.push_back(&it);
         th_ = std::thread([this] { run(); });
@@ -454,6 +457,10 @@ public:
 
 private:
     void release_buf(Item &it) {
+        if (it.buf && it.registered) {
+            inq_unpin_host(it.buf);
+            it.registered = false;
+        }
         if (it.buf) {
             if (pool_ && (it.pinned || it.node >= 0 || !numa_query_ || numa_query_() < 0)) pool_->give(HostBufPool::B{it.buf, it.cap, it.pinned, it.node});
             else if (it.pinned) inq_free_pinned(it.buf);
@@ -584,6 +591,11 @@ private:
             const auto t0 = std::chrono::steady_clock::now();
             inq_span_t sp;
             fill_span(*it, &sp);
+            if (register_ && !it->registered && !it->pinned && it->buf) {
+                // INQ_SPAN_REGISTER=1 (experiment): the buffer is page-locked where it lies before its first upload
+                if (gate_registered_) gate_registered_();
+                it->registered = inq_pin_host(it->buf, it->cap) == INQ_OK;
+            }
             it->staged = stage_(sp, it->slot);
             if (verbose_)
                 std::fprintf(stderr, "[inq loader] @%.1f slot %d: upload %.2f ms for %.1f MB%s\n", stamp_ms(), it->slot,
@@ -602,6 +614,8 @@ private:
     StageFn stage_;
     HostBufPool *pool_ = nullptr;
     std::function<void()> gate_;
+    bool register_ = std::getenv("INQ_SPAN_REGISTER") && std::getenv("INQ_SPAN_REGISTER")[0] == '1';
+    std::function<void()> gate_registered_;  // waits for the runtime before the first registration
     std::function<int()> numa_query_;  // the GPU's NUMA node, kNumaUnknown while the context is not there yet, -1 = do not place
     int device_ = 0;
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
@@ -806,7 +820,7 @@ static SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamF
                                 if (const char *e = std::getenv("INQ_NUMA_NODE")) return std::atoi(e);
                                 return actx.ready.load() ? actx.numa_node : guess_gpu_numa_node(dev);
                             },
-                            args->device);
+                            args->device, [&actx] { (void)actx.wait(); });
 }
 
 static int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,
