@@ -45,7 +45,11 @@ typedef struct inq_call_args {
 #define INQ_EXIT_PANIC 101 /* the reference's panic!/expect/unwrap paths          */
 
 /* Runs the whole command; writes header + rows to out_fd.  Returns the exit status; a message
- * for non-zero statuses is copied to errbuf (and printed to stderr by the CLI). */
+ * for non-zero statuses is copied to errbuf (and printed to stderr by the CLI).
+ * Side effect worth knowing in a long-lived host process: the threads this call creates for reading, uploading and starting the
+ * HIP runtime (and the helper threads the runtime spawns from the latter) are kept on the CPUs of the GPU's NUMA node and prefer
+ * its memory (uploads run at the PCIe rate only from there); the calling thread is left alone.  INQ_NUMA_NODE=-1 in the
+ * environment switches that off, INQ_NUMA_CPUS=0 keeps the memory preference only. */
 int inq_genotype_repeats(const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap);
 
 /* One process per GPU (inquistr_amd/call_dist.py; the reference's counterpart is the rayon loop over loci, src/call.rs:115-136,
