@@ -293,7 +293,7 @@ __device__ __forceinline__ void root_match(WgLds<T> &L, uint32_t p, uint32_t own
 // Returns the position behind the last decoded symbol (| kStopped / kStopEob).  `bad` collects INQ_INFLATE_* bits.
 // MODE 0 with tok != null also leaves the symbols behind as tokens (tok = this segment's column of the block's token scratch,
 // stride T words): *ntok = how many the chain produced (only the first kTokCap are stored), *mid_tok = how many before `mid`.
-template <int T, int MODE, bool PAIR>
+template <int T, int MODE, int FORM>
 __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, uint32_t seg_end, uint32_t &nbytes, uint8_t *out, uint32_t o,
                                                    uint32_t r0, uint32_t &bad, uint32_t *mid = nullptr, uint32_t *tok = nullptr,
                                                    uint32_t *ntok = nullptr, uint32_t *mid_tok = nullptr) {
@@ -338,6 +338,7 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
         lit = !(e & (E_LEN << 4));
 #endif
         const uint32_t n = e & 15u, xb = (e >> 8) & 15u;  // a literal has no extra bits
+        constexpr bool PAIR = FORM == 1;
         if constexpr (PAIR) {
             if (lit) {
                 // a literal: look at the symbol behind it in the bits already peeked (>= 32 - 15 of them are left) - when that is a
@@ -737,7 +738,7 @@ __device__ __forceinline__ void stage_load(WgLds<T> &L, const uint8_t *payload, 
 #ifndef INQ_WG_WAVES
 #define INQ_WG_WAVES 4
 #endif
-template <int T, bool PAIR>
+template <int T, int FORM>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES, INQ_WG_WAVES))) void bgzf_inflate_wg_kernel(InflateArgs a) {
     __shared__ WgLds<T> L;
     const int tid = (int)threadIdx.x;
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             uint32_t start = tid == 0 ? (P & 31u) : (uint32_t)tid * kSegBits;
             uint32_t nbytes = 0, bad = 0, mid = kNoMid, ntok = 0, mid_tok = 0;
             uint32_t *const tok = a.tokens ? a.tokens + (bi * kTokCap) * (uint64_t)T + (uint32_t)tid : nullptr;
-            uint32_t end = decode_segment<T, 0, PAIR>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
+            uint32_t end = decode_segment<T, 0, FORM>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
             DBG_N(1);
             DBG_N(2);
             // ---- until every chain starts where its left neighbour's ended (lanes behind the first stop do not matter)
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 }
                 if (mismatch) {
                     start = left & 0x3fffffffu;
-                    end = decode_segment<T, 0, PAIR>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
+                    end = decode_segment<T, 0, FORM>(L, start, seg_end, nbytes, nullptr, 0u, 0u, bad, &mid, tok, &ntok, &mid_tok);
                 }
                 DBG_N(2);
                 __syncthreads();  // end_bit[] read by everyone before it is rewritten
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 if (lone) {
                     if ((uint32_t)tid == k0) {
                         uint32_t nb2 = nbytes;
-                        (void)decode_segment<T, 2, PAIR>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
+                        (void)decode_segment<T, 2, FORM>(L, start, seg_end, nb2, out, out0 + off_b, r0, cbad);
                     }
                 } else {
                     // two jobs per segment, dealt over all lanes: the first half of its chain, and the rest from where the chain
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                             continue;
                         }
                         uint32_t nb2 = jn;
-                        (void)decode_segment<T, 1, PAIR>(L, js, je, nb2, out, out0 + jo, r0, cbad);
+                        (void)decode_segment<T, 1, FORM>(L, js, je, nb2, out, out0 + jo, r0, cbad);
                     }
                 }
                 if (cbad) atomicOr(&L.status, cbad);
@@ -1067,9 +1068,11 @@ void launch_bgzf_inflate_wg(const InflateArgs &a, hipStream_t s) {
     // two forms of the symbol loop: a second literal decoded from the same peek (literal-heavy data: sequence / quality
     // bytes, +18 - 24 %), or not (match-heavy data, CIGAR-only records: the second look costs 4.6 % there).  The caller says
     // which (InflateArgs::lit_pairs, from the code lengths of a few sampled block headers: deflate_probe.h); any condition
-    // INSIDE the loop costs more than it saves.
-    if (a.lit_pairs) hipLaunchKernelGGL((bgzf_inflate_wg_kernel<T, true>), dim3((uint32_t)a.n_blocks), dim3(T), 0, s, a);
-    else hipLaunchKernelGGL((bgzf_inflate_wg_kernel<T, false>), dim3((uint32_t)a.n_blocks), dim3(T), 0, s, a);
+    // INSIDE the loop costs more than it saves.  (A third form for match-heavy data - a literal and the length code behind it
+    // in one turn - was worth 1.4 % on CIGAR-only blocks at zlib level 1 and nothing at level 6: not kept,
+    // profiles/r03_results/inflate_literal_length_fusion_ab.txt.)
+    if (a.lit_pairs) hipLaunchKernelGGL((bgzf_inflate_wg_kernel<T, 1>), dim3((uint32_t)a.n_blocks), dim3(T), 0, s, a);
+    else hipLaunchKernelGGL((bgzf_inflate_wg_kernel<T, 0>), dim3((uint32_t)a.n_blocks), dim3(T), 0, s, a);
 }
 
 }  // namespace inq

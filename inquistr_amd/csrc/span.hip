@@ -191,7 +191,7 @@ int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t c
     ia.algo = c->inflate_algo;
     // literal-heavy or match-heavy?  (the host still has the compressed bytes: a few block headers are read; option
     // "inflate_lit_pairs" = 0 / 1 forces a form, -1 = look)
-    ia.lit_pairs = c->inflate_lit_pairs < 0 ? inflate_wants_literal_pairs(comp, comp_bytes, blocks, n_blocks) : (c->inflate_lit_pairs ? 1u : 0u);
+    ia.lit_pairs = c->inflate_lit_pairs < 0 ? inflate_wants_literal_pairs(comp, comp_bytes, blocks, n_blocks) : (uint32_t)c->inflate_lit_pairs;
     ia.tokens = nullptr;
     if (ia.algo != 1u && (c->inflate_tokens < 0 ? ia.lit_pairs == 0u : c->inflate_tokens != 0)) {
         if ((rc = ensure(c, S->tok, inflate_token_words(n_blocks) * 4)) != INQ_OK) return rc;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU box, round 3: literal + length fused in one turn of the loop (form 2) on match-heavy data - correctness and A/B.
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r03s
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+timeout -k 10 900 python3 -m pytest tests/test_gpu_front.py -m gpu -x -q > $OUT/gputest.log 2>&1; echo "pytest rc $?" | tee -a $OUT/gputest.log; tail -4 $OUT/gputest.log
+for lv in 1 6; do for k in cigar seq ont; do
+  for form in 0 2 1; do for tk in 0 1; do
+    echo -n "level $lv $k form=$form tokens=$tk: " | tee -a $OUT/inflate_form2.txt
+    PAIRS=$form TOKENS=$tk ALGO=0 timeout -k 10 200 python3 tools/inflate_bench.py 20000 $lv $k 2>&1 | grep -v amdgpu.ids | tail -1 | sed 's/comp .* kernel/kernel/' | tee -a $OUT/inflate_form2.txt
+  done; done
+done; done
