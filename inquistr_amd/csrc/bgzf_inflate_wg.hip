@@ -972,10 +972,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                             const uint32_t a2 = r2_ - 32768u < kRootLit - 32768u ? L.root[(r2_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r2_;
                             const uint32_t a3 = r3_ - 32768u < kRootLit - 32768u ? L.root[(r3_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r3_;
                             const uint64_t nw = (uint64_t)a0 | ((uint64_t)a1 << 16) | ((uint64_t)a2 << 32) | ((uint64_t)a3 << 48);
-                            if (nw != w) {
-                                __builtin_memcpy(&L.root[4u * g], &nw, 8);
-                                changed = true;
-                            }
+                            if (nw != w) __builtin_memcpy(&L.root[4u * g], &nw, 8);
+                            // another sweep only while a pointer into this stretch is left (not "while something changed": the
+                            // sweep that resolves the last pointers is the last one, nobody has to look again to find nothing)
+                            changed |= (a0 - 32768u < kRootLit - 32768u) | (a1 - 32768u < kRootLit - 32768u) | (a2 - 32768u < kRootLit - 32768u) |
+                                       (a3 - 32768u < kRootLit - 32768u);
                         }
                         if (changed) L.flag = 1u;
                         DBG_N(3);
