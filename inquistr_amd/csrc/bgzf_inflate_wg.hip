@@ -967,14 +967,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                             // a pointer into this stretch takes over what its target holds (a literal, an earlier byte, or a pointer
                             // further back); bytes behind nbytes_s hold stale roots of an earlier stretch: following them is
                             // harmless (bounded index), and nobody reads them
-                            const uint32_t a0 = r0_ - 32768u < kRootLit - 32768u ? L.root[(r0_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r0_;
-                            const uint32_t a1 = r1_ - 32768u < kRootLit - 32768u ? L.root[(r1_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r1_;
-                            const uint32_t a2 = r2_ - 32768u < kRootLit - 32768u ? L.root[(r2_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r2_;
-                            const uint32_t a3 = r3_ - 32768u < kRootLit - 32768u ? L.root[(r3_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r3_;
+                            uint32_t a0 = r0_ - 32768u < kRootLit - 32768u ? L.root[(r0_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r0_;
+                            uint32_t a1 = r1_ - 32768u < kRootLit - 32768u ? L.root[(r1_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r1_;
+                            uint32_t a2 = r2_ - 32768u < kRootLit - 32768u ? L.root[(r2_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r2_;
+                            uint32_t a3 = r3_ - 32768u < kRootLit - 32768u ? L.root[(r3_ - 32768u) & (WgLds<T>::kRoundCap - 1)] : r3_;
                             const uint64_t nw = (uint64_t)a0 | ((uint64_t)a1 << 16) | ((uint64_t)a2 << 32) | ((uint64_t)a3 << 48);
                             if (nw != w) __builtin_memcpy(&L.root[4u * g], &nw, 8);
                             // another sweep only while a pointer into this stretch is left (not "while something changed": the
-                            // sweep that resolves the last pointers is the last one, nobody has to look again to find nothing)
+                            // sweep that resolves the last pointers is the last one, nobody has to look again to find nothing:
+                            // 1 - 3.5 % on all kinds of data; a second hop per sweep where the first lands on a pointer: +-1 %, not kept;
+                            // profiles/r03_results/inflate_sweep_end.txt, inflate_sweep_hop2.txt)
                             changed |= (a0 - 32768u < kRootLit - 32768u) | (a1 - 32768u < kRootLit - 32768u) | (a2 - 32768u < kRootLit - 32768u) |
                                        (a3 - 32768u < kRootLit - 32768u);
                         }
