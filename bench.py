@@ -15,6 +15,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -319,6 +320,28 @@ def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str =
             "note": "CPU modes = oracle/ref_shaped_call: CPU restatement of the reference's control flow, not the Rust binary"}
 
 
+def measured_read_peak():
+    """SURVEY 8(d) prices the kernel against the 8 TB/s spec peak AND against what a pure streaming read reaches on the box:
+    tools/hbm_read_peak.hip (built by __graft_entry__.build()) reads 2.4 GB with the hot kernel's access shape - one wave per
+    24 KB, 16 B per lane, non-temporal - and nothing else; best of 10 launches, HIP events, in a process of its own."""
+    exe = os.path.join(ROOT, "inquistr_amd", "lib", "hbm_read_peak")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    except Exception:  # noqa: BLE001  the line stays valid without it
+        return None
+    best = {}
+    for ln in out.splitlines():
+        f = ln.split()
+        if len(f) >= 4 and f[-1] == "GB/s":
+            best[" ".join(f[:-4])] = float(f[-2])
+    if "locus-shaped nt" not in best:
+        return None
+    return {"value": best["locus-shaped nt"], "unit": "GB/s", "all": best,
+            "what": "pure read of 2.4 GB, one wave per 24 KB segment, 16 B per lane, non-temporal (the hot kernel's shape), best of 10, measured in this run"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -564,6 +587,11 @@ def main():
             },
             "n_tie_loci": ties,
         }
+        if world == 1:
+            pk = measured_read_peak()
+            if pk:
+                line["roofline"]["peak_measured"] = pk
+                line["roofline"]["frac_of_measured"] = achieved / pk["value"]
         if world == 1 and not args.no_cpu_baseline:
             n_s = min(args.cpu_sample_loci, n_mine)
             want, line["cpu_baseline"] = cpu_baseline(wl, n_s)

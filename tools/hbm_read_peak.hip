@@ -54,19 +54,19 @@ int main() {
     u32x4 *buf;
     unsigned *sink;
     if (hipMalloc(&buf, n16 * 16) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) return 1;
-    hipMemset(buf, 1, n16 * 16);
+    (void)hipMemset(buf, 1, n16 * 16);
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
     auto run = [&](const char *name, auto launch) {
         float best = 1e9f;
         for (int rep = 0; rep < 12; ++rep) {
-            hipEventRecord(e0);
+            (void)hipEventRecord(e0);
             launch();
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
             float ms;
-            hipEventElapsedTime(&ms, e0, e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
             if (rep >= 2 && ms < best) best = ms;
         }
         std::printf("%-28s %8.1f us  %7.0f GB/s\n", name, best * 1e3, n16 * 16 / (best * 1e-3) / 1e9);
