@@ -84,7 +84,7 @@ def cpu_baseline(wl, sample_loci: int, budget_s: float = 10.0):
 
 
 def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_loci: int = 10_000, c_loci: int = 2_000, seq: bool = False,
-             level: int = 1):
+             level: int = 1, lean: bool = False):
     """End to end (BAM + BED -> .inq) next to the reference-shaped CPU programs, small enough for the default run.
     Product CLI with the device front end: median of `reps` whole-process wall times (HIP start-up included; the CLI
     leaves through _Exit once the rows are written).  CPU side = oracle/ref_shaped_call, the reference's control flow
@@ -94,7 +94,8 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
     host_cores_available() threads too; outputs are compared byte for byte.
     seq: records shaped like a real long-read BAM (SEQ + QUAL of the query length, NM, ML / MM tags, HP last: ~18 KB per
     record instead of ~0.85 KB; tools/synth_bam_writer.cc inq_synth_write_bam_seq), the shape north_star's ">= 10x the
-    reference CPU inquiSTR call on a synthetic long-read BAM" is about."""
+    reference CPU inquiSTR call on a synthetic long-read BAM" is about.
+    lean: a file of many GB - only the product CLI (device front end), CPU mode B on all granted cores and the stage times."""
     import statistics
     import subprocess
     import tempfile
@@ -134,7 +135,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         dev = [run(cmd, dict(os.environ, INQ_FRONTEND="device")) for _ in range(reps)]
         t_dev = statistics.median(t for t, _ in dev)
         out_dev = dev[0][1]
-        t_host, out_host = run(cmd, dict(os.environ, INQ_FRONTEND="host"))
+        t_host, out_host = (None, None) if lean else run(cmd, dict(os.environ, INQ_FRONTEND="host"))
         rows = out_dev.splitlines(keepends=True)
         bam_bytes = os.path.getsize(prefix + ".bam")
         res = {
@@ -146,8 +147,9 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
             **({"inflated_mb": info["inflated_bytes"] / 1e6, "bgzf_blocks": info["n_blocks"]} if info else {}),
             "gpu_cli_device_front": {"seconds_median": t_dev, "seconds_all": [t for t, _ in dev], "runs": reps,
                                      "loci_per_s": loci / t_dev, "identical_across_runs": all(o == out_dev for _, o in dev)},
-            "gpu_cli_host_front": {"seconds": t_host, "loci_per_s": loci / t_host, "inq_identical": out_host == out_dev},
         }
+        if not lean:
+            res["gpu_cli_host_front"] = {"seconds": t_host, "loci_per_s": loci / t_host, "inq_identical": out_host == out_dev}
         args_tail = [str(int(wl.unphased)), str(wl.minlen), str(wl.support), "S"]
         tb, out_b = run([ref, prefix + ".bam", prefix + ".bed", "B", str(threads)] + args_tail)
         res["cpu_B"] = {"seconds": tb, "loci": loci, "loci_per_s": loci / tb, "cores": threads, "inq_identical": out_b == out_dev}
@@ -158,6 +160,14 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         # the device front end's own stage times for this file (HIP events / host clocks inside the CLI, one extra run)
         r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="2"))
         res["device_front_stages"] = stage_summary(r.stderr.decode(), bam_bytes)
+        if lean:
+            res["inq_identical"] = bool(res["cpu_B"]["inq_identical"] and res.get("cpu_B_all_cores", res["cpu_B"])["inq_identical"])
+            res["speedup_vs_B"] = res["gpu_cli_device_front"]["loci_per_s"] / res["cpu_B"]["loci_per_s"]
+            if "cpu_B_all_cores" in res:
+                res["speedup_vs_B_all_cores"] = res["gpu_cli_device_front"]["loci_per_s"] / res["cpu_B_all_cores"]["loci_per_s"]
+            res["note"] = ("speed-up = ratio of loci/s; cpu_B = oracle/ref_shaped_call mode B (one reader per worker, own BGZF / BAM / BAI reader, "
+                           "no code shared with the product), not the Rust binary")
+            return res
         na, nc = min(a_loci, loci), min(c_loci, loci)
         ta, out_a = run([ref, prefix + ".bam", sub_bed(na), "A", str(threads)] + args_tail)
         res["cpu_A"] = {"seconds": ta, "loci": na, "loci_per_s": na / ta, "cores": threads,
@@ -356,6 +366,8 @@ def main():
     ap.add_argument("--l2-seq-default-loci", type=int, default=6_000,
                     help="loci of the SEQ / QUAL-bearing BAM the default line's l2_seq block is timed on (30 reads x ~18 KB each per locus)")
     ap.add_argument("--no-l2-seq", action="store_true", help="skip the l2_seq block of the default N=1 line")
+    ap.add_argument("--l2-seq-large-loci", type=int, default=40_000,
+                    help="loci of the large SEQ / QUAL-bearing BAM (40 000 = 12.8 GB) of the default line's l2_seq_large block; 0 skips it")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: the workload's n_loci are split over the ranks (config #4: --workload shard500k --scaling strong)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_latest.json"))
@@ -616,6 +628,26 @@ def main():
                 line["l2_seq"] = l2_block(wl.name, min(args.l2_seq_default_loci, wl.n_loci), host_threads(), dev, a_loci=2_000, c_loci=300, seq=True)
             except Exception as e:  # noqa: BLE001
                 line["l2_seq"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_l2 and not args.no_l2_seq and args.l2_seq_large_loci > 0:
+            # ... and on a file large enough for the process's fixed costs (the HIP runtime's start-up, 0.2 - 0.5 s) not to be the
+            # measurement: ~0.32 MB of BAM per locus, generated in /tmp and kept in the page cache like every file here
+            import shutil
+            import tempfile
+
+            need = int(args.l2_seq_large_loci * 0.33e6 * 1.3)
+            free = shutil.disk_usage(tempfile.gettempdir()).free
+            try:
+                avail = int(next(ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")).split()[1]) * 1024
+            except Exception:  # noqa: BLE001
+                avail = 0
+            if free < need or avail < 2 * need:
+                line["l2_seq_large"] = {"skipped": f"needs {need / 1e9:.0f} GB of disk and twice that of memory for the page cache; "
+                                                   f"{free / 1e9:.0f} GB / {avail / 1e9:.0f} GB available"}
+            else:
+                try:
+                    line["l2_seq_large"] = l2_block(wl.name, min(args.l2_seq_large_loci, wl.n_loci), host_threads(), dev, reps=3, seq=True, lean=True)
+                except Exception as e:  # noqa: BLE001
+                    line["l2_seq_large"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
