@@ -38,6 +38,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/inquistr_hip.h"
 #include "front_kernels.h"
 #include "wave_primitives.h"
@@ -505,23 +507,31 @@ __device__ __forceinline__ void wg_scan2(uint32_t a, uint32_t b, uint32_t &ex_a,
 // code-length code's lengths; lanes 0..18 build that code's 7-bit decode table (one symbol each); the workgroup decodes the
 // literal/length and distance code lengths through it into L.lens (header_lengths_wg).
 template <int T>
-__device__ uint32_t header_counts(WgLds<T> &L, SegBits &b) {  // lane 0
+__device__ uint32_t header_counts(WgLds<T> &L, SegBits &b) {  // lane 0; the code-length code's lengths: header_cl_lens, by lanes 0..18
     const uint32_t bits = b.peek();
     const uint32_t hlit = (bits & 31u) + 257u, hdist = ((bits >> 5) & 31u) + 1u, hclen = ((bits >> 10) & 15u) + 4u;
     b.consume(14u);
     if (hlit > 286u || hdist > 30u) return INQ_INFLATE_BAD_HEADER;  // zlib: "too many length or distance symbols"
-    const uint64_t order = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
-                           5ull << 45 | 11ull << 50 | 4ull << 55;
-    const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
-    for (int i = 0; i < 19; ++i) L.cl_len[i] = 0;
-    for (uint32_t i = 0; i < hclen; ++i) {
-        const uint32_t sy = i < 12u ? (uint32_t)(order >> (5u * i)) & 31u : (uint32_t)(order_hi >> (5u * (i - 12u))) & 31u;
-        L.cl_len[sy] = (uint8_t)(b.peek() & 7u);
-        b.consume(3u);
+    for (uint32_t left = 3u * hclen; left;) {  // (consume takes < 32 bits)
+        const uint32_t n = left < 30u ? left : 30u;
+        b.consume(n);
+        left -= n;
     }
     L.hlit = hlit;
     L.hdist = hdist;
     return 0u;
+}
+// lane i < 19 of a dynamic block's header at stage bit p0: the i-th 3-bit field behind the 17 bits of type and counts is the
+// length of code-length symbol order[i] (RFC 1951 3.2.7); fields beyond HCLEN are zero
+template <int T>
+__device__ __forceinline__ void header_cl_lens(WgLds<T> &L, uint32_t p0, uint32_t i) {
+    auto field = [&](uint32_t at, uint32_t mask) { return __builtin_amdgcn_alignbit(L.stage[(at >> 5) + 1u], L.stage[at >> 5], at & 31u) & mask; };
+    const uint32_t hclen = field(p0 + 13u, 15u) + 4u;
+    const uint64_t order = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 | 10ull << 40 |
+                           5ull << 45 | 11ull << 50 | 4ull << 55;
+    const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+    const uint32_t sy = i < 12u ? (uint32_t)(order >> (5u * i)) & 31u : (uint32_t)(order_hi >> (5u * (i - 12u))) & 31u;
+    L.cl_len[sy] = (uint8_t)(i < hclen ? field(p0 + 17u + 3u * i, 7u) : 0u);
 }
 
 template <int T>
@@ -699,29 +709,46 @@ __device__ void build_tables(WgLds<T> &L, int tid) {
         for (int c0 = 0; c0 < nsym; c0 += 64) {
             const int s = c0 + lane;
             const uint32_t n = s < nsym ? L.lens[sbase + s] : 0u;
-            for (uint32_t len = 1; len <= 15u; ++len) {
-                const uint64_t m = ballot64(n == len);
-                if (m == 0ull) continue;
-                const uint32_t r0 = L.run[tbl][len];
-                if (n == len) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    L.sorted[sbase + r0 + rank] = (uint16_t)s;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) L.run[tbl][len] = r0 + (uint32_t)__popcll(m);
-                __builtin_amdgcn_wave_barrier();
+            // the lanes whose symbol has this lane's code length, from four ballots (one per bit of the length) instead of a
+            // turn of the loop per length: every length of the chunk is ranked at once
+            uint64_t m = ~0ull;
+#pragma unroll
+            for (uint32_t bit = 0; bit < 4u; ++bit) {
+                const uint64_t bal = ballot64(((n >> bit) & 1u) != 0u);
+                m &= ((n >> bit) & 1u) ? bal : ~bal;
             }
+            const uint32_t r0 = L.run[tbl][n & 15u];
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (n) L.sorted[sbase + r0 + rank] = (uint16_t)s;
+            __builtin_amdgcn_wave_barrier();  // every lane has read run[] before the first lane of a length moves it on
+            if (n && rank == 0u) L.run[tbl][n] = r0 + (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
-    for (int e = tid; e < (1 << kLitBits); e += T) {
-        const uint32_t v15 = __brev((uint32_t)e) >> 17;
-        L.lut_ll[e] = v15 < L.limit[0][kLitBits] ? canon_entry<T>(L, 0, v15, 1u) : (v15 < L.limit[0][15] ? kLongEntry : kNoCode);
-    }
-    for (int e = tid; e < (1 << kDistBits); e += T) {
-        const uint32_t v15 = __brev((uint32_t)e) >> 17;
-        L.lut_d[e] = v15 < L.limit[1][kDistBits] ? canon_entry<T>(L, 1, v15, 1u) : (v15 < L.limit[1][15] ? kLongEntry : kNoCode);
-    }
+    // an entry's code length is the number of limits its pattern is not below (they grow with the length): the limits are read once,
+    // the count has no dependent LDS read in it
+    auto fill = [&](auto tbl_c, uint32_t *lut, int bits) {
+        constexpr int tbl = decltype(tbl_c)::value;
+        uint32_t lim[16];
+#pragma unroll
+        for (int k = 1; k <= 15; ++k) lim[k] = L.limit[tbl][k];
+        for (int e = tid; e < (1 << bits); e += T) {
+            const uint32_t v15 = __brev((uint32_t)e) >> 17;
+            uint32_t len = 1u;
+#pragma unroll
+            for (int k = 1; k < 15; ++k) len += (k < bits && v15 >= lim[k]) ? 1u : 0u;
+            uint32_t ent = v15 < lim[15] ? kLongEntry : kNoCode;
+            if (v15 < lim[bits]) {
+                const uint32_t idx = L.base[tbl][len] + (v15 >> (15u - len));
+                if (tbl == 0) ent = idx < (uint32_t)kMaxLit ? ll_entry(L.sorted[idx], len) : kNoCode;
+                else ent = idx < (uint32_t)kMaxDist ? dist_entry(L.sorted[kMaxLit + idx], len) : kNoCode;
+            }
+            lut[e] = ent;
+        }
+    };
+    fill(std::integral_constant<int, 0>{}, L.lut_ll, kLitBits);
+    fill(std::integral_constant<int, 1>{}, L.lut_d, kDistBits);
     __syncthreads();
 }
 
@@ -798,6 +825,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             L.P = (P0 & ~31u) + hb.pos;
             if (st) L.status = st;
         }
+        // (whatever the block's type is: the lengths are only used behind a dynamic block's counts)
+        if (tid >= 64 && tid < 64 + 19) header_cl_lens<T>(L, P0 & 31u, (uint32_t)tid - 64u);
         for (int i = tid; i < 128; i += T) L.cl_lut[i] = 0;
         __syncthreads();
         if (L.status) break;
