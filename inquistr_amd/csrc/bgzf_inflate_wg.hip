@@ -768,6 +768,8 @@ __device__ __forceinline__ void stage_load(WgLds<T> &L, const uint8_t *payload, 
 template <int T, int FORM>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES, INQ_WG_WAVES))) void bgzf_inflate_wg_kernel(InflateArgs a) {
     __shared__ WgLds<T> L;
+    constexpr uint32_t LDS_STAGE_BYTES = 4u * (uint32_t)WgLds<T>::kStage;
+    static_assert(LDS_STAGE_BYTES / 128u + 2u <= (uint32_t)T, "one lane per line of the next round's bits");
     const int tid = (int)threadIdx.x;
     const uint64_t bi = blockIdx.x;
     const inq_bgzf_block_t blk = a.blocks[bi];
@@ -933,6 +935,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             __syncthreads();
             DBG_LAP(1);
             if (L.status) break;
+            // where the next round (or the next block's header) will stage its bits from is known now: one dword of each of its
+            // 128-byte lines is asked for here, so that the lines are in L2 when the commit is over and stage_load wants them
+            // (the value is looked at behind the commit, which keeps the load; nothing depends on it)
+            uint32_t warm = 0;
+            if (tid < (int)(LDS_STAGE_BYTES / 128u + 2u)) {
+                const uint8_t *p = payload + 4ull * (uint64_t)(L.P >> 5) + 128ull * (uint32_t)tid;
+                warm = ld_u32(p < hard ? p : hard);
+            }
             // ---- commit, in stretches of lanes whose bytes fit the root array: the round is counted once, whatever it inflates to
             uint32_t k0 = 0;
             while (k0 < ncommit) {
@@ -1049,6 +1059,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
                 DBG_LAP(3);
                 k0 = k1;
             }
+            if (warm == 0x9e3779b9u) atomicOr(&L.flag, 0u);  // (no effect: it only makes the early load's value used)
             if (L.status) break;
             if (L.eob) break;
             if (L.P > payload_bits) {  // a round that ran off the payload without meeting end-of-block
