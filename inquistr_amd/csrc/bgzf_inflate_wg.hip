@@ -48,6 +48,9 @@ namespace inq {
 
 namespace {
 
+#ifndef INQ_WG_T
+#define INQ_WG_T 128
+#endif
 #ifndef INQ_WG_LITBITS
 #define INQ_WG_LITBITS 10
 #endif
@@ -57,6 +60,9 @@ namespace {
 constexpr int kLitBits = INQ_WG_LITBITS, kDistBits = INQ_WG_DISTBITS;
 #ifndef INQ_WG_LITFIRST
 #define INQ_WG_LITFIRST 1
+#endif
+#ifndef INQ_WG_STRETCH_SEGS
+#define INQ_WG_STRETCH_SEGS (INQ_WG_T / 2)
 #endif
 #ifndef INQ_WG_SEGBITS
 #define INQ_WG_SEGBITS 256
@@ -948,7 +954,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(INQ_WG_WAVES,
             while (k0 < ncommit) {
                 const uint32_t r_lo = L.off_sh[k0];
                 // k1 = first lane at or behind k0 whose bytes end beyond the array
-                const bool over = (uint32_t)tid >= k0 && (uint32_t)tid < ncommit && off_b + nbytes - r_lo > (uint32_t)WgLds<T>::kRoundCap;
+                // ... or, on data that hardly inflates, the first one that would make the stretch longer than T / 2 segments: two
+                // jobs per segment are then one job per lane, where a longer stretch has some lanes do two in a row while the
+                // others wait
+                const bool over = (uint32_t)tid >= k0 && (uint32_t)tid < ncommit &&
+                                  (off_b + nbytes - r_lo > (uint32_t)WgLds<T>::kRoundCap || (uint32_t)tid >= k0 + (uint32_t)INQ_WG_STRETCH_SEGS);
                 uint32_t k1 = wg_first<T>(over, L.red, L.red2);
                 const bool lone = k1 == k0;  // a single lane exceeds the array: it writes its literals and matches in order by itself
                 if (k1 == 0xffffu) k1 = ncommit;
