@@ -2,7 +2,7 @@
 # GPU box, round 3: finer clock probe of the workgroup inflate (scratch build): lane 0's own decode / job time against the waits.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r03p2
+OUT=$ROOT/gpurun_out/r03p3
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
