@@ -362,6 +362,7 @@ def main():
     ap.add_argument("--cpu-sample-loci", type=int, default=20_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-l2", action="store_true", help="skip the end-to-end block of the default N=1 line")
+    ap.add_argument("--no-read-peak", action="store_true", help="skip the pure-read ceiling run (a child process; not wanted under a profiler)")
     ap.add_argument("--l2-default-loci", type=int, default=100_000, help="loci of the BAM the default line's l2 block is timed on")
     ap.add_argument("--l2-seq-default-loci", type=int, default=6_000,
                     help="loci of the SEQ / QUAL-bearing BAM the default line's l2_seq block is timed on (30 reads x ~18 KB each per locus)")
@@ -599,7 +600,7 @@ def main():
             },
             "n_tie_loci": ties,
         }
-        if world == 1:
+        if world == 1 and not args.no_read_peak:
             pk = measured_read_peak()
             if pk:
                 line["roofline"]["peak_measured"] = pk
