@@ -160,6 +160,34 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         # the device front end's own stage times for this file (HIP events / host clocks inside the CLI, one extra run)
         r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="2"))
         res["device_front_stages"] = stage_summary(r.stderr.decode(), bam_bytes)
+        # the same command, handed to a process that already holds the device context (`inquistr serve`; `inquistr call` with
+        # INQ_SERVER set passes its arguments and its stdout to it): what a file costs in a pipeline that starts one process per
+        # sample, without the HIP runtime's start-up and the exit of a process that mapped GBs.  Whole client process, start to exit.
+        try:
+            sock = os.path.join(tmp, "inq.sock")
+            server = subprocess.Popen([cli, "serve", "--socket", sock, "--idle-exit", "300"], env=dict(os.environ, INQ_FRONTEND="device"),
+                                      stderr=subprocess.DEVNULL)
+            try:
+                for _ in range(400):
+                    if os.path.exists(sock):
+                        break
+                    time.sleep(0.025)
+                env_s = dict(os.environ, INQ_SERVER=sock)
+                run(cmd, env_s)  # the context's start-up is the first caller's
+                sv = [run(cmd, env_s) for _ in range(reps)]
+                t_sv = statistics.median(t for t, _ in sv)
+                res["gpu_cli_served"] = {"seconds_median": t_sv, "seconds_all": [t for t, _ in sv], "runs": reps, "loci_per_s": loci / t_sv,
+                                         "inq_identical": all(o == out_dev for _, o in sv),
+                                         "note": "inquistr call with INQ_SERVER=<socket of a running `inquistr serve`>: same CLI, the device context is resident"}
+                res["speedup_served_vs_B"] = res["gpu_cli_served"]["loci_per_s"] / res["cpu_B"]["loci_per_s"]
+                subprocess.run([cli, "serve", "--socket", sock, "--quit"], capture_output=True)
+                server.wait(timeout=60)
+            finally:
+                if server.poll() is None:
+                    server.kill()
+                    server.wait(timeout=60)
+        except Exception as e:  # noqa: BLE001
+            res["gpu_cli_served"] = {"error": f"{type(e).__name__}: {e}"}
         if lean:
             res["inq_identical"] = bool(res["cpu_B"]["inq_identical"] and res.get("cpu_B_all_cores", res["cpu_B"])["inq_identical"])
             res["speedup_vs_B"] = res["gpu_cli_device_front"]["loci_per_s"] / res["cpu_B"]["loci_per_s"]

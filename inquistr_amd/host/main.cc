@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/inquistr_host.h"
+#include "serve.h"
 
 static void usage(FILE *f) {
     std::fputs(
@@ -167,12 +168,46 @@ int main(int argc, char **argv) {
         inq_session_close(S);
         return rc;
     }
+    if (argc >= 2 && std::strcmp(argv[1], "serve") == 0) {
+        // Not a subcommand of the reference: a process that keeps the device context, so that `inquistr call` - one process per
+        // sample, as workflow managers start it - does not pay the HIP runtime's start-up (0.1 - 0.4 s) per file.  `call` hands
+        // its arguments and its stdout to the server named by INQ_SERVER=<socket>; without one it runs as always.
+        std::string sock;
+        int device = 0;
+        double idle = 0.0;
+        for (int i = 2; i < argc; ++i) {
+            const std::string k = argv[i];
+            auto val = [&]() -> const char * {
+                if (i + 1 >= argc) {
+                    std::fprintf(stderr, "error: a value is required for '%s' but none was supplied\n", argv[i]);
+                    std::exit(2);
+                }
+                return argv[++i];
+            };
+            if (k == "--socket") sock = val();
+            else if (k == "--device") device = (int)std::strtol(val(), nullptr, 10);
+            else if (k == "--idle-exit") idle = std::strtod(val(), nullptr);
+            else if (k == "--quit") {
+                if (sock.empty()) sock = std::getenv("INQ_SERVER") ? std::getenv("INQ_SERVER") : "";
+                return inq::client_quit(sock.c_str()) ? 0 : 1;
+            } else {
+                std::fprintf(stderr, "error: unexpected argument '%s' found\n", k.c_str());
+                return 2;
+            }
+        }
+        if (sock.empty()) {
+            std::fputs("Usage: inquistr serve --socket PATH [--device N] [--idle-exit SECONDS]\n       inquistr serve --socket PATH --quit\n", stderr);
+            return 2;
+        }
+        ::setenv("INQ_FAST_EXIT", "1", 0);
+        return inq::serve_main(sock.c_str(), device, idle);
+    }
     if (argc < 2 || std::strcmp(argv[1], "call") != 0) {
         if (argc >= 2 && (!std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help"))) {
             std::puts("Tool to genotype STRs from long reads (MI355X build: `call` only)\n\nUsage: inquistr call [OPTIONS] <BAM>");
             return 0;
         }
-        std::fputs("error: this build provides the `call`, `combine`, `outlier` (and `cohort`: many `call`s in one process) subcommands only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
+        std::fputs("error: this build provides the `call`, `combine`, `outlier` (and `cohort`: many `call`s in one process; `serve`: a process that keeps the device context for `call`s with INQ_SERVER set) subcommands only\n\nUsage: inquistr call [OPTIONS] <BAM>\n", stderr);
         return 2;
     }
     if (argc == 2) {  // arg_required_else_help
@@ -235,6 +270,20 @@ int main(int argc, char **argv) {
         return 2;
     }
     a.bam = bam.c_str();
+    if (const char *server = std::getenv("INQ_SERVER"); server && *server) {
+        int st = 0;
+        std::string msg;
+        const int got = inq::client_call(server, &a, 1 /* stdout */, &st, &msg);
+        if (got > 0) {
+            if (st != 0) std::fprintf(stderr, st == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", msg.c_str());
+            return st;
+        }
+        if (got < 0) {
+            std::fprintf(stderr, "the server at %s went away during the call\n", server);
+            return 1;
+        }
+        // no server there: the call runs here, as without INQ_SERVER
+    }
     char err[1024] = {0};
     ::setenv("INQ_FAST_EXIT", "1", 0);  // this process ends with the call: see run_device_front
     int rc = inq_genotype_repeats(&a, 1 /* stdout */, err, sizeof err);

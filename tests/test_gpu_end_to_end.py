@@ -5,6 +5,7 @@ byte for byte."""
 import functools
 import os
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -225,3 +226,56 @@ def test_session_survives_a_file_that_fails_on_the_device(tmp_path, frontend):
     finally:
         os.environ.clear()
         os.environ.update(env_before)
+
+
+def test_call_through_a_resident_server_equals_call(tmp_path):
+    """`inquistr serve` keeps the device context; `inquistr call` with INQ_SERVER set hands it the arguments (relative paths made
+    absolute) and its stdout: same bytes, same exit status and message as the call run by itself - also for a file the reference
+    panics on, after which the server still answers -, and without a server at that address the call runs by itself."""
+    from tools import make_synth_bam
+
+    prefixes = []
+    for k in range(3):
+        prefix = str(tmp_path / f"s{k}")
+        make_synth_bam.write_native("unphased100k" if k != 1 else "phased10k", 400 + 100 * k, prefix, threads=4)
+        prefixes.append(prefix)
+    sock = str(tmp_path / "inq.sock")
+    env_direct = dict(os.environ, INQ_FRONTEND="device")
+    env_direct.pop("INQ_SERVER", None)
+    env_served = dict(env_direct, INQ_SERVER=sock)
+    # no server yet: the call runs by itself
+    alone = subprocess.run([call.CLI_PATH, "call", prefixes[0] + ".bam", "-R", prefixes[0] + ".bed", "-u", "-t", "4"], capture_output=True,
+                           text=True, env=env_served)
+    assert alone.returncode == 0 and alone.stdout.count("\n") == 401
+    server = subprocess.Popen([call.CLI_PATH, "serve", "--socket", sock, "--idle-exit", "120"], env=env_direct, stderr=subprocess.PIPE, text=True)
+    try:
+        for _ in range(200):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        assert os.path.exists(sock)
+        for rep in range(2):
+            for k, p in enumerate(prefixes):
+                flags = ["-t", "4"] + ([] if k == 1 else ["-u"])
+                want = subprocess.run([call.CLI_PATH, "call", p + ".bam", "-R", p + ".bed"] + flags, capture_output=True, text=True, env=env_direct)
+                got = subprocess.run([call.CLI_PATH, "call", os.path.basename(p) + ".bam", "-R", os.path.basename(p) + ".bed"] + flags,
+                                     capture_output=True, text=True, env=env_served, cwd=str(tmp_path))
+                assert want.returncode == 0 and got.returncode == 0, (want.stderr, got.stderr)
+                assert got.stdout == want.stdout and got.stdout.count("\n") == 401 + 100 * k
+        # errors travel: a missing file (exit 1), a locus on an unknown contig (the reference's panic, exit 101)
+        for args in (["nope.bam", "-R", prefixes[0] + ".bed"], [prefixes[0] + ".bam", "-r", "chrNope:100-200"]):
+            want = subprocess.run([call.CLI_PATH, "call"] + args, capture_output=True, text=True, env=env_direct, cwd=str(tmp_path))
+            got = subprocess.run([call.CLI_PATH, "call"] + args, capture_output=True, text=True, env=env_served, cwd=str(tmp_path))
+            assert got.returncode == want.returncode != 0 and got.stdout == want.stdout
+            if "-r" in args:  # (the other message names the file, by the path each side was given)
+                assert got.stderr.strip().splitlines()[-1] == want.stderr.strip().splitlines()[-1]
+        again = subprocess.run([call.CLI_PATH, "call", prefixes[2] + ".bam", "-R", prefixes[2] + ".bed", "-u"], capture_output=True, text=True, env=env_served)
+        assert again.returncode == 0 and again.stdout.count("\n") == 601
+        quit_ = subprocess.run([call.CLI_PATH, "serve", "--socket", sock, "--quit"], capture_output=True, text=True)
+        assert quit_.returncode == 0
+        assert server.wait(timeout=30) == 0
+        assert "leaving after 9 calls" in server.stderr.read()
+    finally:
+        if server.poll() is None:
+            server.kill()
+            server.wait(timeout=30)
