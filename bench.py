@@ -180,6 +180,23 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                                          "inq_identical": all(o == out_dev for _, o in sv),
                                          "note": "inquistr call with INQ_SERVER=<socket of a running `inquistr serve`>: same CLI, the device context is resident"}
                 res["speedup_served_vs_B"] = res["gpu_cli_served"]["loci_per_s"] / res["cpu_B"]["loci_per_s"]
+                # ... and with callers queueing (a workflow manager starts several at once): the server stages file k + 1 while it
+                # calls file k; 8 callers started together, wall time until the last has left
+                n_par = 8
+                t = time.perf_counter()
+                # (stdout into files: the server writes a caller's rows while the others wait their turn; pipes read one after the
+                # other by this process would fill up and stall the queue)
+                fs = [open(os.path.join(tmp, f"par{i}.inq"), "wb") for i in range(n_par)]
+                ps = [subprocess.Popen(cmd, env=env_s, stdout=fs[i], stderr=subprocess.DEVNULL) for i in range(n_par)]
+                for p in ps:
+                    p.wait(timeout=300)
+                dt_par = time.perf_counter() - t
+                for f in fs:
+                    f.close()
+                outs = [open(os.path.join(tmp, f"par{i}.inq"), "rb").read() for i in range(n_par)]
+                res["gpu_cli_served"]["callers_at_once"] = {"callers": n_par, "seconds_all_done": dt_par, "seconds_per_file": dt_par / n_par,
+                                                             "loci_per_s": loci * n_par / dt_par, "inq_identical": all(o == out_dev for o in outs),
+                                                             "speedup_vs_B": (loci * n_par / dt_par) / res["cpu_B"]["loci_per_s"]}
                 subprocess.run([cli, "serve", "--socket", sock, "--quit"], capture_output=True)
                 server.wait(timeout=60)
             finally:

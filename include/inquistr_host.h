@@ -95,6 +95,15 @@ int inq_session_open(int32_t device, inq_session_t **out); /* returns at once; t
 int inq_session_call(inq_session_t *s, const inq_call_args_t *args, int out_fd, char *errbuf, size_t errcap);
 int inq_session_call_many(inq_session_t *s, const inq_call_args_t *args, size_t n, const int *out_fds, int *statuses, char *errbuf, size_t errcap);
 void inq_session_close(inq_session_t *s);
+/* The two halves of inq_session_call, for a caller that receives its files one by one (`inquistr serve`): inq_session_stage opens the
+ * BAM, validates the targets, plans the spans and starts reading and uploading them - it may run on another thread while the file
+ * before is inside inq_session_run -; inq_session_run does the calling and writes the .inq (and reports what staging found wrong),
+ * and frees the handle.  At most ONE file may be staged ahead of the one that is running; files run in the order they were staged.
+ * inq_session_discard drops a staged file that will not be run. */
+typedef struct inq_staged inq_staged_t;
+int inq_session_stage(inq_session_t *s, const inq_call_args_t *args, inq_staged_t **out);
+int inq_session_run(inq_session_t *s, inq_staged_t *staged, int out_fd, char *errbuf, size_t errcap);
+void inq_session_discard(inq_staged_t *staged);
 
 /* ---- BAM -> batch front end (no GPU involved) ---- */
 typedef struct inq_frontend inq_frontend_t;

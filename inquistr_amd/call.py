@@ -36,6 +36,9 @@ HOST_ABI_SYMBOLS = (
     "inq_session_call",
     "inq_session_call_many",
     "inq_session_close",
+    "inq_session_stage",
+    "inq_session_run",
+    "inq_session_discard",
     "inq_combine",
     "inq_frontend_open",
     "inq_frontend_n_targets",

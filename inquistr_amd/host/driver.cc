@@ -1583,6 +1583,7 @@ void inq_run_close(inq_run_t *r) { delete r; }
 struct inq_session {
     AsyncCtx actx;
     HostBufPool pool;
+    uint64_t n_staged = 0;  // inq_session_stage: which of the two sets of device slots the next file takes
 };
 
 namespace {
@@ -1690,6 +1691,31 @@ static int inq_session_call_many_impl(inq_session_t *S, const inq_call_args_t *a
 int inq_session_call_many(inq_session_t *S, const inq_call_args_t *args, size_t n, const int *out_fds, int *statuses, char *errbuf, size_t errcap) {
     INQ_GUARD(inq_session_call_many_impl(S, args, n, out_fds, statuses, errbuf, errcap), errbuf, errcap)
 }
+
+struct inq_staged {
+    StagedFile f;
+};
+int inq_session_stage(inq_session_t *S, const inq_call_args_t *args, inq_staged_t **out) {
+    if (!S || !args || !out) return INQ_EXIT_ERROR;
+    *out = nullptr;
+    try {
+        std::unique_ptr<inq_staged> st(new inq_staged());
+        stage_file(S, args, 3 * (int)(S->n_staged++ & 1u), st->f);  // what it finds wrong is reported by inq_session_run
+        *out = st.release();
+        return INQ_EXIT_OK;
+    } catch (...) {
+        return INQ_EXIT_ERROR;
+    }
+}
+static int inq_session_run_impl(inq_session_t *S, inq_staged_t *st, int out_fd, char *errbuf, size_t errcap) {
+    if (!S || !st) return INQ_EXIT_ERROR;
+    std::unique_ptr<inq_staged> own(st);
+    return run_staged(S, own->f, out_fd, errbuf, errcap);
+}
+int inq_session_run(inq_session_t *S, inq_staged_t *st, int out_fd, char *errbuf, size_t errcap) {
+    INQ_GUARD(inq_session_run_impl(S, st, out_fd, errbuf, errcap), errbuf, errcap)
+}
+void inq_session_discard(inq_staged_t *st) { delete st; }
 
 void inq_session_close(inq_session_t *S) {
     if (!S) return;

@@ -16,7 +16,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace inq {
@@ -197,63 +202,138 @@ int serve_main(const char *socket_path, int device, double idle_exit_s) {
         return 1;
     }
     std::fprintf(stderr, "serve: listening on %s (device %d)\n", socket_path, device);
-    auto last = std::chrono::steady_clock::now();
+    // Two threads: the FRONT one accepts a caller, reads its request and stages the file (opens it, validates the targets, plans
+    // the spans, starts reading and uploading them) as soon as the file staged before it has been taken; THIS one takes staged
+    // files in order, runs them and answers.  With callers queueing - a workflow manager starts several at once - file k + 1 is
+    // staged while file k is called, as inside inq_session_call_many.
+    struct Item {
+        int cs = -1, out_fd = -1;
+        inq_staged_t *staged = nullptr;
+        bool quit = false;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    Item *box = nullptr;  // the one staged item waiting for the runner
+    bool front_done = false;
+    std::atomic<bool> running{false};
+    std::thread front([&] {
+        auto last = std::chrono::steady_clock::now();
+        for (;;) {
+            if (g_stop) break;
+            pollfd pf{ls, POLLIN, 0};
+            const int pr = ::poll(&pf, 1, 200);
+            if (pr <= 0) {
+                bool idle;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    idle = box == nullptr && !running.load();
+                }
+                if (!idle) last = std::chrono::steady_clock::now();  // a call is waiting or running: not idle
+                else if (idle_exit_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - last).count() > idle_exit_s) break;
+                continue;
+            }
+            const int cs = ::accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
+            if (cs < 0) continue;
+            uint32_t magic = 0, body_len = 0;
+            int out_fd = -1;
+            if (!recv_header(cs, magic, body_len, out_fd)) {
+                ::close(cs);
+                continue;
+            }
+            std::unique_ptr<Item> it(new Item());
+            it->cs = cs, it->out_fd = out_fd;
+            bool bad = false;
+            if (magic == kMagicQuit) it->quit = true;
+            else {
+                std::vector<char> body(body_len <= kMaxBody ? body_len : 0);
+                bad = magic != kMagicCall || body_len > kMaxBody || out_fd < 0 || !read_all(cs, body.data(), body.size());
+                Reader rd{body.data(), body.data() + body.size()};
+                inq_call_args_t a;
+                std::memset(&a, 0, sizeof a);
+                std::string s[5];
+                bool have[5] = {false, false, false, false, false};
+                if (!bad) {
+                    a.minlen = rd.get<uint32_t>();
+                    a.support = rd.get<uint64_t>();
+                    a.threads = rd.get<uint64_t>();
+                    a.unphased = rd.get<char>() ? 1 : 0;
+                    a.device = device;  // the context this server holds
+                    for (int k = 0; k < 5 && rd.ok; ++k) rd.str(s[k], have[k]);
+                    bad = !rd.ok || !have[0];
+                }
+                if (bad) {
+                    answer(cs, INQ_EXIT_ERROR, "serve: malformed request");
+                    ::close(cs);
+                    if (out_fd >= 0) ::close(out_fd);
+                    continue;
+                }
+                a.bam = s[0].c_str();
+                a.region = have[1] ? s[1].c_str() : nullptr;
+                a.region_file = have[2] ? s[2].c_str() : nullptr;
+                a.sample_name = have[3] ? s[3].c_str() : nullptr;
+                a.reference = have[4] ? s[4].c_str() : nullptr;
+                {   // at most one file staged ahead of the one that runs: wait until the runner has taken the one before
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return box == nullptr; });
+                }
+                if (inq_session_stage(S, &a, &it->staged) != 0) it->staged = nullptr;  // (the strings are copied by the staging)
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return box == nullptr; });
+                box = it.release();
+            }
+            cv.notify_all();
+            last = std::chrono::steady_clock::now();
+            if (magic == kMagicQuit) break;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            front_done = true;
+        }
+        cv.notify_all();
+    });
     uint64_t served = 0;
-    while (!g_stop) {
-        pollfd pf{ls, POLLIN, 0};
-        const int pr = ::poll(&pf, 1, 200);
-        if (pr <= 0) {
-            if (idle_exit_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - last).count() > idle_exit_s) break;
-            continue;
+    for (;;) {
+        Item *it = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return box != nullptr || front_done; });
+            it = box;
+            box = nullptr;
         }
-        const int cs = ::accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
-        if (cs < 0) continue;
-        uint32_t magic = 0, body_len = 0;
-        int out_fd = -1;
-        if (!recv_header(cs, magic, body_len, out_fd)) {
-            ::close(cs);
-            continue;
-        }
-        if (magic == kMagicQuit) {
-            answer(cs, 0, "");
-            ::close(cs);
-            if (out_fd >= 0) ::close(out_fd);
-            break;
-        }
-        std::vector<char> body(body_len <= kMaxBody ? body_len : 0);
-        if (magic != kMagicCall || body_len > kMaxBody || out_fd < 0 || !read_all(cs, body.data(), body.size())) {
-            answer(cs, INQ_EXIT_ERROR, "serve: malformed request");
-            ::close(cs);
-            if (out_fd >= 0) ::close(out_fd);
-            continue;
-        }
-        Reader rd{body.data(), body.data() + body.size()};
-        inq_call_args_t a;
-        std::memset(&a, 0, sizeof a);
-        a.minlen = rd.get<uint32_t>();
-        a.support = rd.get<uint64_t>();
-        a.threads = rd.get<uint64_t>();
-        a.unphased = rd.get<char>() ? 1 : 0;
-        a.device = device;  // the context this server holds
-        std::string s[5];
-        bool have[5] = {false, false, false, false, false};
-        for (int k = 0; k < 5 && rd.ok; ++k) rd.str(s[k], have[k]);
-        if (!rd.ok || !have[0]) {
-            answer(cs, INQ_EXIT_ERROR, "serve: malformed request");
+        cv.notify_all();  // the front thread may stage the next file now
+        if (!it) break;   // the front thread is gone and nothing is waiting
+        if (it->quit) {
+            answer(it->cs, 0, "");
+        } else if (!it->staged) {
+            answer(it->cs, INQ_EXIT_ERROR, "serve: the file could not be staged");
         } else {
-            a.bam = s[0].c_str();
-            a.region = have[1] ? s[1].c_str() : nullptr;
-            a.region_file = have[2] ? s[2].c_str() : nullptr;
-            a.sample_name = have[3] ? s[3].c_str() : nullptr;
-            a.reference = have[4] ? s[4].c_str() : nullptr;
             char err[1024] = {0};
-            const int rc = inq_session_call(S, &a, out_fd, err, sizeof err);
-            answer(cs, rc, err);
+            running.store(true);
+            const int rc = inq_session_run(S, it->staged, it->out_fd, err, sizeof err);
+            running.store(false);
+            answer(it->cs, rc, err);
             ++served;
         }
-        ::close(out_fd);
-        ::close(cs);
-        last = std::chrono::steady_clock::now();
+        if (it->out_fd >= 0) ::close(it->out_fd);
+        ::close(it->cs);
+        const bool quit = it->quit;
+        delete it;
+        if (quit) break;
+    }
+    g_stop = 1;
+    {   // a file the front thread staged after the quit was taken (it cannot: quit ends it) - or is staging right now
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait_for(lk, std::chrono::seconds(5), [&] { return front_done; });
+    }
+    front.join();
+    if (box) {  // staged, never run
+        if (box->staged) inq_session_discard(box->staged);
+        answer(box->cs, INQ_EXIT_ERROR, "serve: the server is leaving");
+        if (box->out_fd >= 0) ::close(box->out_fd);
+        ::close(box->cs);
+        delete box;
     }
     ::close(ls);
     ::unlink(socket_path);

@@ -271,10 +271,29 @@ def test_call_through_a_resident_server_equals_call(tmp_path):
                 assert got.stderr.strip().splitlines()[-1] == want.stderr.strip().splitlines()[-1]
         again = subprocess.run([call.CLI_PATH, "call", prefixes[2] + ".bam", "-R", prefixes[2] + ".bed", "-u"], capture_output=True, text=True, env=env_served)
         assert again.returncode == 0 and again.stdout.count("\n") == 601
+        # six callers at once (a workflow manager's way): they queue, file k + 1 is staged while file k is called, every one gets its own rows
+        procs = []
+        for k in (0, 1, 2, 2, 1, 0):
+            flags = ["-t", "4"] + ([] if k == 1 else ["-u"])
+            # (stdout into a file: rows of a caller whose pipe nobody reads yet would stall the server's queue)
+            f = open(tmp_path / f"par{len(procs)}.inq", "w")
+            procs.append((k, f, subprocess.Popen([call.CLI_PATH, "call", prefixes[k] + ".bam", "-R", prefixes[k] + ".bed"] + flags, stdout=f,
+                                                 stderr=subprocess.PIPE, text=True, env=env_served)))
+        wants = {}
+        for k, f, pr in procs:
+            _, err = pr.communicate(timeout=120)
+            assert pr.returncode == 0, err
+            f.close()
+            out = open(f.name).read()
+            if k not in wants:
+                flags = ["-t", "4"] + ([] if k == 1 else ["-u"])
+                wants[k] = subprocess.run([call.CLI_PATH, "call", prefixes[k] + ".bam", "-R", prefixes[k] + ".bed"] + flags, capture_output=True,
+                                          text=True, env=env_direct).stdout
+            assert out == wants[k]
         quit_ = subprocess.run([call.CLI_PATH, "serve", "--socket", sock, "--quit"], capture_output=True, text=True)
         assert quit_.returncode == 0
         assert server.wait(timeout=30) == 0
-        assert "leaving after 9 calls" in server.stderr.read()
+        assert "leaving after 15 calls" in server.stderr.read()
     finally:
         if server.poll() is None:
             server.kill()
