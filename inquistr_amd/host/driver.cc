@@ -69,7 +69,20 @@ struct Prepared {
 };
 
 // src/call.rs:87-102 + get_targets :182-202.  Returns an exit status.
-int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg) {
+// A cohort is called with ONE BED: inside a session (inquistr cohort / serve) the parsed and validated target list of the last BED is
+// kept and taken again when the file is the same (device, inode, size, modification time) and the BAM's contigs are (names and lengths
+// decide every check of from_bed, src/repeats.rs:96-115).  100 000 targets: 12 - 25 ms of a 70 ms call.
+struct BedCache {
+    std::mutex mu;
+    std::string path;
+    uint64_t dev = 0, ino = 0, size = 0;
+    int64_t mtime_ns = 0;
+    std::map<std::string, uint64_t> lengths;
+    TargetsResult tr;
+    bool valid = false;
+};
+
+int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg, BedCache *bed_cache = nullptr) {
     if (!a || !a->bam) {
         msg = "no BAM given";
         return INQ_EXIT_ERROR;
@@ -90,6 +103,7 @@ int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg) {
     }
     P.sample = a->sample_name ? std::string(a->sample_name) : sample_name_from_path(bamp);  // :91-100
     // get_chrom_lengths_from_bam_header opens the BAM before the target arguments are looked at (:187)
+    const auto t_open = std::chrono::steady_clock::now();
     P.bam.reset(new BamFile(1));  // header + index; with -t > 1 every sweep worker opens its own reader
     std::string e;
     if (!P.bam->open(bamp, &e)) {
@@ -101,12 +115,31 @@ int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg) {
         msg = e;
         return INQ_EXIT_PANIC;
     }
+    const auto t_targets = std::chrono::steady_clock::now();
     TargetsResult tr;
     if (a->region && !a->region_file)
         tr = targets_from_string(a->region, lengths);  // :190
-    else if (!a->region && a->region_file)
-        tr = targets_from_bed(a->region_file, lengths);  // :192-195
-    else {
+    else if (!a->region && a->region_file) {
+        struct stat sb;
+        const bool have_stat = bed_cache && ::stat(a->region_file, &sb) == 0;
+        bool hit = false;
+        if (have_stat) {
+            std::lock_guard<std::mutex> lk(bed_cache->mu);
+            hit = bed_cache->valid && bed_cache->path == a->region_file && bed_cache->dev == (uint64_t)sb.st_dev && bed_cache->ino == (uint64_t)sb.st_ino &&
+                  bed_cache->size == (uint64_t)sb.st_size &&
+                  bed_cache->mtime_ns == (int64_t)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec && bed_cache->lengths == lengths;
+            if (hit) tr = bed_cache->tr;
+        }
+        if (!hit) {
+            tr = targets_from_bed(a->region_file, lengths);  // :192-195
+            if (have_stat) {
+                std::lock_guard<std::mutex> lk(bed_cache->mu);
+                bed_cache->path = a->region_file, bed_cache->dev = (uint64_t)sb.st_dev, bed_cache->ino = (uint64_t)sb.st_ino;
+                bed_cache->size = (uint64_t)sb.st_size, bed_cache->mtime_ns = (int64_t)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec;
+                bed_cache->lengths = lengths, bed_cache->tr = tr, bed_cache->valid = true;
+            }
+        }
+    } else {
         msg = "ERROR: Specify a region string (-r) or a region_file (-R)!";  // :197-200
         return INQ_EXIT_ERROR;
     }
@@ -122,6 +155,12 @@ int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg) {
         }
     }
     P.targets.swap(tr.data);
+    if (const char *tm = std::getenv("INQ_TIMING"); tm && tm[0] == '2') {
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[inq prepare] header + index %.2f ms, targets (%zu) %.2f ms\n",
+                     std::chrono::duration<double, std::milli>(t_targets - t_open).count(), P.targets.size(),
+                     std::chrono::duration<double, std::milli>(now - t_targets).count());
+    }
     return INQ_EXIT_OK;
 }
 
@@ -1583,6 +1622,7 @@ void inq_run_close(inq_run_t *r) { delete r; }
 struct inq_session {
     AsyncCtx actx;
     HostBufPool pool;
+    BedCache bed_cache;
     uint64_t n_staged = 0;  // inq_session_stage: which of the two sets of device slots the next file takes
 };
 
@@ -1602,7 +1642,7 @@ void stage_file(inq_session *S, const inq_call_args_t *a, int slot_base, StagedF
     try {
         out.args.reset(new OwnedArgs(*a));
         out.slot_base = slot_base;
-        out.rc = prepare(&out.args->a, out.P, out.msg);
+        out.rc = prepare(&out.args->a, out.P, out.msg, &S->bed_cache);
         if (out.rc != INQ_EXIT_OK) return;
         out.front = use_device_front(&out.args->a, *out.P.bam, out.P.targets) ? 2 : 1;
         if (out.front == 2) out.pipe.reset(start_span_pipeline(&out.args->a, *out.P.bam, out.P.targets, S->actx, slot_base, &S->pool));

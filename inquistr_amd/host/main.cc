@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/inquistr_host.h"
+#include "hostapi.h"
 #include "serve.h"
 
 static void usage(FILE *f) {
@@ -35,7 +36,7 @@ int main(int argc, char **argv) {
             return 2;
         }
         char err[1024] = {0};
-        int rc = inq_combine(argv + 2, (size_t)(argc - 2), 1, err, sizeof err);
+        int rc = inq::host_api().combine(argv + 2, (size_t)(argc - 2), 1, err, sizeof err);
         if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
         return rc;
     }
@@ -88,7 +89,7 @@ int main(int argc, char **argv) {
         o.combined = combined;
         char err[1024] = {0};
         ::setenv("INQ_FAST_EXIT", "1", 0);  // this process ends with the command: the device context is left to the operating system
-        int rc = inq_outlier(&o, 1, err, sizeof err);
+        int rc = inq::host_api().outlier(&o, 1, err, sizeof err);
         if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
         std::fflush(nullptr);
         const char *fast = std::getenv("INQ_FAST_EXIT");  // the lines went out through write(2): skip the runtime's tear-down (0.15 - 0.2 s)
@@ -133,14 +134,14 @@ int main(int argc, char **argv) {
         }
         ::setenv("INQ_FAST_EXIT", "1", 0);
         inq_session_t *S = nullptr;
-        if (inq_session_open(base.device, &S) != 0) return 1;
+        if (inq::host_api().session_open(base.device, &S) != 0) return 1;
         std::vector<inq_call_args_t> args(bams.size(), base);
         std::vector<std::string> outs(bams.size());
         std::vector<int> fds(bams.size(), -1), st(bams.size(), 0);
         for (size_t k = 0; k < bams.size(); ++k) {
             args[k].bam = bams[k].c_str();
             char name[4096];
-            inq_host_sample_name(bams[k].c_str(), name, sizeof name);
+            inq::host_api().host_sample_name(bams[k].c_str(), name, sizeof name);
             outs[k] = out_dir + "/" + name + ".inq";
             fds[k] = ::open(outs[k].c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
             if (fds[k] < 0) {
@@ -149,7 +150,7 @@ int main(int argc, char **argv) {
             }
         }
         char err[2048] = {0};
-        int rc = inq_session_call_many(S, args.data(), args.size(), fds.data(), st.data(), err, sizeof err);
+        int rc = inq::host_api().session_call_many(S, args.data(), args.size(), fds.data(), st.data(), err, sizeof err);
         for (int fd : fds) ::close(fd);
         for (size_t k = 0; k < bams.size(); ++k)
             if (st[k] != 0) std::fprintf(stderr, "%s: exit status %d\n", bams[k].c_str(), st[k]);
@@ -158,14 +159,14 @@ int main(int argc, char **argv) {
             int cfd = ::open(combined.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
             std::vector<const char *> files;
             for (auto &o : outs) files.push_back(o.c_str());
-            rc = cfd < 0 ? 1 : inq_combine(files.data(), files.size(), cfd, err, sizeof err);
+            rc = cfd < 0 ? 1 : inq::host_api().combine(files.data(), files.size(), cfd, err, sizeof err);
             if (cfd >= 0) ::close(cfd);
             if (rc != 0) std::fprintf(stderr, "%s\n", err);
         }
         std::fflush(nullptr);
         const char *fast = std::getenv("INQ_FAST_EXIT");
         if (fast && fast[0] == '1') std::_Exit(rc);
-        inq_session_close(S);
+        inq::host_api().session_close(S);
         return rc;
     }
     if (argc >= 2 && std::strcmp(argv[1], "serve") == 0) {
@@ -286,7 +287,7 @@ int main(int argc, char **argv) {
     }
     char err[1024] = {0};
     ::setenv("INQ_FAST_EXIT", "1", 0);  // this process ends with the call: see run_device_front
-    int rc = inq_genotype_repeats(&a, 1 /* stdout */, err, sizeof err);
+    int rc = inq::host_api().genotype_repeats(&a, 1 /* stdout */, err, sizeof err);
     if (rc != 0) {
         if (rc == INQ_EXIT_PANIC)
             std::fprintf(stderr, "thread 'main' panicked:\n%s\n", err);

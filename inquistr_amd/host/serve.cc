@@ -3,6 +3,8 @@
 // prints.  The rows go straight from the server into the caller's stdout: byte for byte what `inquistr call` writes itself.
 #include "serve.h"
 
+#include "hostapi.h"
+
 #include <poll.h>
 #include <signal.h>
 #include <sys/socket.h>
@@ -196,7 +198,7 @@ int serve_main(const char *socket_path, int device, double idle_exit_s) {
     ::signal(SIGPIPE, SIG_IGN);  // a caller that is gone (its stdout closed) fails its own call, not the server
 
     inq_session_t *S = nullptr;
-    if (inq_session_open(device, &S) != 0) {  // returns at once: the HIP runtime starts on a thread of its own
+    if (host_api().session_open(device, &S) != 0) {  // returns at once: the HIP runtime starts on a thread of its own
         ::close(ls);
         ::unlink(socket_path);
         return 1;
@@ -276,7 +278,7 @@ int serve_main(const char *socket_path, int device, double idle_exit_s) {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return box == nullptr; });
                 }
-                if (inq_session_stage(S, &a, &it->staged) != 0) it->staged = nullptr;  // (the strings are copied by the staging)
+                if (host_api().session_stage(S, &a, &it->staged) != 0) it->staged = nullptr;  // (the strings are copied by the staging)
             }
             {
                 std::unique_lock<std::mutex> lk(mu);
@@ -311,7 +313,7 @@ int serve_main(const char *socket_path, int device, double idle_exit_s) {
         } else {
             char err[1024] = {0};
             running.store(true);
-            const int rc = inq_session_run(S, it->staged, it->out_fd, err, sizeof err);
+            const int rc = host_api().session_run(S, it->staged, it->out_fd, err, sizeof err);
             running.store(false);
             answer(it->cs, rc, err);
             ++served;
@@ -329,7 +331,7 @@ int serve_main(const char *socket_path, int device, double idle_exit_s) {
     }
     front.join();
     if (box) {  // staged, never run
-        if (box->staged) inq_session_discard(box->staged);
+        if (box->staged) host_api().session_discard(box->staged);
         answer(box->cs, INQ_EXIT_ERROR, "serve: the server is leaving");
         if (box->out_fd >= 0) ::close(box->out_fd);
         ::close(box->cs);
@@ -341,7 +343,7 @@ int serve_main(const char *socket_path, int device, double idle_exit_s) {
     std::fflush(nullptr);
     const char *fast = std::getenv("INQ_FAST_EXIT");  // as the other commands: the context is left to the operating system
     if (fast && fast[0] == '1') std::_Exit(0);
-    inq_session_close(S);
+    host_api().session_close(S);
     return 0;
 }
 

@@ -298,3 +298,58 @@ def test_call_through_a_resident_server_equals_call(tmp_path):
         if server.poll() is None:
             server.kill()
             server.wait(timeout=30)
+
+
+def test_session_target_list_is_reused_only_when_it_may_be(tmp_path):
+    """A session keeps the parsed and validated BED of the file before (a cohort has one BED): it is taken again for the same
+    file and the same contigs - and only then.  A BAM whose contig is shorter makes the reference panic on a locus beyond its
+    end (src/repeats.rs:108-114) although the BAM before accepted it; a BED rewritten in place gives the new rows."""
+    from tools import bamio
+
+    def write(path, ln):
+        w = bamio.BamWriter(path, [("chr1", ln)], block=3000)
+        for k in range(30):
+            pos = 10_000 + 20_000 * k
+            for r in range(8):
+                w.add(f"r{k}_{r}", 0, 0, pos - 300, 60, [("M", 400), ("I", 9 + k % 5), ("M", 400)], [("HP", "C", 1 + r % 2)])
+        w.close()
+
+    long_, short = str(tmp_path / "long.bam"), str(tmp_path / "short.bam")
+    write(long_, 3_000_000)
+    write(short, 650_000)
+    bed = str(tmp_path / "loci.bed")
+
+    def put_bed(ks):
+        with open(bed, "w") as f:
+            f.write("".join(f"chr1\t{10_000 + 20_000 * k + 90}\t{10_000 + 20_000 * k + 110}\n" for k in ks))
+
+    def direct(bam):
+        r = subprocess.run([call.CLI_PATH, "call", bam, "-R", bed, "-t", "2"], capture_output=True, text=True, env=dict(os.environ, INQ_FRONTEND="device"))
+        return r.returncode, r.stdout
+
+    def in_session(S, bam, name):
+        o = tmp_path / name
+        try:
+            with open(o, "w") as f:
+                S.call(bam, region_file=bed, threads=2, out=f, frontend="device")
+            return 0, o.read_text()
+        except call.CallError as e:
+            return e.status, o.read_text()
+
+    put_bed(range(0, 29))  # the last locus ends at 570 110: inside both contigs
+    with call.Session(0) as S:
+        want_long, want_short = direct(long_), direct(short)
+        assert want_long[0] == want_short[0] == 0 and want_long[1].count("\n") == 30
+        assert in_session(S, long_, "a.inq") == want_long
+        assert in_session(S, long_, "b.inq") == want_long      # the kept list
+        assert in_session(S, short, "c.inq") == want_short     # same BED, other contig length: validated again, still fine
+        put_bed(range(0, 30))  # + a locus at 590 090 .. 590 110 ... and one beyond the short contig's end
+        with open(bed, "a") as f:
+            f.write("chr1\t700000\t700050\n")
+        st = os.stat(bed)
+        os.utime(bed, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000))
+        want_long2, want_short2 = direct(long_), direct(short)
+        assert want_long2[0] == 0 and want_long2[1].count("\n") == 32 and want_short2[0] == 101
+        assert in_session(S, long_, "d.inq") == want_long2     # the rewritten BED is read again
+        assert in_session(S, short, "e.inq")[0] == 101         # the list the long contig accepted is not taken for the short one
+        assert in_session(S, long_, "f.inq") == want_long2
