@@ -9,6 +9,7 @@
 #include <signal.h>
 #include <sys/socket.h>
 #include <sys/stat.h>
+#include <sys/time.h>
 #include <sys/un.h>
 #include <unistd.h>
 
@@ -236,6 +237,10 @@ int serve_main(const char *socket_path, int device, double idle_exit_s) {
             }
             const int cs = ::accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
             if (cs < 0) continue;
+            {   // a caller that connects and then says nothing must not hold the queue
+                timeval tv{10, 0};
+                ::setsockopt(cs, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+            }
             uint32_t magic = 0, body_len = 0;
             int out_fd = -1;
             if (!recv_header(cs, magic, body_len, out_fd)) {

@@ -54,3 +54,75 @@ def test_served_call_reports_what_the_call_itself_reports(tmp_path):
         if server.poll() is None:
             server.kill()
             server.wait(timeout=30)
+
+
+def test_server_leaves_on_sigterm_and_on_idle(tmp_path):
+    import signal
+
+    env = dict(os.environ)
+    env.pop("INQ_SERVER", None)
+    for how in ("term", "idle"):
+        sock = str(tmp_path / f"{how}.sock")
+        args = [call.CLI_PATH, "serve", "--socket", sock] + (["--idle-exit", "0.5"] if how == "idle" else [])
+        server = subprocess.Popen(args, env=env, stderr=subprocess.PIPE, text=True)
+        try:
+            for _ in range(200):
+                if os.path.exists(sock):
+                    break
+                time.sleep(0.05)
+            assert os.path.exists(sock)
+            if how == "term":
+                server.send_signal(signal.SIGTERM)
+            assert server.wait(timeout=30) == 0
+            assert "leaving after 0 calls" in server.stderr.read() and not os.path.exists(sock)
+        finally:
+            if server.poll() is None:
+                server.kill()
+                server.wait(timeout=30)
+
+
+def test_malformed_requests_are_refused_and_the_server_stays(tmp_path):
+    """Garbage on the socket (no descriptor, wrong magic, a body shorter than announced) gets an error answer or a closed
+    connection; the next proper request is served."""
+    import socket
+    import struct
+
+    bam, bed, loci, recs = _make_case(tmp_path, 6, n_loci=5)
+    sock = str(tmp_path / "m.sock")
+    env = dict(os.environ)
+    env.pop("INQ_SERVER", None)
+    server = subprocess.Popen([call.CLI_PATH, "serve", "--socket", sock, "--idle-exit", "60"], env=env, stderr=subprocess.PIPE, text=True)
+    try:
+        for _ in range(200):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        for payload in (b"", b"abc", struct.pack("<II", 0x12345678, 0), struct.pack("<II", 0x31514E49, 16) + b"\x00" * 4,
+                        struct.pack("<II", 0x31514E49, 0xFFFFFFFF)):
+            c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            c.settimeout(10)
+            c.connect(sock)
+            if payload:
+                c.sendall(payload)
+            c.shutdown(socket.SHUT_WR)
+            got = b""
+            try:
+                while True:
+                    chunk = c.recv(4096)
+                    if not chunk:
+                        break
+                    got += chunk
+            except (ConnectionResetError, socket.timeout):
+                pass
+            c.close()
+            if len(got) >= 4:
+                assert struct.unpack("<i", got[:4])[0] != 0
+        if not _have_gpu():
+            served = subprocess.run([call.CLI_PATH, "call", bam, "-R", bed], capture_output=True, text=True, env=dict(env, INQ_SERVER=sock))
+            assert served.returncode == 1 and "no CPU fallback" in served.stderr
+        assert subprocess.run([call.CLI_PATH, "serve", "--socket", sock, "--quit"], env=env).returncode == 0
+        assert server.wait(timeout=30) == 0
+    finally:
+        if server.poll() is None:
+            server.kill()
+            server.wait(timeout=30)
