@@ -181,6 +181,9 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * block) so that its commit step does not decode them again (+3 - 4 % on match-heavy blocks, -2 ... -5 % on sequence / quality
  * bytes: the stores cost what the second decode did), 0 = it decodes again, -1 (default) = on for spans whose sampled block
  * headers say match-heavy;
+ * "inflate_ahead" = 1: inq_span_stage inflates a span right behind its upload, on a stream of its own, so that the inflate of
+ * span k + 1 runs next to span k's record scan, gather and join (costs one inflated buffer and token scratch per staging slot);
+ * 0 (default) = the span is inflated when it is called;
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);

@@ -474,6 +474,10 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
         c->inflate_lit_pairs = value < 0 ? -1 : (value != 0);
         return INQ_OK;
     }
+    if (std::strcmp(key, "inflate_ahead") == 0) {
+        c->inflate_ahead = value != 0;
+        return INQ_OK;
+    }
     if (std::strcmp(key, "inflate_tokens") == 0) {
         c->inflate_tokens = value < 0 ? -1 : (value != 0);
         return INQ_OK;

@@ -45,6 +45,10 @@ struct inq_ctx {
     // sampled block headers say match-heavy (the same look that picks the symbol loop's form), 0 / 1 = off / on
     int inflate_tokens = -1;
     int inflate_lit_pairs = -1;  // workgroup inflate's symbol loop: 1 = a second literal from the same peek, 0 = not, -1 = by the data (deflate_probe.h)
+    // a staged span (inq_span_stage) is inflated right behind its upload, on a stream of its own: the device's time per span call drops
+    // by a third, but a staging slot then holds an inflated buffer and token scratch of its own (4 GB more to allocate and to give back
+    // for a 1 GB file: +0.3 s for a one-file process), and with the device out of the way the loop is bound by the host's reads: off
+    int inflate_ahead = 0;
     uint32_t inflate_algo = 2;  // 0 = workgroup per BGZF block, 1 = lane per block, 2 = the quicker one (0 since round 2)
     std::vector<inq::EvTriple> ev_pool;
     size_t ev_used = 0;

@@ -42,8 +42,15 @@ struct SpanState {
         const void *host_comp = nullptr;
         uint64_t comp_bytes = 0, n_blocks = 0, n_anchors = 0;
         bool valid = false;
+        // ... and inflated there too (option "inflate_ahead"), on a stream of its own: the inflate of span k + 1 runs next to span
+        // k's record scan, gather and join - kernels that leave most of the chip idle - and next to the tail of span k's inflate
+        DevBuf u, tok;
+        unsigned int *d_err = nullptr;  // the INQ_INFLATE_* bits of this slot's blocks
+        hipEvent_t ev_up = nullptr, ev_inf0 = nullptr, ev_inf1 = nullptr;
+        bool inflated = false;
     } stage[6];  // two sets of three: the spans of the NEXT file of a cohort are staged while this file's are still being called
     hipStream_t copy_stream = nullptr;
+    hipStream_t ahead_stream = nullptr;  // the inflates launched at staging time
     hipStream_t warm_stream = nullptr;  // the one warm-up copy below: the copy stream may be busy uploading the next span
     // the batch the last inq_call_span built
     uint64_t n_reads = 0, n_cigar_words = 0, n_pairs = 0, n_loci = 0;
@@ -69,9 +76,14 @@ void span_state_destroy(SpanState *S) {
                       &S->reads, &S->info, &S->key, &S->endkey, &S->pmax, &S->cig_off, &S->cigar, &S->anchor_stop, &S->ltid, &S->lstart, &S->lend, &S->locus_cnt,
                       &S->locus_off, &S->pair_read, &S->p1, &S->p2, &S->tmp, &S->tok})
         if (b->p) (void)hipFree(b->p);
-    for (auto &g : S->stage)
-        for (DevBuf *b : {&g.comp, &g.blocks, &g.anchors, &g.anchor_stop})
+    for (auto &g : S->stage) {
+        for (DevBuf *b : {&g.comp, &g.blocks, &g.anchors, &g.anchor_stop, &g.u, &g.tok})
             if (b->p) (void)hipFree(b->p);
+        if (g.d_err) (void)hipFree(g.d_err);
+        for (hipEvent_t e : {g.ev_up, g.ev_inf0, g.ev_inf1})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (S->ahead_stream) (void)hipStreamDestroy(S->ahead_stream);
     for (DevBuf *b : {&S->acc.cigar, &S->acc.reads, &S->acc.pair_read, &S->acc.off, &S->acc.lstart, &S->acc.lend})
         if (b->p) (void)hipFree(b->p);
     if (S->copy_stream) (void)hipStreamDestroy(S->copy_stream);
@@ -98,6 +110,14 @@ int inq::span_state_init(inq_ctx *c) {
     S->have_ev = true;
     HIP_TRY(c, hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&S->warm_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&S->ahead_stream, hipStreamNonBlocking));
+    if (const char *e = std::getenv("INQ_INFLATE_AHEAD")) c->inflate_ahead = std::atoi(e) != 0;  // A/B and tests; the option is "inflate_ahead"
+    for (auto &g : S->stage) {
+        HIP_TRY(c, hipMalloc((void **)&g.d_err, sizeof(unsigned int)));
+        HIP_TRY(c, hipEventCreate(&g.ev_up));
+        HIP_TRY(c, hipEventCreate(&g.ev_inf0));
+        HIP_TRY(c, hipEventCreate(&g.ev_inf1));
+    }
     return INQ_OK;
 }
 
@@ -168,11 +188,17 @@ int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t c
         d_comp = S->comp.p;
         d_blocks = S->blocks.p;
     }
+    HIP_TRY(c, hipMemsetAsync(S->d_st, 0, sizeof(FrontStatus), s));
+    HIP_TRY(c, hipMemsetAsync(&S->d_st->first_bad, 0xff, sizeof(unsigned long long), s));
+    if (staged && staged->inflated) {  // inflated when it was staged: wait for that, take over its status word
+        HIP_TRY(c, hipEventRecord(S->ev[1], s));
+        HIP_TRY(c, hipStreamWaitEvent(s, staged->ev_inf1, 0));
+        HIP_TRY(c, hipMemcpyAsync(&S->d_st->inflate, staged->d_err, sizeof(unsigned int), hipMemcpyDeviceToDevice, s));
+        return INQ_OK;
+    }
     if ((rc = ensure(c, S->u, out_bytes + kPad)) != INQ_OK) return rc;
     if (want_block_status && (rc = ensure(c, S->block_status, n_blocks * 4)) != INQ_OK) return rc;
     HIP_TRY(c, hipMemsetAsync((uint8_t *)S->u.p + out_bytes, 0, kPad, s));
-    HIP_TRY(c, hipMemsetAsync(S->d_st, 0, sizeof(FrontStatus), s));
-    HIP_TRY(c, hipMemsetAsync(&S->d_st->first_bad, 0xff, sizeof(unsigned long long), s));
     HIP_TRY(c, hipEventRecord(S->ev[1], s));
     InflateArgs ia;
     ia.comp = (const uint8_t *)d_comp;
@@ -291,7 +317,8 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
 
     ScanArgs a;
     std::memset(&a, 0, sizeof a);
-    a.u = (const uint8_t *)S->u.p;
+    const bool ahead = staged && staged->inflated;
+    a.u = (const uint8_t *)(ahead ? staged->u.p : S->u.p);
     a.u_bytes = u_bytes;
     a.anchors = (const uint64_t *)(staged ? staged->anchors.p : S->anchors.p);
     a.n_anchors = na;
@@ -320,7 +347,7 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     if (!S->copy_path_warm && u_bytes >= (512u << 10)) {
         // the first device-to-host copy of this size costs the host ~8 ms inside the runtime; spent here, on another stream,
         // it hides behind the inflate that was just enqueued instead of sitting behind the last kernel of the span
-        HIP_TRY(c, hipMemcpyAsync(S->h_rows, S->u.p, 512u << 10, hipMemcpyDeviceToHost, S->warm_stream));
+        HIP_TRY(c, hipMemcpyAsync(S->h_rows, ahead ? staged->u.p : S->u.p, 512u << 10, hipMemcpyDeviceToHost, S->warm_stream));
         S->copy_path_warm = true;
     }
     HIP_TRY(c, hipMemcpyAsync(&S->h->val[0], a.anchor_base + na, 8, hipMemcpyDeviceToHost, s));
@@ -422,6 +449,11 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
         };
         stats->ms_upload = el(0, 1);
         stats->ms_inflate = el(1, 2);
+        if (ahead) {  // the inflate ran on its own stream while the span before was scanned: its own events
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, staged->ev_inf0, staged->ev_inf1);
+            stats->ms_inflate = (double)ms;
+        }
         stats->ms_scan = el(2, 3);
         stats->ms_join = el(3, 4);
         stats->ms_call = defer ? 0.0 : el(4, 5);
@@ -603,7 +635,40 @@ int span_stage_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
     if (nb) HIP_TRY(c, hipMemcpyAsync(g.blocks.p, sp->blocks, nb * sizeof(inq_bgzf_block_t), hipMemcpyHostToDevice, s));
     if (na) HIP_TRY(c, hipMemcpyAsync(g.anchors.p, sp->anchors, na * 8, hipMemcpyHostToDevice, s));
     if (na) HIP_TRY(c, hipMemcpyAsync(g.anchor_stop.p, sp->anchor_stop, na * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    g.inflated = false;
+    if (c->inflate_ahead && nb) {
+        // the inflate behind the upload, on the ahead stream (the copy stream goes on with the next span's bytes)
+        if ((rc = ensure(c, g.u, u_bytes + kPad)) != INQ_OK) return rc;
+        HIP_TRY(c, hipEventRecord(g.ev_up, s));
+        hipStream_t sa = S->ahead_stream;
+        HIP_TRY(c, hipStreamWaitEvent(sa, g.ev_up, 0));
+        HIP_TRY(c, hipMemsetAsync((uint8_t *)g.u.p + u_bytes, 0, kPad, sa));
+        HIP_TRY(c, hipMemsetAsync(g.d_err, 0, sizeof(unsigned int), sa));
+        HIP_TRY(c, hipEventRecord(g.ev_inf0, sa));
+        InflateArgs ia;
+        ia.comp = (const uint8_t *)g.comp.p;
+        ia.comp_bytes = sp->comp_bytes;
+        ia.blocks = (const inq_bgzf_block_t *)g.blocks.p;
+        ia.n_blocks = nb;
+        ia.out = (uint8_t *)g.u.p;
+        ia.out_bytes = u_bytes;
+        ia.block_status = nullptr;
+        ia.err = g.d_err;
+        ia.verify_crc = c->verify_crc ? 1u : 0u;
+        ia.debug_flags = 0u;
+        ia.algo = c->inflate_algo;
+        ia.lit_pairs = c->inflate_lit_pairs < 0 ? inflate_wants_literal_pairs(sp->comp, sp->comp_bytes, sp->blocks, nb) : (uint32_t)c->inflate_lit_pairs;
+        ia.tokens = nullptr;
+        if (ia.algo != 1u && (c->inflate_tokens < 0 ? ia.lit_pairs == 0u : c->inflate_tokens != 0)) {
+            if ((rc = ensure(c, g.tok, inflate_token_words(nb) * 4)) != INQ_OK) return rc;
+            ia.tokens = (uint32_t *)g.tok.p;
+        }
+        launch_bgzf_inflate(ia, sa);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(g.ev_inf1, sa));
+        g.inflated = true;
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));  // the upload (the caller's buffer is free again); the inflate goes on
     g.host_comp = sp->comp;
     g.comp_bytes = sp->comp_bytes;
     g.n_blocks = nb;

@@ -700,8 +700,9 @@ def test_many_spans_with_staged_uploads_equal_the_host_front_end(tmp_path, monke
     make_synth_bam.write("unphased100k", 20_000, prefix)
     texts = {}
     for name, env in (("host", {"INQ_FRONTEND": "host"}), ("device64", {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "64"}),
+                      ("device64_inflated_when_staged", {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "64", "INQ_INFLATE_AHEAD": "1"}),
                       ("device", {"INQ_FRONTEND": "device"}), ("auto", {})):
-        for k in ("INQ_FRONTEND", "INQ_SPAN_MB"):
+        for k in ("INQ_FRONTEND", "INQ_SPAN_MB", "INQ_INFLATE_AHEAD"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -709,6 +710,6 @@ def test_many_spans_with_staged_uploads_equal_the_host_front_end(tmp_path, monke
         with open(out, "w") as f:
             call.genotype_repeats(prefix + ".bam", None, prefix + ".bed", 5, 3, 8, True, "S", None, out=f)
         texts[name] = out.read_text()
-    assert texts["host"] == texts["device64"] == texts["device"] == texts["auto"]
+    assert texts["host"] == texts["device64"] == texts["device64_inflated_when_staged"] == texts["device"] == texts["auto"]
     rows = texts["host"].splitlines()
     assert len(rows) == 20_001 and not any(r.endswith("NaN\tNaN") for r in rows[1:])
