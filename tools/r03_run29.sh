@@ -2,7 +2,7 @@
 # GPU box, round 3: where a served call's 89 ms go (server-side stage lines, INQ_TIMING=2) - 1.0 GB CIGAR-only file, 100 000 loci.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r03sv
+OUT=$ROOT/gpurun_out/r03sv2
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
@@ -17,4 +17,4 @@ for i in 1 2 3 4; do
 done
 $CLI serve --socket /tmp/sv.sock --quit
 wait $SP
-grep -v "^\[inq span\]" $OUT/server.err | tail -40
+grep -E "inq prepare|device front end:|inq output" $OUT/server.err | tail -12
