@@ -190,6 +190,7 @@ int main(int argc, char **argv) {
             else if (k == "--idle-exit") idle = std::strtod(val(), nullptr);
             else if (k == "--quit") {
                 if (sock.empty()) sock = std::getenv("INQ_SERVER") ? std::getenv("INQ_SERVER") : "";
+                if (sock == "auto") sock = inq::auto_socket_path(device);
                 return inq::client_quit(sock.c_str()) ? 0 : 1;
             } else {
                 std::fprintf(stderr, "error: unexpected argument '%s' found\n", k.c_str());
@@ -271,7 +272,21 @@ int main(int argc, char **argv) {
         return 2;
     }
     a.bam = bam.c_str();
-    if (const char *server = std::getenv("INQ_SERVER"); server && *server) {
+    if (const char *server_env = std::getenv("INQ_SERVER"); server_env && *server_env) {
+        // INQ_SERVER=auto: this user's server for the device, started (detached; it leaves after INQ_SERVER_IDLE seconds without a
+        // call, 120 by default) when none is running - the first call of a batch pays the start-up, the others find the context there
+        std::string server_path = server_env;
+        if (server_path == "auto") {
+            server_path = inq::auto_socket_path(a.device);
+            char exe[4096];
+            const ssize_t n = ::readlink("/proc/self/exe", exe, sizeof exe - 1);
+            const char *idle = std::getenv("INQ_SERVER_IDLE");
+            if (n > 0) {
+                exe[n] = 0;
+                (void)inq::ensure_server(exe, server_path.c_str(), a.device, idle && *idle ? std::strtod(idle, nullptr) : 120.0);
+            }
+        }
+        const char *server = server_path.c_str();
         int st = 0;
         std::string msg;
         const int got = inq::client_call(server, &a, 1 /* stdout */, &st, &msg);

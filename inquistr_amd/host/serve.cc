@@ -11,6 +11,8 @@
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <sys/un.h>
+#include <sys/wait.h>
+#include <fcntl.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -382,6 +384,47 @@ int client_call(const char *socket_path, const inq_call_args_t *a, int out_fd, i
     *status = st;
     *message = msg;
     return 1;
+}
+
+std::string auto_socket_path(int device) {
+    const char *run = std::getenv("XDG_RUNTIME_DIR");
+    std::string dir = run && *run ? run : "/tmp";
+    return dir + "/inquistr-" + std::to_string((unsigned long)::getuid()) + "-dev" + std::to_string(device) + ".sock";
+}
+
+bool ensure_server(const char *self_exe, const char *socket_path, int device, double idle_exit_s) {
+    if (int probe = connect_to(socket_path); probe >= 0) {
+        ::close(probe);
+        return true;
+    }
+    // a child of a child, in a session of its own, stdio on /dev/null: nothing of it hangs on the caller's terminal or pipes
+    // (this process has not touched the GPU - the host library is not even loaded -, so starting another program from it is safe)
+    const pid_t pid = ::fork();
+    if (pid < 0) return false;
+    if (pid == 0) {
+        if (::setsid() < 0) ::_exit(1);
+        const pid_t p2 = ::fork();
+        if (p2 != 0) ::_exit(p2 < 0 ? 1 : 0);
+        const int dn = ::open("/dev/null", O_RDWR);
+        if (dn >= 0) {
+            ::dup2(dn, 0), ::dup2(dn, 1), ::dup2(dn, 2);
+            if (dn > 2) ::close(dn);
+        }
+        const std::string dev = std::to_string(device), idle = std::to_string(idle_exit_s);
+        ::execl(self_exe, self_exe, "serve", "--socket", socket_path, "--device", dev.c_str(), "--idle-exit", idle.c_str(), (char *)nullptr);
+        ::_exit(127);
+    }
+    int st = 0;
+    while (::waitpid(pid, &st, 0) < 0 && errno == EINTR) {
+    }
+    for (int i = 0; i < 400; ++i) {  // the socket is there before the runtime starts: a few milliseconds
+        if (int probe = connect_to(socket_path); probe >= 0) {
+            ::close(probe);
+            return true;
+        }
+        ::usleep(5000);
+    }
+    return false;
 }
 
 bool client_quit(const char *socket_path) {

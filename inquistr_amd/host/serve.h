@@ -17,6 +17,12 @@ int serve_main(const char *socket_path, int device, double idle_exit_s);
 // have been written: an error, not a case for doing the call again).
 int client_call(const char *socket_path, const inq_call_args_t *a, int out_fd, int *status, std::string *message);
 
+// INQ_SERVER=auto: the socket of this user's server for `device` (under $XDG_RUNTIME_DIR or /tmp), and a server started behind it
+// when none answers - detached, leaving by itself after `idle_exit_s` seconds without a call.  True when a server listens (was
+// there or came up within a few seconds).
+std::string auto_socket_path(int device);
+bool ensure_server(const char *self_exe, const char *socket_path, int device, double idle_exit_s);
+
 // Asks the server to leave.  True if it answered.
 bool client_quit(const char *socket_path);
 

@@ -353,3 +353,28 @@ def test_session_target_list_is_reused_only_when_it_may_be(tmp_path):
         assert in_session(S, long_, "d.inq") == want_long2     # the rewritten BED is read again
         assert in_session(S, short, "e.inq")[0] == 101         # the list the long contig accepted is not taken for the short one
         assert in_session(S, long_, "f.inq") == want_long2
+
+
+def test_auto_server_gives_the_calls_own_rows(tmp_path):
+    """INQ_SERVER=auto: the first `inquistr call` starts the user's server for the device and is served by it, the next ones find
+    it; rows, status and message are the call's own.  The server is asked to leave at the end (it would by itself when idle)."""
+    from tools import make_synth_bam
+
+    prefix = str(tmp_path / "a")
+    make_synth_bam.write_native("unphased100k", 700, prefix, threads=4)
+    env_direct = dict(os.environ, INQ_FRONTEND="device")
+    env_direct.pop("INQ_SERVER", None)
+    env_auto = dict(env_direct, INQ_SERVER="auto", XDG_RUNTIME_DIR=str(tmp_path), INQ_SERVER_IDLE="30")
+    sock = tmp_path / f"inquistr-{os.getuid()}-dev0.sock"
+    cmd = [call.CLI_PATH, "call", prefix + ".bam", "-R", prefix + ".bed", "-u", "-t", "4"]
+    want = subprocess.run(cmd, capture_output=True, text=True, env=env_direct)
+    assert want.returncode == 0 and want.stdout.count("\n") == 701
+    try:
+        for _ in range(3):
+            got = subprocess.run(cmd, capture_output=True, text=True, env=env_auto, timeout=120)
+            assert got.returncode == 0 and got.stdout == want.stdout and sock.exists()
+        bad = subprocess.run([call.CLI_PATH, "call", prefix + ".bam", "-r", "chrNope:100-200"], capture_output=True, text=True, env=env_auto, timeout=120)
+        assert bad.returncode == 101 and bad.stdout == ""
+    finally:
+        q = subprocess.run([call.CLI_PATH, "serve", "--socket", str(sock), "--quit"], capture_output=True, text=True, timeout=60)
+    assert q.returncode == 0

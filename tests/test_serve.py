@@ -126,3 +126,25 @@ def test_malformed_requests_are_refused_and_the_server_stays(tmp_path):
         if server.poll() is None:
             server.kill()
             server.wait(timeout=30)
+
+
+@pytest.mark.skipif(_have_gpu(), reason="the GPU twin is in tests/test_gpu_end_to_end.py")
+def test_auto_server_is_started_once_and_found_again(tmp_path):
+    """INQ_SERVER=auto: the first call starts this user's server for the device (detached, idle exit), the second finds it; the
+    call's own status and message come back either way."""
+    bam, bed, loci, recs = _make_case(tmp_path, 7, n_loci=6)
+    env = dict(os.environ, INQ_SERVER="auto", XDG_RUNTIME_DIR=str(tmp_path), INQ_SERVER_IDLE="20")
+    sock = tmp_path / f"inquistr-{os.getuid()}-dev0.sock"
+    try:
+        for _ in range(2):
+            r = subprocess.run([call.CLI_PATH, "call", bam, "-R", bed, "-t", "2"], capture_output=True, text=True, env=env, timeout=60)
+            assert r.returncode == 1 and "no CPU fallback" in r.stderr and r.stdout == ""
+            assert sock.exists()
+    finally:
+        q = subprocess.run([call.CLI_PATH, "serve", "--socket", str(sock), "--quit"], capture_output=True, text=True, timeout=60)
+    assert q.returncode == 0
+    for _ in range(100):
+        if not sock.exists():
+            break
+        time.sleep(0.05)
+    assert not sock.exists()
