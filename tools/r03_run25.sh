@@ -2,7 +2,7 @@
 # GPU box, round 3: the default bench line with the measured read ceiling and the 12.8 GB SEQ-bearing block; wall time of the whole command.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r03b8
+OUT=$ROOT/gpurun_out/r03b9
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
@@ -13,7 +13,7 @@ t1=$(date +%s.%N)
 python3 -c "print(f\"bench.py default: {$t1 - $t0:.1f} s\")" | tee $OUT/bench_wall.txt
 python3 - <<'PY'
 import json, os
-d = json.loads(open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r03b8/bench_default.json").read().strip().splitlines()[-1])
+d = json.loads(open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r03b9/bench_default.json").read().strip().splitlines()[-1])
 r = d["roofline"]; print({k: r.get(k) for k in ("achieved", "frac", "frac_of_measured")}, r.get("peak_measured", {}).get("all"))
 for k in ("l2", "l2_seq", "l2_seq_large"):
     b = d.get(k, {})
