@@ -293,12 +293,18 @@ __global__ __launch_bounds__(256) void cigar_gather_kernel(ScanArgs a, uint64_t 
     // the extent was checked against the record for the in-record CIGAR; the CG payload by aux_size()
     int64_t rlen = 0;
     uint32_t clip = 0;
-    for (uint32_t k = lane; k < n4; k += 64u) {
-        const uint32_t w = k < n ? ld32(src + (uint64_t)k * 4u) : 0u;
-        dst[k] = w;
-        const uint32_t op = w & 0xfu;
-        if ((0x18Du >> op) & 1u) rlen += (int64_t)(w >> 4);  // M D N = X consume the reference
-        clip |= op == 4u;
+    // four operations (16 bytes) per lane and step: the source lies wherever the record does, the destination is 16-byte aligned
+    for (uint32_t k = lane * 4u; k < n4; k += 256u) {
+        uint32_t w[4];
+        if (k + 4u <= n) __builtin_memcpy(w, src + (uint64_t)k * 4u, 16);
+        else
+            for (uint32_t j = 0; j < 4u; ++j) w[j] = k + j < n ? ld32(src + (uint64_t)(k + j) * 4u) : 0u;
+        *reinterpret_cast<uint4 *>(dst + k) = make_uint4(w[0], w[1], w[2], w[3]);
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t op = w[j] & 0xfu;
+            if ((0x18Du >> op) & 1u) rlen += (int64_t)(w[j] >> 4);  // M D N = X consume the reference
+            clip |= op == 4u;
+        }
     }
     for (int off = 32; off; off >>= 1) {
         rlen += __shfl_xor(rlen, off);
