@@ -117,6 +117,14 @@ int connect_to(const char *path) {
         ::close(fd);
         return -1;
     }
+    // only this user's server gets a caller's arguments and its stdout (a socket somebody else put at a guessable path - the
+    // INQ_SERVER=auto one under /tmp - is not a server to talk to)
+    ucred cred;
+    socklen_t len = sizeof cred;
+    if (::getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cred, &len) != 0 || cred.uid != ::getuid()) {
+        ::close(fd);
+        return -1;
+    }
     return fd;
 }
 
