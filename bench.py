@@ -172,6 +172,9 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                     if os.path.exists(sock):
                         break
                     time.sleep(0.025)
+                if not os.path.exists(sock) or server.poll() is not None:
+                    # (never fall through to callers that would each start a context of their own: the box allows six on the card)
+                    raise RuntimeError("inquistr serve did not come up")
                 env_s = dict(os.environ, INQ_SERVER=sock)
                 run(cmd, env_s)  # the context's start-up is the first caller's
                 sv = [run(cmd, env_s) for _ in range(reps)]
@@ -181,8 +184,10 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                                          "note": "inquistr call with INQ_SERVER=<socket of a running `inquistr serve`>: same CLI, the device context is resident"}
                 res["speedup_served_vs_B"] = res["gpu_cli_served"]["loci_per_s"] / res["cpu_B"]["loci_per_s"]
                 # ... and with callers queueing (a workflow manager starts several at once): the server stages file k + 1 while it
-                # calls file k; 8 callers started together, wall time until the last has left
-                n_par = 8
+                # calls file k; 4 callers started together, wall time until the last has left
+                n_par = 4  # (with this process and the server: six on the card at most even if every caller had to start a context)
+                if server.poll() is not None:
+                    raise RuntimeError("inquistr serve is gone")
                 t = time.perf_counter()
                 # (stdout into files: the server writes a caller's rows while the others wait their turn; pipes read one after the
                 # other by this process would fill up and stall the queue)

@@ -271,9 +271,10 @@ def test_call_through_a_resident_server_equals_call(tmp_path):
                 assert got.stderr.strip().splitlines()[-1] == want.stderr.strip().splitlines()[-1]
         again = subprocess.run([call.CLI_PATH, "call", prefixes[2] + ".bam", "-R", prefixes[2] + ".bed", "-u"], capture_output=True, text=True, env=env_served)
         assert again.returncode == 0 and again.stdout.count("\n") == 601
-        # six callers at once (a workflow manager's way): they queue, file k + 1 is staged while file k is called, every one gets its own rows
+        # four callers at once (a workflow manager's way; four, so that even without the server the box's limit of six processes on the
+        # card holds): they queue, file k + 1 is staged while file k is called, every one gets its own rows
         procs = []
-        for k in (0, 1, 2, 2, 1, 0):
+        for k in (0, 1, 2, 1):
             flags = ["-t", "4"] + ([] if k == 1 else ["-u"])
             # (stdout into a file: rows of a caller whose pipe nobody reads yet would stall the server's queue)
             f = open(tmp_path / f"par{len(procs)}.inq", "w")
@@ -293,7 +294,7 @@ def test_call_through_a_resident_server_equals_call(tmp_path):
         quit_ = subprocess.run([call.CLI_PATH, "serve", "--socket", sock, "--quit"], capture_output=True, text=True)
         assert quit_.returncode == 0
         assert server.wait(timeout=30) == 0
-        assert "leaving after 15 calls" in server.stderr.read()
+        assert "leaving after 13 calls" in server.stderr.read()
     finally:
         if server.poll() is None:
             server.kill()
