@@ -122,9 +122,9 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
             open(p, "w").write("".join(bed_lines[:n]))
             return p
 
-        def run(cmd, env=None):
+        def run(cmd, env=None, timeout=None):
             t = time.perf_counter()
-            r = subprocess.run(cmd, capture_output=True, env=env)
+            r = subprocess.run(cmd, capture_output=True, env=env, timeout=timeout)
             dt = time.perf_counter() - t
             if r.returncode != 0:
                 raise RuntimeError(f"{cmd[0]} exited {r.returncode}: {r.stderr.decode()[-300:]}")
@@ -176,8 +176,8 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                     # (never fall through to callers that would each start a context of their own: the box allows six on the card)
                     raise RuntimeError("inquistr serve did not come up")
                 env_s = dict(os.environ, INQ_SERVER=sock)
-                run(cmd, env_s)  # the context's start-up is the first caller's
-                sv = [run(cmd, env_s) for _ in range(reps)]
+                run(cmd, env_s, timeout=300)  # the context's start-up is the first caller's (a stuck server must not hold the line)
+                sv = [run(cmd, env_s, timeout=300) for _ in range(reps)]
                 t_sv = statistics.median(t for t, _ in sv)
                 res["gpu_cli_served"] = {"seconds_median": t_sv, "seconds_all": [t for t, _ in sv], "runs": reps, "loci_per_s": loci / t_sv,
                                          "inq_identical": all(o == out_dev for _, o in sv),
@@ -202,7 +202,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                 res["gpu_cli_served"]["callers_at_once"] = {"callers": n_par, "seconds_all_done": dt_par, "seconds_per_file": dt_par / n_par,
                                                              "loci_per_s": loci * n_par / dt_par, "inq_identical": all(o == out_dev for o in outs),
                                                              "speedup_vs_B": (loci * n_par / dt_par) / res["cpu_B"]["loci_per_s"]}
-                subprocess.run([cli, "serve", "--socket", sock, "--quit"], capture_output=True)
+                subprocess.run([cli, "serve", "--socket", sock, "--quit"], capture_output=True, timeout=60)
                 server.wait(timeout=60)
             finally:
                 if server.poll() is None:
