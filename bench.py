@@ -193,8 +193,14 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                 # other by this process would fill up and stall the queue)
                 fs = [open(os.path.join(tmp, f"par{i}.inq"), "wb") for i in range(n_par)]
                 ps = [subprocess.Popen(cmd, env=env_s, stdout=fs[i], stderr=subprocess.DEVNULL) for i in range(n_par)]
-                for p in ps:
-                    p.wait(timeout=300)
+                try:
+                    for p in ps:
+                        p.wait(timeout=300)
+                except Exception:
+                    for p in ps:
+                        if p.poll() is None:
+                            p.kill()
+                    raise
                 dt_par = time.perf_counter() - t
                 for f in fs:
                     f.close()
