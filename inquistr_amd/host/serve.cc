@@ -400,13 +400,34 @@ std::string auto_socket_path(int device) {
     return dir + "/inquistr-" + std::to_string((unsigned long)::getuid()) + "-dev" + std::to_string(device) + ".sock";
 }
 
+// Is a GPU runtime (or a tool that initialises one: rocprofv3's preloaded library does) mapped into this process?  Read from the
+// kernel's own list of the process's mappings, so that it also sees what LD_PRELOAD brought in.  `maps_path` is a test seam.
+bool gpu_runtime_mapped(const char *maps_path) {
+    FILE *f = std::fopen(maps_path ? maps_path : "/proc/self/maps", "r");
+    if (!f) return true;  // cannot tell: behave as if it were (the call then runs in this process)
+    char line[4096];
+    bool hit = false;
+    while (!hit && std::fgets(line, sizeof line, f))
+        for (const char *lib : {"libhsa-runtime64", "libamdhip64", "librocprofiler", "librocprof-", "libroctracer", "librocm_smi"})
+            if (std::strstr(line, lib)) {
+                hit = true;
+                break;
+            }
+    std::fclose(f);
+    return hit;
+}
+
 bool ensure_server(const char *self_exe, const char *socket_path, int device, double idle_exit_s) {
     if (int probe = connect_to(socket_path); probe >= 0) {
         ::close(probe);
         return true;
     }
+    // Starting the server means fork + exec.  That is only safe from a process that has not initialised the GPU: normally true here
+    // (the host library is not even loaded when a `call` looks for its server), but NOT when a library preloaded into this process
+    // has done it - a profiler's tool library does.  Checked, not assumed: with a GPU runtime mapped the auto-start is refused and
+    // the caller runs the call in its own process.
+    if (gpu_runtime_mapped(nullptr)) return false;
     // a child of a child, in a session of its own, stdio on /dev/null: nothing of it hangs on the caller's terminal or pipes
-    // (this process has not touched the GPU - the host library is not even loaded -, so starting another program from it is safe)
     const pid_t pid = ::fork();
     if (pid < 0) return false;
     if (pid == 0) {

@@ -148,3 +148,27 @@ def test_auto_server_is_started_once_and_found_again(tmp_path):
             break
         time.sleep(0.05)
     assert not sock.exists()
+
+
+def test_auto_server_is_not_started_from_a_process_that_maps_a_gpu_runtime(tmp_path):
+    """Starting the server is fork + exec, which is only safe from a process that has not initialised the GPU.  A tool library
+    preloaded into `inquistr call` (a profiler's is) may have: with a GPU runtime among the process's mappings the auto-start is
+    refused - no server, no socket - and the call runs in the caller's own process, with its own status and message."""
+    hip = "/opt/rocm/lib/libamdhip64.so"
+    if not os.path.exists(hip):
+        pytest.skip("no HIP runtime library to preload")
+    bam, bed, loci, recs = _make_case(tmp_path, 11, n_loci=6)
+    env = dict(os.environ, INQ_SERVER="auto", XDG_RUNTIME_DIR=str(tmp_path), INQ_SERVER_IDLE="5", LD_PRELOAD=hip)
+    sock = tmp_path / f"inquistr-{os.getuid()}-dev0.sock"
+    r = subprocess.run([call.CLI_PATH, "call", bam, "-R", bed, "-t", "2"], capture_output=True, text=True, env=env, timeout=60)
+    try:
+        assert not sock.exists(), "a server was started from a process with the HIP runtime mapped"
+        # the call itself ran here: on a box without a GPU that is the loud failure, on a GPU box the rows
+        assert r.returncode in (0, 1)
+        if r.returncode == 1:
+            assert "no CPU fallback" in r.stderr and r.stdout == ""
+        else:
+            assert r.stdout.startswith("chromosome\tbegin\tend\t")
+    finally:
+        if sock.exists():
+            subprocess.run([call.CLI_PATH, "serve", "--socket", str(sock), "--quit"], capture_output=True, text=True, timeout=60)
