@@ -83,8 +83,115 @@ def cpu_baseline(wl, sample_loci: int, budget_s: float = 10.0):
     }
 
 
+PCIE_SPEC_GBS = 64.0  # PCIe Gen5 x16, one direction, before protocol overhead (the link an MI355X hangs on)
+
+
+def h2d_copy_peak(dev, mb: int = 256, reps: int = 6):
+    """What the host-to-device link delivers on this box, measured in this run: one pinned buffer of a span's size (256 MB) copied
+    to the device `reps` times on a stream of its own, HIP events around each copy, best and median.  The `pcie` roofline objects
+    of the L2 blocks are priced against it (and against the 64 GB/s of the Gen5 x16 specification)."""
+    import statistics
+
+    import torch
+
+    n = mb << 20
+    h = torch.empty(n, dtype=torch.uint8).pin_memory()
+    d = torch.empty(n, dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    rates = []
+    with torch.cuda.stream(s):
+        d.copy_(h, non_blocking=True)  # the first copy sets the path up
+        s.synchronize()
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            d.copy_(h, non_blocking=True)
+            e1.record(s)
+            s.synchronize()
+            rates.append(n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del h, d
+    return {"value": max(rates), "median": statistics.median(rates), "unit": "GB/s",
+            "what": f"pinned host -> device copy of {mb} MB, best of {reps} (HIP events), measured in this run"}
+
+
+def startup_floor(reps: int = 5):
+    """What ANY process that launches one kernel on this box pays: tools/hip_startup_probe.hip (hipInit, a stream, one empty kernel,
+    three allocations, one small copy - nothing of this repo), whole process from start to exit, measured in this run.  Printed
+    beside every whole-process time of the L2 blocks: the difference is what the product adds."""
+    import statistics
+
+    exe = os.path.join(ROOT, "inquistr_amd", "lib", "hip_startup_probe")
+    if not os.path.exists(exe):
+        return None
+    ts, stages = [], None
+    for _ in range(reps):
+        t = time.perf_counter()
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        ts.append(time.perf_counter() - t)
+        if r.returncode != 0:
+            return None
+        stages = r.stdout
+    inner = 0.0
+    for ln in (stages or "").splitlines():
+        f = ln.split()
+        if len(f) >= 2 and f[-1] == "ms":
+            try:
+                inner += float(f[-2])
+            except ValueError:
+                pass
+    med = statistics.median(ts)
+    return {"seconds_median": med, "seconds_all": ts, "runs": reps, "inside_main_ms_last_run": inner,
+            "start_and_exit_ms_last_run": max(0.0, ts[-1] * 1e3 - inner),
+            "what": "bare HIP process (tools/hip_startup_probe.hip: hipInit, one stream, one empty kernel, 6 GB of allocations, a 1 MB copy), "
+                    "start to exit; `inside_main` = the sum of its own stage clocks, the rest is loading the runtime's libraries and the exit"}
+
+
+def l1_block(wl, dev_index: int, loci: int = 50_000, reps: int = 5):
+    """L1: the host-buffer entry inq_call_batch - H2D of the SoA, the locus kernels, D2H of the rows - on pinned host
+    buffers; bound by the PCIe link, never `value`."""
+    import ctypes as C
+
+    import numpy as np
+
+    from inquistr_amd import hipcall, synth
+    from inquistr_amd.batch import Batch
+
+    b = synth.generate_numpy(wl, 0, loci)
+    L = hipcall.load()
+    keep, arrs = [], {}
+    try:
+        for name in ("cigar", "reads", "pair_read", "locus_pair_off", "locus_start", "locus_end"):
+            arr = getattr(b, name)
+            ptr = C.c_void_p()
+            if L.inq_alloc_pinned(max(arr.nbytes, 1), C.byref(ptr)) != 0:
+                raise RuntimeError("inq_alloc_pinned failed")
+            keep.append(ptr)
+            buf = (C.c_uint8 * max(arr.nbytes, 1)).from_address(ptr.value)
+            out = np.frombuffer(buf, dtype=np.uint8, count=arr.nbytes).view(arr.dtype)
+            out[...] = arr
+            arrs[name] = out
+        pb = Batch(minlen=b.minlen, support=b.support, unphased=b.unphased, **arrs)
+        with hipcall.Context(dev_index) as ctx:
+            ctx.call_batch(pb)  # allocations
+            times = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                rc, _res = ctx.call_batch(pb)
+                times.append(time.perf_counter() - t0)
+                if rc != 0:
+                    raise RuntimeError(f"inq_call_batch returned {rc}")
+        best = min(times)
+        nbytes = b.cigar.nbytes + b.reads.nbytes + b.pair_read.nbytes + b.locus_pair_off.nbytes + b.locus_start.nbytes + b.locus_end.nbytes
+        return {"level": "L1: inq_call_batch on pinned host buffers (H2D + kernels + D2H)", "loci": loci, "loci_per_s": loci / best,
+                "ms_per_call": best * 1e3, "ms_all": [x * 1e3 for x in times], "host_bytes_in": int(nbytes), "GBps_host_to_device_incl_kernels": nbytes / best / 1e9,
+                "note": "PCIe-inclusive: never `value`"}
+    finally:
+        for ptr in keep:
+            L.inq_free_pinned(ptr)
+
+
 def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_loci: int = 10_000, c_loci: int = 2_000, seq: bool = False,
-             level: int = 1, lean: bool = False):
+             level: int = 6, lean: bool = False, served_callers: int = 0, cohort: bool = True, floor=None, h2d=None, trace_runs: int = 1):
     """End to end (BAM + BED -> .inq) next to the reference-shaped CPU programs, small enough for the default run.
     Product CLI with the device front end: median of `reps` whole-process wall times (HIP start-up included; the CLI
     leaves through _Exit once the rows are written).  CPU side = oracle/ref_shaped_call, the reference's control flow
@@ -95,7 +202,11 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
     seq: records shaped like a real long-read BAM (SEQ + QUAL of the query length, NM, ML / MM tags, HP last: ~18 KB per
     record instead of ~0.85 KB; tools/synth_bam_writer.cc inq_synth_write_bam_seq), the shape north_star's ">= 10x the
     reference CPU inquiSTR call on a synthetic long-read BAM" is about.
-    lean: a file of many GB - only the product CLI (device front end), CPU mode B on all granted cores and the stage times."""
+    lean: a file of many GB - only the product CLI (device front end), CPU mode B on all granted cores and the stage times.
+    level: zlib level of the BGZF blocks (6 = htslib's default for BAM output; 1 = round 1 - 3's files).
+    served_callers: > 0 adds that many `inquistr call` processes queueing at one resident server (off in the default line: with
+    this process and the server they were six processes on the card).  cohort: the many-files-in-one-process figures.
+    floor / h2d: this run's startup_floor() and h2d_copy_peak(), quoted beside the whole-process times / in the `pcie` object."""
     import statistics
     import subprocess
     import tempfile
@@ -111,6 +222,15 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         info = {}
         make_synth_bam.write_native(workload, loci, prefix, threads=host_cores_available(), device=device, seq=seq, level=level, info=info)
         gen_s = time.perf_counter() - t0
+        # the file at rest before anything is timed: a BAM being read minutes after it was written is not the case measured, and
+        # GBs of dirty pages under write-back showed up as one slow run in five (profiles/r04_results/: reads 23 ms per span)
+        t_sync = time.perf_counter()
+        fd = os.open(prefix + ".bam", os.O_RDONLY)
+        try:
+            os.fsync(fd)
+        finally:
+            os.close(fd)
+        sync_s = time.perf_counter() - t_sync
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
         cli = os.path.join(ROOT, "inquistr_amd", "lib", "inquistr")
         ref = os.path.join(ROOT, "oracle", "ref_shaped_call")
@@ -141,7 +261,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         res = {
             "level": "L2: BAM + BED -> .inq, whole process, start to exit", "workload": workload, "loci": loci, "threads": threads,
             "host_cores_available": host_cores_available(),
-            "bam_mb": bam_bytes / 1e6, "bam_gen_s": gen_s, "zlib_level": level,
+            "bam_mb": bam_bytes / 1e6, "bam_gen_s": gen_s, "bam_fsync_s": sync_s, "zlib_level": level,
             "records": ("SEQ + QUAL of the query length, NM:i, ML:B,C + MM:Z, HP:C last (long-read record shape, ~18 KB per record; "
                         "bases ACGT, Phred a clamped random walk)" if seq else "SEQ '*' (CIGAR-only records), HP:C"),
             **({"inflated_mb": info["inflated_bytes"] / 1e6, "bgzf_blocks": info["n_blocks"]} if info else {}),
@@ -160,6 +280,26 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         # the device front end's own stage times for this file (HIP events / host clocks inside the CLI, one extra run)
         r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="2"))
         res["device_front_stages"] = stage_summary(r.stderr.decode(), bam_bytes)
+        loops = [res["device_front_stages"].get("span_loop_s")]
+        for _ in range(max(0, trace_runs - 1)):  # more samples of the span loop's own time (INQ_TIMING=1: one line per run)
+            r2 = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="1"))
+            loops.append(stage_summary(r2.stderr.decode(), bam_bytes).get("span_loop_s"))
+        loops = [x for x in loops if x]
+        if loops:
+            # The L2 path is bound by the host-to-device link: every compressed byte of the spans crosses it once, and nothing
+            # else of comparable size does.  achieved = compressed bytes of the spans / the span loop's own time (first span
+            # handed to the device -> last flush: the process's fixed costs are in `startup_floor`, not here).
+            comp_gb = res["device_front_stages"]["span_loop_comp_mb"] / 1e3
+            ach = comp_gb / statistics.median(loops)
+            res["pcie"] = {"bound": "pcie", "achieved": ach, "unit": "GB/s", "peak": PCIE_SPEC_GBS, "frac": ach / PCIE_SPEC_GBS,
+                           "span_loop_s_all": loops, "achieved_all": [comp_gb / x for x in loops], "compressed_gb": comp_gb,
+                           "what": "compressed bytes of the spans / time from the first span's device call to the last flush (CLI's own clock, INQ_TIMING), median"}
+            if h2d:
+                res["pcie"]["peak_measured"] = h2d
+                res["pcie"]["frac_of_measured"] = ach / h2d["value"]
+        if floor:
+            res["startup_floor"] = floor
+            res["gpu_cli_device_front"]["seconds_median_minus_floor"] = t_dev - floor["seconds_median"]
         # the same command, handed to a process that already holds the device context (`inquistr serve`; `inquistr call` with
         # INQ_SERVER set passes its arguments and its stdout to it): what a file costs in a pipeline that starts one process per
         # sample, without the HIP runtime's start-up and the exit of a process that mapped GBs.  Whole client process, start to exit.
@@ -183,34 +323,39 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                                          "inq_identical": all(o == out_dev for _, o in sv),
                                          "note": "inquistr call with INQ_SERVER=<socket of a running `inquistr serve`>: same CLI, the device context is resident"}
                 res["speedup_served_vs_B"] = res["gpu_cli_served"]["loci_per_s"] / res["cpu_B"]["loci_per_s"]
-                # ... and with callers queueing (a workflow manager starts several at once): the server stages file k + 1 while it
-                # calls file k; 4 callers started together, wall time until the last has left
-                n_par = 4  # (with this process and the server: six on the card at most even if every caller had to start a context)
-                if server.poll() is not None:
-                    raise RuntimeError("inquistr serve is gone")
-                t = time.perf_counter()
-                # (stdout into files: the server writes a caller's rows while the others wait their turn; pipes read one after the
-                # other by this process would fill up and stall the queue)
-                fs = [open(os.path.join(tmp, f"par{i}.inq"), "wb") for i in range(n_par)]
-                ps = [subprocess.Popen(cmd, env=env_s, stdout=fs[i], stderr=subprocess.DEVNULL) for i in range(n_par)]
-                try:
-                    for p in ps:
-                        p.wait(timeout=300)
-                except Exception:
-                    for p in ps:
-                        if p.poll() is None:
-                            p.kill()
-                    raise
-                dt_par = time.perf_counter() - t
-                for f in fs:
-                    f.close()
-                outs = [open(os.path.join(tmp, f"par{i}.inq"), "rb").read() for i in range(n_par)]
-                res["gpu_cli_served"]["callers_at_once"] = {"callers": n_par, "seconds_all_done": dt_par, "seconds_per_file": dt_par / n_par,
-                                                             "loci_per_s": loci * n_par / dt_par, "inq_identical": all(o == out_dev for o in outs),
-                                                             "speedup_vs_B": (loci * n_par / dt_par) / res["cpu_B"]["loci_per_s"]}
-                subprocess.run([cli, "serve", "--socket", sock, "--quit"], capture_output=True, timeout=60)
-                server.wait(timeout=60)
+                if served_callers > 0:
+                    # ... and with callers queueing (a workflow manager starts several at once): the server stages file k + 1 while it
+                    # calls file k; 4 callers started together, wall time until the last has left
+                    n_par = served_callers
+                    if server.poll() is not None:
+                        raise RuntimeError("inquistr serve is gone")
+                    t = time.perf_counter()
+                    # (stdout into files: the server writes a caller's rows while the others wait their turn; pipes read one after the
+                    # other by this process would fill up and stall the queue)
+                    fs = [open(os.path.join(tmp, f"par{i}.inq"), "wb") for i in range(n_par)]
+                    ps = [subprocess.Popen(cmd, env=env_s, stdout=fs[i], stderr=subprocess.DEVNULL) for i in range(n_par)]
+                    try:
+                        for p in ps:
+                            p.wait(timeout=300)
+                    except Exception:
+                        for p in ps:
+                            if p.poll() is None:
+                                p.kill()
+                        raise
+                    dt_par = time.perf_counter() - t
+                    for f in fs:
+                        f.close()
+                    outs = [open(os.path.join(tmp, f"par{i}.inq"), "rb").read() for i in range(n_par)]
+                    res["gpu_cli_served"]["callers_at_once"] = {"callers": n_par, "seconds_all_done": dt_par, "seconds_per_file": dt_par / n_par,
+                                                                 "loci_per_s": loci * n_par / dt_par, "inq_identical": all(o == out_dev for o in outs),
+                                                                 "speedup_vs_B": (loci * n_par / dt_par) / res["cpu_B"]["loci_per_s"]}
             finally:
+                if server.poll() is None:
+                    subprocess.run([cli, "serve", "--socket", sock, "--quit"], capture_output=True, timeout=60)
+                    try:
+                        server.wait(timeout=60)
+                    except Exception:  # noqa: BLE001
+                        pass
                 if server.poll() is None:
                     server.kill()
                     server.wait(timeout=60)
@@ -238,38 +383,39 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         # a cohort: the same command for several BAMs in ONE process (`inquistr cohort` = inq_session_call_many: one HIP context,
         # file k + 1 staged while file k is called).  The HIP runtime's start-up - 0.1 to 0.4 s from run to run, most of a single
         # file's time at this size - is paid once; what an added file costs is (t(n files) - t(1 file)) / (n - 1).
-        try:
-            n_co = 5
-            links = []
-            for k in range(n_co):
-                ln = f"{prefix}.co{k}.bam"
-                for ext in ("", ".bai"):
-                    if os.path.exists(ln + ext):
-                        os.unlink(ln + ext)
-                    os.link(prefix + ".bam" + ext, ln + ext)
-                links.append(ln)
-            outdir = os.path.join(tmp, "cohort_out")
-            os.makedirs(outdir, exist_ok=True)
-            co = [cli, "cohort", "-R", prefix + ".bed", "-t", str(threads), "--out-dir", outdir] + un
-            env_d = dict(os.environ, INQ_FRONTEND="device")
-            t1 = statistics.median(run(co + links[:1], env_d)[0] for _ in range(3))
-            tn = statistics.median(run(co + links, env_d)[0] for _ in range(3))
-            per = max((tn - t1) / (n_co - 1), 1e-9)
-            # the library's own clock between two files of the cohort (stderr of one more run): what a file costs once the
-            # context is there, without the process's start and its exit (tearing down GBs of mappings: tenths of a second)
-            r = subprocess.run(co + links, capture_output=True, env=dict(env_d, INQ_TIMING="1"))
-            import re as _re
+        if cohort:
+            try:
+                n_co = 5
+                links = []
+                for k in range(n_co):
+                    ln = f"{prefix}.co{k}.bam"
+                    for ext in ("", ".bai"):
+                        if os.path.exists(ln + ext):
+                            os.unlink(ln + ext)
+                        os.link(prefix + ".bam" + ext, ln + ext)
+                    links.append(ln)
+                outdir = os.path.join(tmp, "cohort_out")
+                os.makedirs(outdir, exist_ok=True)
+                co = [cli, "cohort", "-R", prefix + ".bed", "-t", str(threads), "--out-dir", outdir] + un
+                env_d = dict(os.environ, INQ_FRONTEND="device")
+                t1 = statistics.median(run(co + links[:1], env_d)[0] for _ in range(3))
+                tn = statistics.median(run(co + links, env_d)[0] for _ in range(3))
+                per = max((tn - t1) / (n_co - 1), 1e-9)
+                # the library's own clock between two files of the cohort (stderr of one more run): what a file costs once the
+                # context is there, without the process's start and its exit (tearing down GBs of mappings: tenths of a second)
+                r = subprocess.run(co + links, capture_output=True, env=dict(env_d, INQ_TIMING="1"))
+                import re as _re
 
-            inner = [float(x) for x in _re.findall(r"\[inq session\].*?([\d.]+) ms since the previous file finished", r.stderr.decode())]
-            body = out_dev.split(b"\n", 1)[1]
-            same = all(open(os.path.join(outdir, os.path.basename(ln)[: -len(".bam")] + ".inq"), "rb").read().split(b"\n", 1)[1] == body for ln in links)
-            res["cohort"] = {"files": n_co, "seconds_1_file": t1, "seconds_n_files": tn, "seconds_per_added_file": per,
-                             "loci_per_s_per_added_file": loci / per, "speedup_vs_B_per_added_file": (loci / per) / res["cpu_B"]["loci_per_s"],
-                             "ms_per_file_inside_the_session": inner[1:], "loci_per_s_inside_the_session": (loci / (statistics.median(inner[1:]) / 1e3)) if len(inner) > 1 else None,
-                             "rows_identical_to_single_calls": bool(same),
-                             "note": "inquistr cohort (many calls in one process, one device context); medians of 3 whole-process wall times; the files are hard links of the one BAM (every program here reads from the page cache)"}
-        except Exception as e:  # noqa: BLE001
-            res["cohort"] = {"error": f"{type(e).__name__}: {e}"}
+                inner = [float(x) for x in _re.findall(r"\[inq session\].*?([\d.]+) ms since the previous file finished", r.stderr.decode())]
+                body = out_dev.split(b"\n", 1)[1]
+                same = all(open(os.path.join(outdir, os.path.basename(ln)[: -len(".bam")] + ".inq"), "rb").read().split(b"\n", 1)[1] == body for ln in links)
+                res["cohort"] = {"files": n_co, "seconds_1_file": t1, "seconds_n_files": tn, "seconds_per_added_file": per,
+                                 "loci_per_s_per_added_file": loci / per, "speedup_vs_B_per_added_file": (loci / per) / res["cpu_B"]["loci_per_s"],
+                                 "ms_per_file_inside_the_session": inner[1:], "loci_per_s_inside_the_session": (loci / (statistics.median(inner[1:]) / 1e3)) if len(inner) > 1 else None,
+                                 "rows_identical_to_single_calls": bool(same),
+                                 "note": "inquistr cohort (many calls in one process, one device context); medians of 3 whole-process wall times; the files are hard links of the one BAM (every program here reads from the page cache)"}
+            except Exception as e:  # noqa: BLE001
+                res["cohort"] = {"error": f"{type(e).__name__}: {e}"}
         if "cpu_B_all_cores" in res:
             res["inq_identical"] = bool(res["inq_identical"] and res["cpu_B_all_cores"]["inq_identical"])
             res["speedup_vs_B_all_cores"] = res["gpu_cli_device_front"]["loci_per_s"] / res["cpu_B_all_cores"]["loci_per_s"]
@@ -311,6 +457,13 @@ def stage_summary(stderr_text: str, bam_bytes: int):
     for ln in stderr_text.splitlines():
         if ln.startswith("[inq timing] device front end:"):
             tot["cli_timing"] = ln[len("[inq timing] "):]
+        m = re.search(r"\[inq timing\] span loop: (\d+) spans, ([\d.]+) MB compressed, ([\d.]+) s", ln)
+        if m:  # first span handed to the device -> last flush done: the file's cost behind the process's fixed costs
+            tot["span_loop_s"] = float(m.group(3))
+            tot["span_loop_comp_mb"] = float(m.group(2))
+        m = re.search(r"device context ready \(inq_ctx_create ([\d.]+) ms\)", ln)
+        if m:
+            tot["ctx_create_ms"] = float(m.group(1))
     return tot
 
 
@@ -423,8 +576,11 @@ def main():
     ap.add_argument("--l2-seq-default-loci", type=int, default=6_000,
                     help="loci of the SEQ / QUAL-bearing BAM the default line's l2_seq block is timed on (30 reads x ~18 KB each per locus)")
     ap.add_argument("--no-l2-seq", action="store_true", help="skip the l2_seq block of the default N=1 line")
-    ap.add_argument("--l2-seq-large-loci", type=int, default=40_000,
-                    help="loci of the large SEQ / QUAL-bearing BAM (40 000 = 12.8 GB) of the default line's l2_seq_large block; 0 skips it")
+    ap.add_argument("--l2-seq-large-loci", type=int, default=-1,
+                    help="loci of the large SEQ / QUAL-bearing BAM of the default line's l2_seq_large block (0.32 GB per 1 000 loci; north_star's "
+                         "configuration is 100 000 = 32 GB); -1 = the largest size up to 100 000 that disk, page cache and --l2-seq-large-gen-budget admit; 0 skips it")
+    ap.add_argument("--l2-seq-large-gen-budget", type=float, default=80.0, help="seconds the default line may spend WRITING the large file")
+    ap.add_argument("--l2-level", type=int, default=6, help="zlib level of the BAMs the l2 blocks are timed on (6 = htslib's default)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: the workload's n_loci are split over the ranks (config #4: --workload shard500k --scaling strong)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_latest.json"))
@@ -676,33 +832,76 @@ def main():
             line["parity_checked_loci"] = n_s
             line["parity"] = "rows of the cpu_baseline sample produced by the timed steps == CPU oracle rows (bit-exact, NaN == NaN)"
         if world == 1 and not args.no_l2:
+            # The end-to-end blocks.  Files are written at zlib level 6 (htslib's default for BAM output); `l2_seq_level1` is the
+            # level-1 twin of `l2_seq` (rounds 1 - 3 wrote level 1), so that what the level does is visible in one line.
+            # At most three GPU processes at any time: this one, and either a CLI run or a server with its one caller.
+            floor = None
+            h2d = None
             try:
-                line["l2"] = l2_block(wl.name, min(args.l2_default_loci, wl.n_loci), host_threads(), dev)
+                floor = startup_floor()
+                h2d = h2d_copy_peak(dev)
+            except Exception as e:  # noqa: BLE001
+                line["l2_probe_error"] = f"{type(e).__name__}: {e}"
+            if floor:
+                line["startup_floor"] = floor
+            if h2d:
+                line["h2d_copy_peak"] = h2d
+            try:
+                line["l1"] = l1_block(wl, local_rank)
+            except Exception as e:  # noqa: BLE001
+                line["l1"] = {"error": f"{type(e).__name__}: {e}"}
+            lvl = args.l2_level
+            try:
+                line["l2"] = l2_block(wl.name, min(args.l2_default_loci, wl.n_loci), host_threads(), dev, level=lvl, floor=floor, h2d=h2d)
             except Exception as e:  # noqa: BLE001  the L0 line above stays valid without it
                 line["l2"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_l2 and not args.no_l2_seq:
             try:  # the same comparison on records shaped like a real long-read BAM (SEQ, QUAL, ML / MM, HP last)
-                line["l2_seq"] = l2_block(wl.name, min(args.l2_seq_default_loci, wl.n_loci), host_threads(), dev, a_loci=2_000, c_loci=300, seq=True)
+                line["l2_seq"] = l2_block(wl.name, min(args.l2_seq_default_loci, wl.n_loci), host_threads(), dev, a_loci=2_000, c_loci=300, seq=True,
+                                          level=lvl, cohort=False, floor=floor, h2d=h2d)
             except Exception as e:  # noqa: BLE001
                 line["l2_seq"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_l2 and not args.no_l2_seq and args.l2_seq_large_loci > 0:
+            if lvl != 1:
+                try:
+                    line["l2_seq_level1"] = l2_block(wl.name, min(args.l2_seq_default_loci, wl.n_loci), host_threads(), dev, reps=3, seq=True, level=1,
+                                                     lean=True, cohort=False, floor=floor, h2d=h2d)
+                except Exception as e:  # noqa: BLE001
+                    line["l2_seq_level1"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_l2 and not args.no_l2_seq and args.l2_seq_large_loci != 0:
             # ... and on a file large enough for the process's fixed costs (the HIP runtime's start-up, 0.2 - 0.5 s) not to be the
-            # measurement: ~0.32 MB of BAM per locus, generated in /tmp and kept in the page cache like every file here
+            # measurement: north_star's own configuration is 100 000 loci x 30 reads of long-read records = 32 GB of BAM.  The default
+            # line takes the largest size up to that which (a) disk and page cache admit and (b) can be WRITTEN within
+            # --l2-seq-large-gen-budget seconds at this level on the cores this box grants, estimated from the l2_seq file written a
+            # moment ago (zlib level 6 costs ~55 core-milliseconds per MB of records; 100 000 loci are ~3 core-hours/60);
+            # --l2-seq-large-loci 100000 forces the full configuration (profiles/r04_results/ holds such a run).
             import shutil
             import tempfile
 
-            need = int(args.l2_seq_large_loci * 0.33e6 * 1.3)
+            want = args.l2_seq_large_loci if args.l2_seq_large_loci > 0 else 100_000
+            chosen_by = "--l2-seq-large-loci" if args.l2_seq_large_loci > 0 else "north_star's 100 000 loci"
+            if args.l2_seq_large_loci < 0:
+                small = line.get("l2_seq", {})
+                rate = small.get("loci", 0) / small["bam_gen_s"] if small.get("bam_gen_s") else 0.0  # loci written per second
+                if rate > 0 and want > rate * args.l2_seq_large_gen_budget:
+                    want = int(rate * args.l2_seq_large_gen_budget) // 1000 * 1000
+                    chosen_by = (f"generation budget: {args.l2_seq_large_gen_budget:.0f} s at {rate:.0f} loci/s written "
+                                 f"(level {lvl}, {host_cores_available()} cores)")
             free = shutil.disk_usage(tempfile.gettempdir()).free
             try:
                 avail = int(next(ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")).split()[1]) * 1024
             except Exception:  # noqa: BLE001
                 avail = 0
-            if free < need or avail < 2 * need:
-                line["l2_seq_large"] = {"skipped": f"needs {need / 1e9:.0f} GB of disk and twice that of memory for the page cache; "
-                                                   f"{free / 1e9:.0f} GB / {avail / 1e9:.0f} GB available"}
+            per_locus = 0.33e6 * 1.3
+            cap = int(min(free / per_locus, avail / (2 * per_locus))) // 1000 * 1000
+            if cap < want:
+                want, chosen_by = cap, f"disk / page cache: {free / 1e9:.0f} GB free in {tempfile.gettempdir()}, {avail / 1e9:.0f} GB of memory available"
+            if want < 5_000:
+                line["l2_seq_large"] = {"skipped": f"no room or time for a large file ({chosen_by})"}
             else:
                 try:
-                    line["l2_seq_large"] = l2_block(wl.name, min(args.l2_seq_large_loci, wl.n_loci), host_threads(), dev, reps=3, seq=True, lean=True)
+                    line["l2_seq_large"] = l2_block(wl.name, min(want, wl.n_loci), host_threads(), dev, reps=5, seq=True, lean=True, level=lvl,
+                                                    cohort=False, floor=floor, h2d=h2d, trace_runs=5)
+                    line["l2_seq_large"]["size_chosen_by"] = chosen_by
                 except Exception as e:  # noqa: BLE001
                     line["l2_seq_large"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)

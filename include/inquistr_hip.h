@@ -179,11 +179,11 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * call from the code lengths in a few sampled block headers;
  * "inflate_tokens" = 1: the workgroup inflate keeps the symbols its counting passes decode (32 KB of device scratch per BGZF
  * block) so that its commit step does not decode them again (+3 - 4 % on match-heavy blocks, -2 ... -5 % on sequence / quality
- * bytes: the stores cost what the second decode did), 0 = it decodes again, -1 (default) = on for spans whose sampled block
- * headers say match-heavy;
- * "inflate_ahead" = 1: inq_span_stage inflates a span right behind its upload, on a stream of its own, so that the inflate of
- * span k + 1 runs next to span k's record scan, gather and join (costs one inflated buffer and token scratch per staging slot);
- * 0 (default) = the span is inflated when it is called;
+ * bytes, and four times the HBM traffic of the inflate: the stores cost what the second decode did), 0 (default since round 4) =
+ * it decodes again, -1 = on for spans whose sampled block headers say match-heavy (round 3's default);
+ * "inflate_ahead" = 1 (default since round 4): inq_span_stage inflates a span right behind its upload, on a stream of its own, so
+ * that the inflate of span k + 1 runs next to span k's record scan, gather and join (costs one inflated buffer per staging slot:
+ * device allocations cost microseconds, tools/alloc_probe.hip); 0 = the span is inflated when it is called;
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);
@@ -272,12 +272,13 @@ typedef struct inq_span_stats {
 int inq_call_span(inq_ctx_t *ctx, const inq_span_t *span, inq_result_t *result, inq_span_stats_t *stats);
 
 /* Two-step form for files of many spans: inq_span_stage uploads the compressed bytes, the block table and the
- * anchors of a span into one of six device-side slots (0 .. 5) on the library's copy stream and returns when they are
+ * anchors of a span into one of INQ_SPAN_SLOTS device-side slots (0 .. 7) on the library's copy stream and returns when they are
  * there; inq_call_span_staged then runs the span from that slot without uploading.  inq_span_stage may be
  * called from another host thread while an inq_call_span / inq_call_span_staged of an EARLIER span is in
  * progress on the same ctx (different slot): the upload of span k+1 then overlaps the inflate of span k.
  * A slot may be staged again once the call that used it has returned.  span->comp must be the same pointer
  * and sizes in both calls. */
+#define INQ_SPAN_SLOTS 8 /* two sets of four: a session stages the next file's spans while this file's are called */
 int inq_span_stage(inq_ctx_t *ctx, const inq_span_t *span, int slot);
 int inq_call_span_staged(inq_ctx_t *ctx, const inq_span_t *span, int slot, inq_result_t *result,
                          inq_span_stats_t *stats);

@@ -2,6 +2,8 @@
 // HIP only: there is no CPU fallback; without a gfx950 device every entry fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <chrono>
 
 #include <algorithm>
@@ -22,17 +24,39 @@ using namespace inq;
 
 namespace inq {
 
+void retire(inq_ctx *c, void *p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(c->retired_mu);
+    c->retired.emplace_back(p, bytes);
+    c->retired_bytes += bytes;
+}
+
+void purge_retired(inq_ctx *c) {
+    std::vector<std::pair<void *, size_t>> gone;
+    {
+        std::lock_guard<std::mutex> g(c->retired_mu);
+        gone.swap(c->retired);
+        c->retired_bytes = 0;
+    }
+    for (auto &e : gone) (void)hipFree(e.first);  // hipFree waits for the device: work that still reads the buffer ends first
+}
+
 int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return INQ_OK;
     if (b.p) {
-        // earlier launches (possibly on the caller's stream) may still use the old buffer
-        HIP_TRY(c, hipDeviceSynchronize());
-        HIP_TRY(c, hipFree(b.p));
+        // earlier launches (possibly on the caller's stream) may still use the old buffer: it is parked, not freed (ctx.h)
+        retire(c, b.p, b.cap);
         b.p = nullptr;
         b.cap = 0;
+        bool too_much;
+        {
+            std::lock_guard<std::mutex> g(c->retired_mu);
+            too_much = c->retired_bytes > (16ull << 30);
+        }
+        if (too_much) purge_retired(c);
     }
     // grow with headroom: batches of a sweep vary in size, reallocating for each new maximum would
-    // put a device-wide free/malloc in front of most calls
+    // put a malloc in front of most calls
     size_t want = bytes < 256 ? 256 : bytes + bytes / 2 + (1u << 16);
     HIP_TRY(c, hipMalloc(&b.p, want));
     b.cap = want;
@@ -129,6 +153,7 @@ void inq_ctx_destroy(inq_ctx_t *c) {
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->span) span_state_destroy(c->span);
+    purge_retired(c);
     for (DevBuf *b : {&c->worklist, &c->sval, &c->smeta, &c->cigar, &c->reads, &c->pair_read, &c->off, &c->lstart,
                       &c->lend, &c->p1, &c->p2, &c->pcall, &c->pbits, &c->ovalues, &c->olen, &c->oflags, &c->okeep, &c->otrans})
         if (b->p) (void)hipFree(b->p);
@@ -328,6 +353,7 @@ static int call_batch_impl(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r) 
     HIP_TRY(c, hipMemsetAsync(&c->d_status->err, 0, sizeof(unsigned int), s));
     HIP_TRY(c, hipMemsetAsync(&c->d_status->ties, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    purge_retired(c);  // the stream is idle: buffers this call outgrew go back now
     r->n_tie_loci = c->h_status->ties;
     return status_to_code(c->h_status->err);
 }

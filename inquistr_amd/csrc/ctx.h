@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/inquistr_hip.h"
@@ -40,16 +42,26 @@ struct inq_ctx {
     int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
     bool timing = false;
     bool verify_crc = true;  // device front end: check inflated blocks against their CRC32
-    // workgroup inflate: the counting passes leave the symbols behind for the commit (option "inflate_tokens"): +3 ... 4 % on
-    // match-heavy blocks (CIGAR-only records), -2 ... -5 % on sequence / quality bytes (profiles/r03_results/): -1 = on where the
-    // sampled block headers say match-heavy (the same look that picks the symbol loop's form), 0 / 1 = off / on
-    int inflate_tokens = -1;
+    // workgroup inflate: the counting passes leave the symbols behind for the commit (option "inflate_tokens").  Round 3 switched it on
+    // for match-heavy spans (+3 ... 4 % on CIGAR-only records); the counters then showed what it moves: 32 KB of scratch per block
+    // written in EVERY counting pass, 7.5 GB of HBM traffic for 1.79 GB of algorithmic bytes on the 501 MB file (profiles/r03_front/).
+    // With the inflate of span k + 1 now running beside the scan / gather / locus kernels of span k that traffic is no longer free:
+    // off unless asked for (1 = on, -1 = on where the sampled block headers say match-heavy, 0 = off)
+    int inflate_tokens = 0;
     int inflate_lit_pairs = -1;  // workgroup inflate's symbol loop: 1 = a second literal from the same peek, 0 = not, -1 = by the data (deflate_probe.h)
     // a staged span (inq_span_stage) is inflated right behind its upload, on a stream of its own: the device's time per span call drops
     // by a third, but a staging slot then holds an inflated buffer and token scratch of its own (4 GB more to allocate and to give back
     // for a 1 GB file: +0.3 s for a one-file process), and with the device out of the way the loop is bound by the host's reads: off
-    int inflate_ahead = 0;
+    int inflate_ahead = 1;
     uint32_t inflate_algo = 2;  // 0 = workgroup per BGZF block, 1 = lane per block, 2 = the quicker one (0 since round 2)
+    // Buffers that were outgrown.  Growing one used to mean hipDeviceSynchronize + hipFree + hipMalloc on the spot; both calls wait for
+    // EVERY stream of the device - in the span loop that is the 5 ms upload of the next span on the copy stream, ten times per file
+    // (profiles/r04_results/span_loop_growth_stalls.txt).  hipMalloc alone costs 10 - 200 us whatever the size (tools/alloc_probe.hip),
+    // so the old buffer is parked here - earlier launches may still read it - and given back at a point where the device is idle
+    // anyway (the end of a flush / of a host-buffer call, the destruction of the ctx) or when more than 16 GB wait.
+    std::mutex retired_mu;  // the uploader thread (inq_span_stage) grows its slots while the caller grows the scan buffers
+    std::vector<std::pair<void *, size_t>> retired;
+    size_t retired_bytes = 0;
     std::vector<inq::EvTriple> ev_pool;
     size_t ev_used = 0;
     inq::SpanState *span = nullptr;  // created on first use by the device front end
@@ -65,8 +77,10 @@ struct inq_ctx {
     } while (0)
 
 namespace inq {
-// grows b to at least `bytes` (with headroom); synchronises the device before freeing the old buffer
+// grows b to at least `bytes` (with headroom); the old buffer is retired, not freed: no synchronisation, contents NOT kept
 int ensure(inq_ctx *c, DevBuf &b, size_t bytes);
+void retire(inq_ctx *c, void *p, size_t bytes);
+void purge_retired(inq_ctx *c);  // hipFree of everything retired (waits for the device: call where it is idle)
 // enqueue-only launch sequence of the locus kernels over a device-resident batch
 int call_batch_device_impl(inq_ctx *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream);
 int status_to_code(uint32_t st);

@@ -48,7 +48,7 @@ struct SpanState {
         unsigned int *d_err = nullptr;  // the INQ_INFLATE_* bits of this slot's blocks
         hipEvent_t ev_up = nullptr, ev_inf0 = nullptr, ev_inf1 = nullptr;
         bool inflated = false;
-    } stage[6];  // two sets of three: the spans of the NEXT file of a cohort are staged while this file's are still being called
+    } stage[INQ_SPAN_SLOTS];  // two sets of four: the spans of the NEXT file of a cohort are staged while this file's are still being called
     hipStream_t copy_stream = nullptr;
     hipStream_t ahead_stream = nullptr;  // the inflates launched at staging time
     hipStream_t warm_stream = nullptr;  // the one warm-up copy below: the copy stream may be busy uploading the next span
@@ -129,7 +129,8 @@ int span_state(inq_ctx *c, SpanState **out) {
     return INQ_OK;
 }
 
-// grows b to `bytes`, keeping its first `used` bytes (the accumulated batch)
+// grows b to `bytes`, keeping its first `used` bytes (the accumulated batch): the copy is ordered on the stream behind everything
+// that wrote the old buffer and in front of everything that will read the new one; the old buffer is retired (ctx.h), nothing waits
 int ensure_keep(inq_ctx *c, DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
     if (bytes <= b.cap && b.p) return INQ_OK;
     void *np = nullptr;
@@ -137,16 +138,14 @@ int ensure_keep(inq_ctx *c, DevBuf &b, size_t bytes, size_t used, hipStream_t s)
     HIP_TRY(c, hipMalloc(&np, want));
     if (b.p) {
         if (used) {
-            hipError_t e = hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            const hipError_t e = hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) {
                 (void)hipFree(np);
                 c->last_err = std::string("growing the deferred batch: ") + hipGetErrorString(e);
                 return INQ_ERR_HIP;
             }
         }
-        HIP_TRY(c, hipDeviceSynchronize());
-        (void)hipFree(b.p);
+        retire(c, b.p, b.cap);
     }
     b.p = np;
     b.cap = want;
@@ -248,7 +247,7 @@ int bgzf_inflate_impl(inq_ctx *c, const uint8_t *comp, uint64_t comp_bytes, cons
 
 // defer: the span's batch is appended to S->acc instead of being called (r may be null then)
 int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_stats_t *stats, int slot, bool defer = false) {
-    if (!c || !sp || (!r && !defer) || slot > 5) return INQ_ERR_ARG;
+    if (!c || !sp || (!r && !defer) || slot >= INQ_SPAN_SLOTS) return INQ_ERR_ARG;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (sp->reserved || sp->unphased > 1) return INQ_ERR_ARG;
     if (sp->n_loci && (!sp->locus_tid || !sp->locus_start || !sp->locus_end || (!defer && (!r->phase1 || !r->phase2)))) return INQ_ERR_ARG;
@@ -408,7 +407,9 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
             return INQ_ERR_BAM;
         }
         if ((rc = ensure_keep(c, A.cigar, (A.n_units + n_units) * 16, A.n_units * 16, s)) != INQ_OK) return rc;
+        wall("  batch CIGAR buffer ready");
         if ((rc = ensure_keep(c, A.reads, (A.n_reads + n_valid) * sizeof(inq_read_t), A.n_reads * sizeof(inq_read_t), s)) != INQ_OK) return rc;
+        wall("  batch read buffer ready");
         a.cigar = (uint32_t *)A.cigar.p + A.n_units * 4;
         a.unit_base = (uint32_t)A.n_units;
         a.read_base = (uint32_t)A.n_reads;
@@ -425,6 +426,7 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     launch_join_count(a, n_valid, s);
     launch_scan_u32_to_u64(a.locus_cnt, a.locus_pair_off, nl, (uint64_t *)S->tmp.p, s);
     HIP_TRY(c, hipGetLastError());
+    wall("  gather + join count enqueued");
     HIP_TRY(c, hipMemcpyAsync(&S->h->val[2], a.locus_pair_off + nl, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&S->h->st, S->d_st, sizeof(FrontStatus), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -600,6 +602,7 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
     HIP_TRY(c, hipStreamSynchronize(s));
     std::memcpy(r->phase1, S->h_rows, nl * 8);
     std::memcpy(r->phase2, S->h_rows + nl, nl * 8);
+    if (c->retired_bytes > (2ull << 30)) purge_retired(c);  // (an unlocked look: a stale value only moves the purge to the next flush)
     if (ms_call) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, S->ev[4], S->ev[5]);
@@ -613,7 +616,7 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
 
 // Runs on whatever host thread calls it, on the copy stream; touches only stage[slot] (and ctx->last_err on failure).
 int span_stage_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
-    if (!c || !sp || slot < 0 || slot > 5) return INQ_ERR_ARG;
+    if (!c || !sp || slot < 0 || slot >= INQ_SPAN_SLOTS) return INQ_ERR_ARG;
     const uint64_t nb = sp->n_blocks, na = sp->n_anchors;
     const uint64_t u_bytes = nb ? sp->blocks[nb - 1].out_off + sp->blocks[nb - 1].isize : 0;
     int rc = check_blocks(sp->comp, sp->comp_bytes, sp->blocks, nb, u_bytes, true);
@@ -626,6 +629,11 @@ int span_stage_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
     g.valid = false;
     constexpr size_t kPad = 64;
     hipStream_t s = S->copy_stream;
+    const bool verbose = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
+    const auto w0 = std::chrono::steady_clock::now();
+    auto wall = [&](const char *what) {
+        if (verbose) std::fprintf(stderr, "[inq stage host] slot %d %-28s at %.2f ms\n", slot, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+    };
     if ((rc = ensure(c, g.comp, sp->comp_bytes + kPad)) != INQ_OK) return rc;
     if ((rc = ensure(c, g.blocks, nb * sizeof(inq_bgzf_block_t))) != INQ_OK) return rc;
     if ((rc = ensure(c, g.anchors, na * 8)) != INQ_OK) return rc;
@@ -635,6 +643,7 @@ int span_stage_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
     if (nb) HIP_TRY(c, hipMemcpyAsync(g.blocks.p, sp->blocks, nb * sizeof(inq_bgzf_block_t), hipMemcpyHostToDevice, s));
     if (na) HIP_TRY(c, hipMemcpyAsync(g.anchors.p, sp->anchors, na * 8, hipMemcpyHostToDevice, s));
     if (na) HIP_TRY(c, hipMemcpyAsync(g.anchor_stop.p, sp->anchor_stop, na * 8, hipMemcpyHostToDevice, s));
+    wall("copies enqueued");
     g.inflated = false;
     if (c->inflate_ahead && nb) {
         // the inflate behind the upload, on the ahead stream (the copy stream goes on with the next span's bytes)
@@ -667,8 +676,10 @@ int span_stage_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(g.ev_inf1, sa));
         g.inflated = true;
+        wall("inflate enqueued");
     }
     HIP_TRY(c, hipStreamSynchronize(s));  // the upload (the caller's buffer is free again); the inflate goes on
+    wall("upload done");
     g.host_comp = sp->comp;
     g.comp_bytes = sp->comp_bytes;
     g.n_blocks = nb;

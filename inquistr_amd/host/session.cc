@@ -92,7 +92,7 @@ static int inq_session_call_many_impl(inq_session_t *S, const inq_call_args_t *a
     for (size_t k = 0; k < n; ++k) {
         // file k + 1 is staged (opened, planned, read, uploaded into the other set of device slots) while file k is called
         std::future<void> next;
-        if (k + 1 < n) next = std::async(std::launch::async, [&, k] { stage_file(S, &args[k + 1], 3 * (int)((k + 1) & 1), st[k + 1]); });
+        if (k + 1 < n) next = std::async(std::launch::async, [&, k] { stage_file(S, &args[k + 1], SpanPipeline::kSlotsPerSet * (int)((k + 1) & 1), st[k + 1]); });
         char msg[1024] = {0};
         const auto t0 = std::chrono::steady_clock::now();
         int rc;
@@ -128,7 +128,7 @@ int inq_session_stage(inq_session_t *S, const inq_call_args_t *args, inq_staged_
     *out = nullptr;
     try {
         std::unique_ptr<inq_staged> st(new inq_staged());
-        stage_file(S, args, 3 * (int)(S->n_staged++ & 1u), st->f);  // what it finds wrong is reported by inq_session_run
+        stage_file(S, args, SpanPipeline::kSlotsPerSet * (int)(S->n_staged++ & 1u), st->f);  // what it finds wrong is reported by inq_session_run
         *out = st.release();
         return INQ_EXIT_OK;
     } catch (...) {

@@ -145,6 +145,10 @@ void SpanPipeline::run() {
     SpanLoader loader;
     std::string e;
     if (!loader.open(path_, &e)) return fail(e);
+    // the reader threads of this file (span_planner.h: spread over the L3 domains of the GPU's NUMA node)
+    const char *pin_env = std::getenv("INQ_IO_PIN");
+    IoPool pool(n_threads_, guess_gpu_numa_node(device_), !(pin_env && pin_env[0] == '0'));
+    if (verbose_) std::fprintf(stderr, "[inq loader] @%.1f %s\n", stamp_ms(), pool.layout().c_str());
     // span k + 1 is planned (index searches for some 25 000 loci: ~4 ms) on a helper thread while span k is being read
     SpanPlan ahead;
     bool have = planner_.next(ahead);
@@ -171,10 +175,23 @@ void SpanPipeline::run() {
         if (nbytes > (64ull << 30)) return fail("a span of the BAM exceeds 64 GiB (index without usable bins)");
         if (!fit(*it, (size_t)nbytes + 64)) return fail("cannot allocate the span buffer");
         const auto t2 = std::chrono::steady_clock::now();
-        if (!loader.load(it->plan, planner_.anchors(), it->buf, n_threads_, it->data, &e)) return fail(e);
+        if (!loader.load(it->plan, planner_.anchors(), it->buf, n_threads_, it->data, &e, &pool)) return fail(e);
         it->staged = false;
         if (verbose_) {
             const auto t3 = std::chrono::steady_clock::now();
+            {   // where the buffer's pages lie (a sample, asked of the kernel), and on which CPUs the readers ran
+                const size_t ps = 4096, n_s = 64;
+                void *pages[n_s];
+                int status[n_s];
+                for (size_t k = 0; k < n_s; ++k) pages[k] = it->buf + ((size_t)nbytes / n_s * k) / ps * ps;
+                long rc = ::syscall(SYS_move_pages, 0, (unsigned long)n_s, pages, nullptr, status, 0);
+                int on[4] = {0, 0, 0, 0};
+                if (rc >= 0)
+                    for (size_t k = 0; k < n_s; ++k)
+                        if (status[k] >= 0 && status[k] < 4) on[status[k]]++;
+                std::fprintf(stderr, "[inq loader] slot %d buffer pages by node (64 samples): %d %d %d %d; reader CPUs: %s\n", it->slot, on[0], on[1], on[2], on[3],
+                             pool.last_cpus().c_str());
+            }
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             std::fprintf(stderr, "[inq loader] @%.1f slot %d: plan %.2f ms, buffer %.2f ms (%s), read+tables %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
                          stamp_ms(), it->slot, ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), nbytes / 1e6,
@@ -328,6 +345,10 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
         constexpr uint64_t kFlushWords = 1ull << 31;    // ... or 8 GB of gathered CIGARs
         std::vector<uint32_t> pending;
         uint64_t pending_words = 0;
+        // the span loop by itself: from the moment the first span is handed to the device (the context is there, the span read and
+        // uploaded) to the last flush - what the file costs once the process's fixed costs are behind it
+        clk::time_point t_loop0{};
+        uint64_t loop_spans = 0, loop_comp_bytes = 0;
         auto flush = [&]() -> int {
             if (pending.empty()) return INQ_EXIT_OK;
             const auto f0 = clk::now();
@@ -386,6 +407,8 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
             // the span's batch is appended to the one on the device; the locus kernels run once enough loci wait (a span of
             // SEQ-bearing records holds a few hundred loci, a launch wants tens of thousands) or the file is through
             inq_span_stats_t stt;
+            if (loop_spans++ == 0) t_loop0 = clk::now();
+            loop_comp_bytes += sp.comp_bytes;
             int rc2 = inq_call_span_deferred(ctx, &sp, it->staged ? it->slot : -1, &stt);
             *t_dev += secs(tb, clk::now());
             if (timing == 2)
@@ -417,6 +440,11 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
         if (hrc == INQ_OK) {
             int frc = flush();
             if (frc != INQ_EXIT_OK) return frc;
+        }
+        if (timing && loop_spans) {
+            const double loop_s = secs(t_loop0, clk::now());
+            std::fprintf(stderr, "[inq timing] span loop: %llu spans, %.1f MB compressed, %.4f s from the first span's call to the last flush = %.2f GB/s\n",
+                         (unsigned long long)loop_spans, loop_comp_bytes / 1e6, loop_s, loop_comp_bytes / 1e9 / std::max(loop_s, 1e-9));
         }
         leak_all = fast_exit;  // only after a clean run: error paths tear down normally
         if (const char *probe = std::getenv("INQ_EXIT_PROBE")) {

@@ -59,6 +59,9 @@ struct HostBufPool {
 // of the caller, who feeds inq_call_span().
 class SpanPipeline {
 public:
+    // span buffers (and device staging slots) per file: one being read, one being uploaded, one being inflated / scanned, and one of
+    // slack - read (4 ms), upload (4.9 ms) and device (4.5 ms) of a 268 MB span are so close that with three any jitter stalled all
+    static constexpr int kSlotsPerSet = INQ_SPAN_SLOTS / 2;
     struct Item {
         SpanPlan plan;
         SpanData data;
@@ -73,7 +76,7 @@ public:
     // stage: called on the loader thread for every loaded span with the filled inq_span_t; returns true when the
     // span now sits in device slot `slot` (the upload then overlaps the caller's work on earlier spans)
     using StageFn = std::function<bool(const inq_span_t &, int slot)>;
-    // slot_base: 0 or 3, the set of device-side staging slots this pipeline uploads into; pool: where span buffers come from
+    // slot_base: 0 or kSlotsPerSet, the set of device-side staging slots this pipeline uploads into; pool: where span buffers come from
     // and go back to (may be null: mapped and unmapped by the pipeline)
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
                  uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr,
@@ -82,8 +85,10 @@ public:
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
           stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), gate_registered_(std::move(runtime_gate)),
           numa_query_(std::move(numa_query)), device_(device) {
-        for (int i = 0; i < 3; ++i) slots_[i].slot = slot_base + i;
-        for (auto &it : slots_) free_.push_back(&it);
+        for (int i = 0; i < kSlotsPerSet; ++i) slots_[i].slot = slot_base + i;
+        int use = kSlotsPerSet;
+        if (const char *e = std::getenv("INQ_SPAN_BUFFERS")) use = std::min(kSlotsPerSet, std::max(2, std::atoi(e)));  // A/B only
+        for (int i = 0; i < use; ++i) free_.push_back(&slots_[i]);
         th_ = std::thread([this] { run(); });
         if (stage_) up_ = std::thread([this] { run_uploads(); });  // span k uploads while span k + 1 is being read
     }
@@ -159,7 +164,7 @@ private:
     std::function<int()> numa_query_;  // the GPU's NUMA node, kNumaUnknown while the context is not there yet, -1 = do not place
     int device_ = 0;
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
-    Item slots_[3];
+    Item slots_[kSlotsPerSet];
     std::vector<Item *> free_;
     std::deque<Item *> ready_, loaded_;
     std::thread th_, up_;

@@ -1,19 +1,159 @@
 #include "span_planner.h"
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <map>
 #include <thread>
 
 namespace inqhost {
 
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// ---------------------------------------------------------------- reader threads
+namespace {
+
+// "0-63,128-191" -> CPUs
+std::vector<int> parse_cpulist(const char *s) {
+    std::vector<int> out;
+    for (const char *p = s; *p;) {
+        char *q;
+        long a = std::strtol(p, &q, 10), b = a;
+        if (q == p) break;
+        if (*q == '-') b = std::strtol(q + 1, &q, 10);
+        for (long k = a; k <= b && k < CPU_SETSIZE; ++k) out.push_back((int)k);
+        if (*q != ',') break;
+        p = q + 1;
+    }
+    return out;
+}
+
+bool read_line(const char *path, char *buf, size_t cap) {
+    FILE *f = std::fopen(path, "r");
+    if (!f) return false;
+    const bool ok = std::fgets(buf, (int)cap, f) != nullptr;
+    std::fclose(f);
+    return ok;
+}
+
+// the CPUs this process may use on `node` (all of them for node < 0), grouped by the L3 cache they share
+std::vector<std::vector<int>> l3_groups(int node) {
+    cpu_set_t have;
+    CPU_ZERO(&have);
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return {};
+    std::vector<int> cpus;
+    char path[160], buf[4096];
+    if (node >= 0) {
+        std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        if (read_line(path, buf, sizeof buf)) cpus = parse_cpulist(buf);
+    }
+    if (cpus.empty())
+        for (int k = 0; k < CPU_SETSIZE; ++k)
+            if (CPU_ISSET(k, &have)) cpus.push_back(k);
+    std::map<long, std::vector<int>> by_l3;
+    for (int k : cpus) {
+        if (!CPU_ISSET(k, &have)) continue;  // never beyond what the process was given
+        std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/id", k);
+        long id = -1;
+        if (read_line(path, buf, sizeof buf)) id = std::strtol(buf, nullptr, 10);
+        by_l3[id].push_back(k);
+    }
+    std::vector<std::vector<int>> out;
+    for (auto &kv : by_l3) out.push_back(std::move(kv.second));
+    return out;
+}
+
+}  // namespace
+
+IoPool::IoPool(int n_threads, int numa_node, bool pin) {
+    const int n = std::max(n_threads, 1);
+    std::vector<std::vector<int>> groups;
+    if (pin) groups = l3_groups(numa_node);
+    if (groups.size() < 2) groups.clear();  // one domain (or no topology to read): nothing to spread over
+    layout_ = std::to_string(n) + " reader threads";
+    if (!groups.empty()) layout_ += ", bound in turn to the " + std::to_string(groups.size()) + " L3 domains of " + (numa_node >= 0 ? "NUMA node " + std::to_string(numa_node) : std::string("the machine"));
+    else layout_ += pin ? ", not bound (one L3 domain or no topology in sysfs)" : ", not bound (INQ_IO_PIN=0)";
+    cpu_at_.assign((size_t)n, -1);
+    for (int i = 1; i < n; ++i) {
+        workers_.emplace_back([this, i] { work(i); });
+        if (!groups.empty()) {
+            const std::vector<int> &g = groups[(size_t)i % groups.size()];
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            for (int k : g) CPU_SET(k, &set);
+            (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof set, &set);  // best effort: placement only
+        }
+    }
+}
+
+IoPool::~IoPool() {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        stop_ = true;
+    }
+    cv_go_.notify_all();
+    for (auto &t : workers_) t.join();
+}
+
+std::string IoPool::last_cpus() const {
+    std::string s;
+    for (int c : cpu_at_) s += (s.empty() ? "" : ",") + std::to_string(c);
+    return s;
+}
+
+void IoPool::work(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<void(size_t)> *fn;
+        size_t n;
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_go_.wait(g, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            fn = fn_;
+            n = n_jobs_;
+        }
+        cpu_at_[(size_t)id] = sched_getcpu();
+        for (;;) {
+            const size_t k = next_.fetch_add(1);
+            if (k >= n) break;
+            (*fn)(k);
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        if (--busy_ == 0) cv_done_.notify_one();
+    }
+}
+
+void IoPool::run(size_t n_jobs, const std::function<void(size_t)> &fn) {
+    if (n_jobs == 0) return;
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        fn_ = &fn;
+        n_jobs_ = n_jobs;
+        next_.store(0);
+        busy_ = (int)workers_.size();
+        ++generation_;
+    }
+    cv_go_.notify_all();
+    cpu_at_[0] = sched_getcpu();
+    for (;;) {  // the caller takes jobs too
+        const size_t k = next_.fetch_add(1);
+        if (k >= n_jobs) break;
+        fn(k);
+    }
+    std::unique_lock<std::mutex> g(mu_);
+    cv_done_.wait(g, [&] { return busy_ == 0; });
+    fn_ = nullptr;
+}
 
 // ---------------------------------------------------------------- .bai views
 const BaiAnchors::PerRef &BaiAnchors::ref(int tid) {
@@ -199,7 +339,7 @@ bool SpanLoader::total_bytes(const SpanPlan &p, uint64_t *bytes, std::string *er
     return true;
 }
 
-bool SpanLoader::load(const SpanPlan &p, BaiAnchors &anch, uint8_t *buf, int n_threads, SpanData &out, std::string *err) const {
+bool SpanLoader::load(const SpanPlan &p, BaiAnchors &anch, uint8_t *buf, int n_threads, SpanData &out, std::string *err, IoPool *pool) const {
     out.blocks.clear();
     out.anchors.clear();
     out.anchor_stop.clear();
@@ -226,23 +366,30 @@ bool SpanLoader::load(const SpanPlan &p, BaiAnchors &anch, uint8_t *buf, int n_t
             uint64_t off, n, at;
         };
         std::vector<Job> jobs;
+        if (pool) n_threads = pool->threads();
         const uint64_t chunk = std::max<uint64_t>(4ull << 20, out.comp_bytes / (uint64_t)std::max(n_threads, 1) / 4 + 1);
         for (const Piece &pc : pieces)
             for (uint64_t o = pc.begin; o < pc.end; o += chunk) jobs.push_back({o, std::min(chunk, pc.end - o), pc.at + (o - pc.begin)});
-        std::atomic<size_t> nextj{0};
         std::atomic<bool> ok{true};
-        auto work = [&] {
-            for (;;) {
-                const size_t k = nextj.fetch_add(1);
-                if (k >= jobs.size()) return;
+        if (pool) {
+            pool->run(jobs.size(), [&](size_t k) {
                 if (!pread_all(fd_, buf + jobs[k].at, jobs[k].off, jobs[k].n)) ok = false;
-            }
-        };
-        const int nt = (int)std::min<size_t>((size_t)std::max(n_threads, 1), jobs.size());
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work);
-        work();
-        for (auto &x : th) x.join();
+            });
+        } else {
+            std::atomic<size_t> nextj{0};
+            auto work = [&] {
+                for (;;) {
+                    const size_t k = nextj.fetch_add(1);
+                    if (k >= jobs.size()) return;
+                    if (!pread_all(fd_, buf + jobs[k].at, jobs[k].off, jobs[k].n)) ok = false;
+                }
+            };
+            const int nt = (int)std::min<size_t>((size_t)std::max(n_threads, 1), jobs.size());
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(work);
+            work();
+            for (auto &x : th) x.join();
+        }
         if (!ok) {
             if (err) *err = "read error in BAM file";
             return false;

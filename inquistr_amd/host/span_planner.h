@@ -10,9 +10,13 @@
 // sorted file) and (c) record-start anchors inside the range (chunk begins + linear index entries).
 // The rest - inflate, record scan, overlap join, calling - is inq_call_span() on the GPU.
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
-#include <string>
+#include <functional>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/inquistr_hip.h"
@@ -83,6 +87,38 @@ struct SpanData {
     uint64_t file_begin = 0;  // file offset of the first segment
 };
 
+// The threads that copy file bytes into a span buffer (pread from the page cache): made once per file, not once per span, and
+// spread over the L3 domains (CCDs) of the NUMA node the GPU hangs on.  Why spread: a copy is bound by memory bandwidth, and on
+// the two-socket EPYC hosts measured a CCD's link to memory carries a fraction of the socket's - when the scheduler happened to
+// start a process's sixteen readers inside ONE CCD every span took 13 - 20 ms to read instead of 4 (the same bytes for five times
+// the CPU time: one run in five, profiles/r04_results/slow_run_in_five.txt).  Threads are bound to a CCD's CPUs, not to one CPU.
+class IoPool {
+public:
+    // numa_node < 0: every CPU this process may use; pin = false: plain threads (INQ_IO_PIN=0)
+    IoPool(int n_threads, int numa_node, bool pin);
+    ~IoPool();
+    IoPool(const IoPool &) = delete;
+    // fn(k) for every k < n_jobs, on the pool's threads and the caller's; returns when all have run
+    void run(size_t n_jobs, const std::function<void(size_t)> &fn);
+    int threads() const { return (int)workers_.size() + 1; }
+    const std::string &layout() const { return layout_; }  // for INQ_TIMING=2
+    std::string last_cpus() const;  // the CPU every thread found itself on when the last run() began (INQ_TIMING=2)
+
+private:
+    void work(int id);
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_go_, cv_done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    std::atomic<size_t> next_{0};
+    size_t n_jobs_ = 0;
+    uint64_t generation_ = 0;
+    int busy_ = 0;
+    bool stop_ = false;
+    std::string layout_;
+    std::vector<int> cpu_at_;  // [threads()]
+};
+
 class SpanLoader {
 public:
     SpanLoader() = default;
@@ -95,7 +131,8 @@ public:
     bool total_bytes(const SpanPlan &p, uint64_t *bytes, std::string *err) const;
     // Reads every segment into buf (back to back) with n_threads preads, walks the block headers, maps the
     // .bai anchors inside each segment to offsets in the inflated byte string.
-    bool load(const SpanPlan &p, BaiAnchors &anch, uint8_t *buf, int n_threads, SpanData &out, std::string *err) const;
+    // (pool may be null: n_threads threads are started for this one call)
+    bool load(const SpanPlan &p, BaiAnchors &anch, uint8_t *buf, int n_threads, SpanData &out, std::string *err, IoPool *pool = nullptr) const;
 
 private:
     int fd_ = -1;

@@ -379,3 +379,61 @@ def test_auto_server_gives_the_calls_own_rows(tmp_path):
     finally:
         q = subprocess.run([call.CLI_PATH, "serve", "--socket", str(sock), "--quit"], capture_output=True, text=True, timeout=60)
     assert q.returncode == 0
+
+
+@pytest.mark.parametrize("workload,n_loci,level", [("unphased100k", 60, 6), ("phased10k", 45, 6), ("expansion50k", 14, 1)])
+def test_native_seq_bearing_file_through_the_device_front_end(tmp_path, monkeypatch, workload, n_loci, level):
+    """Records shaped like a long-read BAM (SEQ + QUAL of the query length, NM, ML:B,C + MM:Z, HP as the LAST tag; ~18 KB each, most
+    of them cut by BGZF block ends) written by the native writer bench.py's l2_seq blocks use (inq_synth_write_bam_seq), at zlib
+    level 6 and 1: the device front end - inflate, CRC, record chain, aux walk over the long tags, gather, join, locus kernels,
+    several spans - must print the rows the plain-Python restatement computes from the records a plain-Python reader finds in the
+    same file (tools/bamio.py on gzip: no code shared with the product)."""
+    import gzip
+    import struct
+
+    from inquistr_amd import synth
+    from tools import bamio, make_synth_bam
+
+    monkeypatch.setattr(make_synth_bam, "LOCI_PER_CONTIG", 9)
+    monkeypatch.setattr(make_synth_bam, "CONTIG_LEN", 50_000 + 20_000 * 10_000 + 400_000)
+    prefix = str(tmp_path / "seq")
+    info = {}
+    n = make_synth_bam.write_native(workload, n_loci, prefix, threads=3, seq=True, level=level, slab_blocks=7, info=info)
+    wl = synth.WORKLOADS[workload]
+    u = gzip.open(prefix + ".bam", "rb").read()
+    assert len(u) == info["inflated_bytes"] and len(u) > 12_000 * n  # the records really carry their bases and qualities
+    l_text = struct.unpack_from("<I", u, 4)[0]
+    p = 8 + l_text
+    (n_ref,) = struct.unpack_from("<I", u, p)
+    p += 4
+    names = []
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<I", u, p)
+        names.append(u[p + 4 : p + 4 + l_name - 1].decode())
+        p += 8 + l_name
+    recs = {t: [] for t in range(n_ref)}
+    n_seen = 0
+    for r in bamio.read_records(u, p):
+        n_seen += 1
+        recs[r["tid"]].append(py.Record(pos=r["pos"], cigar=[(py.OPS[w & 15], w >> 4) for w in r["cigar"]], mapq=r["mapq"], flag=r["flag"],
+                                        tid=r["tid"], hp=r["hp"], sa=r["sa"]))
+    assert n_seen == n
+    loci = []
+    for ln in open(prefix + ".bed"):
+        c, s, e = ln.split()
+        loci.append((c, int(s), int(e), names.index(c)))
+    assert len(loci) == n_loci
+    want = _expected_text(loci, recs, wl.unphased, wl.minlen, wl.support, "S", 4)
+    cmd = [call.CLI_PATH, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", "4", "--sample-name", "S", "-m", str(wl.minlen), "-s", str(wl.support)]
+    cmd += ["-u"] if wl.unphased else []
+    for span_mb in ("256", "1"):  # one span, and several (a 1 MB span holds a few dozen of these records)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_SPAN_MB=span_mb, INQ_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == want, f"rows differ with {span_mb} MB spans"
+        if span_mb == "1":
+            import re
+
+            m = re.search(r"span loop: (\d+) spans", r.stderr)
+            assert m and int(m.group(1)) > 1
+    host = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, INQ_FRONTEND="host"))
+    assert host.returncode == 0 and host.stdout == want
