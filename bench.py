@@ -222,15 +222,6 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         info = {}
         make_synth_bam.write_native(workload, loci, prefix, threads=host_cores_available(), device=device, seq=seq, level=level, info=info)
         gen_s = time.perf_counter() - t0
-        # the file at rest before anything is timed: a BAM being read minutes after it was written is not the case measured, and
-        # GBs of dirty pages under write-back showed up as one slow run in five (profiles/r04_results/: reads 23 ms per span)
-        t_sync = time.perf_counter()
-        fd = os.open(prefix + ".bam", os.O_RDONLY)
-        try:
-            os.fsync(fd)
-        finally:
-            os.close(fd)
-        sync_s = time.perf_counter() - t_sync
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
         cli = os.path.join(ROOT, "inquistr_amd", "lib", "inquistr")
         ref = os.path.join(ROOT, "oracle", "ref_shaped_call")
@@ -251,7 +242,13 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
             return dt, r.stdout
 
         cmd = [cli, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", str(threads), "--sample-name", "S"] + un
-        run(cmd, dict(os.environ, INQ_FRONTEND="device"))  # page cache + code objects warm, as for every program below
+        # Page cache + code objects warm, as for every program below - and warm means read TWICE: the second read of a freshly written
+        # file moves every one of its page-cache pages to the active LRU list (mark_page_accessed: /proc/vmstat pgactivate + 3 131 362
+        # for the 12.8 GB file, 0 - 70 000 in every other run), under one lock per memory node, and sixteen readers then burn 13 - 15 s
+        # of CPU time instead of 3 on that lock: reads of 13 - 21 ms per span instead of 4, always run 2, never run 1 or 3 + - that was
+        # round 3's "one slow run in five" (profiles/r04_results/slow_second_read.txt).  A kernel matter, not a property of any program here.
+        run(cmd, dict(os.environ, INQ_FRONTEND="device"))
+        run(cmd, dict(os.environ, INQ_FRONTEND="device"))
         dev = [run(cmd, dict(os.environ, INQ_FRONTEND="device")) for _ in range(reps)]
         t_dev = statistics.median(t for t, _ in dev)
         out_dev = dev[0][1]
@@ -261,7 +258,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         res = {
             "level": "L2: BAM + BED -> .inq, whole process, start to exit", "workload": workload, "loci": loci, "threads": threads,
             "host_cores_available": host_cores_available(),
-            "bam_mb": bam_bytes / 1e6, "bam_gen_s": gen_s, "bam_fsync_s": sync_s, "zlib_level": level,
+            "bam_mb": bam_bytes / 1e6, "bam_gen_s": gen_s, "zlib_level": level,
             "records": ("SEQ + QUAL of the query length, NM:i, ML:B,C + MM:Z, HP:C last (long-read record shape, ~18 KB per record; "
                         "bases ACGT, Phred a clamped random walk)" if seq else "SEQ '*' (CIGAR-only records), HP:C"),
             **({"inflated_mb": info["inflated_bytes"] / 1e6, "bgzf_blocks": info["n_blocks"]} if info else {}),
@@ -728,7 +725,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    main_stream.synchronize()  # this rank's kernels are through; what follows is the tail of the gathers nothing overlaps any more
+    dt_compute = time.perf_counter() - t0
     drain()
+    dt_own = time.perf_counter() - t0  # this rank's steps + its gathers, before waiting for the other ranks
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -744,6 +744,17 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    # every rank's own clock, so that a scaling run explains itself: its steps, the tail of the gathers behind them (exposed: not
+    # hidden behind kernels), its wait at the closing barrier
+    mine = torch.tensor([dt_compute, dt_own, dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    if world > 1:
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    per_rank = [{"rank": r, "ms_per_step": float(x[1]) * 1e3 / args.steps, "kernels_ms_per_step": float(x[0]) * 1e3 / args.steps,
+                 "gather_exposed_ms_total": (float(x[1]) - float(x[0])) * 1e3, "barrier_wait_ms": (float(x[2]) - float(x[1])) * 1e3}
+                for r, x in enumerate(allr)]
 
     if rank == 0 and world > 1:
         # the last gathered group must hold rank 0's own rows in slot 0
@@ -812,6 +823,11 @@ def main():
             },
             "n_tie_loci": ties,
         }
+        if world > 1:
+            line["per_rank"] = per_rank
+            line["gather"] = {"collective": f"dist.gather ({args.backend})", "bytes_per_rank_per_collective": int(G * 2 * per_gpu * 8),
+                              "collectives": (args.steps + G - 1) // G,
+                              "exposed_ms_total_max_over_ranks": max(p["gather_exposed_ms_total"] for p in per_rank)}
         if world == 1 and not args.no_read_peak:
             pk = measured_read_peak()
             if pk:

@@ -179,6 +179,9 @@ int inq_host_plan_spans(const inq_call_args_t *args, uint64_t max_comp_bytes, ui
 int inq_host_bam_tid(const char *bam_path, const char *contig);
 int inq_host_bai_stats(const char *bai_path, uint32_t *n_ref, int32_t tid, uint64_t *n_mapped, uint64_t *n_unmapped,
                        uint64_t *n_bins, uint64_t *n_intv);
+/* Compressed BAM bytes this process has handed to the device front end so far (all calls, all files): what a rank of the
+ * one-process-per-GPU run read for its share of the targets (inq_run_partition promises every rank about the same). */
+uint64_t inq_host_span_bytes_read(void);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,9 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
     lo, hi = int(cuts[rank]), int(cuts[rank + 1])
     mine = order[lo:hi]
     # ---- this rank's rows
+    import time
+
+    t_rows = time.perf_counter()
     p1 = np.full(len(mine), np.nan)
     p2 = np.full(len(mine), np.nan)
     st, msg = 0, ""
@@ -107,6 +110,13 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
         st, msg = e.status, e.message
     except Exception as e:  # noqa: BLE001  anything else (HIP runtime, memory) is an error exit on every rank too
         st, msg = 1, f"{type(e).__name__}: {e}"
+    if stats is not None:  # every rank: its share, its time, the BAM bytes its device front end was handed
+        stats["rank"], stats["world"], stats["loci"] = rank, world, len(mine)
+        stats["rows_s"] = time.perf_counter() - t_rows
+        try:
+            stats["bam_bytes_read"] = int(hostcall.load().inq_host_span_bytes_read())
+        except Exception:  # noqa: BLE001
+            stats["bam_bytes_read"] = None
     st, msg, bad_rank = _exchange_status(st, msg, rank, world, group)
     if st != 0:
         raise hostcall.CallError(st, f"rank {bad_rank}: {msg}" if world > 1 else msg)
@@ -118,7 +128,10 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
         buf[0, : len(mine)] = torch.from_numpy(p1)
         buf[1, : len(mine)] = torch.from_numpy(p2)
         bufs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        t_g = time.perf_counter()
         dist.gather(buf, bufs, dst=0, group=group)
+        if stats is not None:
+            stats["gather_s"] = time.perf_counter() - t_g  # exposed: nothing overlaps it in a one-file call (16 B per locus)
         if rank != 0:
             return
         full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
@@ -131,8 +144,6 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
         full1[mine], full2[mine] = p1, p2
     # ---- output (rank 0), src/call.rs:137-157: BED order for -t 1, (human chrom, start) order otherwise.  One call into the
     # host library on the f64 arrays (the code inq_genotype_repeats itself ends with): 500 000 rows take tens of milliseconds
-    import time
-
     out = sys.stdout if out is None else out
     t0 = time.perf_counter()
     run.write_inq(full1, full2, out)
@@ -156,6 +167,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-device", action="store_true", help="all ranks on device 0 (rehearsal on a one-GPU box)")
     ap.add_argument("--frontend", default=None, choices=["host", "device"], help="default: by the amount of BAM each rank reads")
+    ap.add_argument("--stats-dir", default=None, help="every rank leaves rank<r>.json there: its loci, seconds, BAM bytes read, the gather's time")
     a = ap.parse_args(argv)
     import torch
     import torch.distributed as dist
@@ -171,9 +183,16 @@ def main(argv: Optional[List[str]] = None) -> int:
         else:
             dist.init_process_group("gloo")
     out = open(a.output, "w") if (a.output and rank == 0) else None
+    stats = {} if a.stats_dir else None
     try:
         genotype_repeats_distributed(a.bam, a.region, a.region_file, a.minlen, a.support, a.threads, a.unphased,
-                                     a.sample_name, out=out, rank=rank, world=world, device=device, frontend=a.frontend)
+                                     a.sample_name, out=out, rank=rank, world=world, device=device, frontend=a.frontend, stats=stats)
+        if stats is not None:
+            import json
+
+            os.makedirs(a.stats_dir, exist_ok=True)
+            with open(os.path.join(a.stats_dir, f"rank{rank}.json"), "w") as f:
+                json.dump(stats, f)
     except hostcall.CallError as e:  # the same status on every rank (the failure was exchanged before the gather)
         if rank == 0:
             print(e.message, file=sys.stderr)

@@ -280,6 +280,10 @@ __device__ uint32_t is_accidental_2d(const uint8_t *u, const RecInfo &ri, bool r
 }
 
 // ---------------------------------------------------------------- CIGAR gather
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// NT: the gathered words leave with the non-temporal policy - they are written once, 0.7 GB per CIGAR-only span, and read once by
+// the locus kernel of a LATER launch; kept out of L2 / the memory-side cache they do not have to be written back underneath it
+template <bool NT>
 __global__ __launch_bounds__(256) void cigar_gather_kernel(ScanArgs a, uint64_t n_valid) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t i = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -299,7 +303,10 @@ __global__ __launch_bounds__(256) void cigar_gather_kernel(ScanArgs a, uint64_t 
         if (k + 4u <= n) __builtin_memcpy(w, src + (uint64_t)k * 4u, 16);
         else
             for (uint32_t j = 0; j < 4u; ++j) w[j] = k + j < n ? ld32(src + (uint64_t)(k + j) * 4u) : 0u;
-        *reinterpret_cast<uint4 *>(dst + k) = make_uint4(w[0], w[1], w[2], w[3]);
+        u32x4_t v;
+        v.x = w[0], v.y = w[1], v.z = w[2], v.w = w[3];
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(dst + k));
+        else *reinterpret_cast<u32x4_t *>(dst + k) = v;
         for (uint32_t j = 0; j < 4u; ++j) {
             const uint32_t op = w[j] & 0xfu;
             if ((0x18Du >> op) & 1u) rlen += (int64_t)(w[j] >> 4);  // M D N = X consume the reference
@@ -515,7 +522,8 @@ void launch_record_parse(const ScanArgs &a, hipStream_t s) {
 }
 void launch_cigar_gather(const ScanArgs &a, uint64_t n_valid, hipStream_t s) {
     if (!n_valid) return;
-    hipLaunchKernelGGL(cigar_gather_kernel, dim3((uint32_t)((n_valid + 3) / 4)), dim3(256), 0, s, a, n_valid);
+    if (a.gather_nt) hipLaunchKernelGGL(cigar_gather_kernel<true>, dim3((uint32_t)((n_valid + 3) / 4)), dim3(256), 0, s, a, n_valid);
+    else hipLaunchKernelGGL(cigar_gather_kernel<false>, dim3((uint32_t)((n_valid + 3) / 4)), dim3(256), 0, s, a, n_valid);
 }
 void launch_join_count(const ScanArgs &a, uint64_t n_valid, hipStream_t s) {
     if (!a.n_loci) return;

@@ -504,6 +504,10 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
         c->inflate_ahead = value != 0;
         return INQ_OK;
     }
+    if (std::strcmp(key, "gather_nt") == 0) {
+        c->gather_nt = value != 0;
+        return INQ_OK;
+    }
     if (std::strcmp(key, "inflate_tokens") == 0) {
         c->inflate_tokens = value < 0 ? -1 : (value != 0);
         return INQ_OK;

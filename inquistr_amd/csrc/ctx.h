@@ -53,6 +53,9 @@ struct inq_ctx {
     // by a third, but a staging slot then holds an inflated buffer and token scratch of its own (4 GB more to allocate and to give back
     // for a 1 GB file: +0.3 s for a one-file process), and with the device out of the way the loop is bound by the host's reads: off
     int inflate_ahead = 1;
+    // the gather's stores bypass the caches (bam_scan.hip): the batch it builds is read by a later launch, not by this one; the locus
+    // kernels behind it run at 5.4 - 6.2 instead of 4.9 - 5.3 TB/s of algorithmic bytes (profiles/r04_results/locus_kernels_in_the_cli.txt)
+    bool gather_nt = true;
     uint32_t inflate_algo = 2;  // 0 = workgroup per BGZF block, 1 = lane per block, 2 = the quicker one (0 since round 2)
     // Buffers that were outgrown.  Growing one used to mean hipDeviceSynchronize + hipFree + hipMalloc on the spot; both calls wait for
     // EVERY stream of the device - in the span loop that is the 5 ms upload of the next span on the copy stream, ten times per file

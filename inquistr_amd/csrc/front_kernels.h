@@ -83,6 +83,7 @@ struct ScanArgs {
     FrontStatus *st;
     // a span appended to the batch of earlier spans (inq_call_span_deferred): the CIGAR units / reads that are already there
     uint32_t unit_base, read_base;
+    uint32_t gather_nt;  // cigar_gather_kernel stores with the non-temporal policy
 };
 
 void launch_chain_count(const ScanArgs &a, hipStream_t s);

@@ -112,6 +112,7 @@ int inq::span_state_init(inq_ctx *c) {
     HIP_TRY(c, hipStreamCreateWithFlags(&S->warm_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&S->ahead_stream, hipStreamNonBlocking));
     if (const char *e = std::getenv("INQ_INFLATE_AHEAD")) c->inflate_ahead = std::atoi(e) != 0;  // A/B and tests; the option is "inflate_ahead"
+    if (const char *e = std::getenv("INQ_GATHER_NT")) c->gather_nt = std::atoi(e) != 0;            // A/B; the option is "gather_nt"
     for (auto &g : S->stage) {
         HIP_TRY(c, hipMalloc((void **)&g.d_err, sizeof(unsigned int)));
         HIP_TRY(c, hipEventCreate(&g.ev_up));
@@ -418,6 +419,7 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
         a.cigar = (uint32_t *)S->cigar.p;
     }
     a.n_cigar_units = n_units;
+    a.gather_nt = c->gather_nt ? 1u : 0u;
     launch_cigar_gather(a, n_valid, s);
     if (defer && n_valid)  // the descriptors, CIGAR offsets already counted from the start of the accumulated buffer
         HIP_TRY(c, hipMemcpyAsync((inq_read_t *)A.reads.p + A.n_reads, a.reads, n_valid * sizeof(inq_read_t), hipMemcpyDeviceToDevice, s));
@@ -593,6 +595,17 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
     HIP_TRY(c, hipEventRecord(S->ev[4], s));
     if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(S->ev[5], s));
+    if (const char *again = std::getenv("INQ_CALL_AGAIN"); again && again[0] == '1') {
+        // measurement only: the same launch sequence once more on the same batch (same rows), to tell what a launch that comes
+        // cold behind the gather pays (caches, translations, write-back) from what the batch's layout costs
+        HIP_TRY(c, hipEventRecord(S->ev[0], s));
+        if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
+        HIP_TRY(c, hipEventRecord(S->ev[1], s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        float ms2 = 0.f;
+        (void)hipEventElapsedTime(&ms2, S->ev[0], S->ev[1]);
+        std::fprintf(stderr, "[inq call] the same %llu loci again: locus kernels %.3f ms\n", (unsigned long long)nl, (double)ms2);
+    }
     HIP_TRY(c, hipStreamSynchronize(S->warm_stream));
     HIP_TRY(c, hipMemcpyAsync(S->h_rows, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(S->h_rows + nl, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));

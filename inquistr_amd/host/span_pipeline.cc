@@ -7,6 +7,8 @@ using namespace inqhost;
 
 namespace inqhost {
 
+static std::atomic<uint64_t> g_span_bytes_read{0};  // inq_host_span_bytes_read
+
 // INQ_TIMING=2 stamps every stage with milliseconds since the library was loaded (about the start of the process)
 const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
 double stamp_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0).count(); }
@@ -409,6 +411,7 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
             inq_span_stats_t stt;
             if (loop_spans++ == 0) t_loop0 = clk::now();
             loop_comp_bytes += sp.comp_bytes;
+            g_span_bytes_read.fetch_add(sp.comp_bytes, std::memory_order_relaxed);
             int rc2 = inq_call_span_deferred(ctx, &sp, it->staged ? it->slot : -1, &stt);
             *t_dev += secs(tb, clk::now());
             if (timing == 2)
@@ -486,6 +489,8 @@ struct inq_spans {
 };
 
 extern "C" {
+
+uint64_t inq_host_span_bytes_read(void) { return inqhost::g_span_bytes_read.load(std::memory_order_relaxed); }
 
 // ---- spans: the host half of the device front end, on its own (no GPU involved) ----
 static int inq_spans_open_impl(const inq_call_args_t *args, uint64_t max_comp_bytes, inq_spans_t **out, char *errbuf, size_t errcap) {

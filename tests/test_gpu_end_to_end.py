@@ -437,3 +437,42 @@ def test_native_seq_bearing_file_through_the_device_front_end(tmp_path, monkeypa
             assert m and int(m.group(1)) > 1
     host = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, INQ_FRONTEND="host"))
     assert host.returncode == 0 and host.stdout == want
+
+
+def test_four_ranks_on_one_gpu_share_the_bytes_and_print_the_same_rows(tmp_path, monkeypatch):
+    """`call_dist` at world size 4, all ranks on this box's one GPU (gloo for the gather; with pytest's own process five processes
+    on the card), over a multi-contig file of long-read-shaped records (SEQ, QUAL, ML / MM, HP last): inq_run_partition cuts the
+    targets so that every rank reads about the same number of BAM bytes - each rank reports what its device front end was handed
+    and the four figures must lie within 15 % of their mean - and the gathered .inq equals the single-process CLI's, byte for byte."""
+    import json
+    import sys
+
+    from inquistr_amd import synth
+    from tools import make_synth_bam
+
+    monkeypatch.setattr(make_synth_bam, "LOCI_PER_CONTIG", 700)
+    monkeypatch.setattr(make_synth_bam, "CONTIG_LEN", 50_000 + 20_000 * 700 + 400_000)
+    prefix = str(tmp_path / "w")
+    n_loci = 3_000
+    make_synth_bam.write_native("unphased100k", n_loci, prefix, seq=True, level=6)
+    wl = synth.WORKLOADS["unphased100k"]
+    assert os.path.getsize(prefix + ".bam") > 600e6
+    single = subprocess.run([call.CLI_PATH, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", "4", "--sample-name", "S", "-u"],
+                            capture_output=True, text=True, env=dict(os.environ, INQ_FRONTEND="device"))
+    assert single.returncode == 0, single.stderr
+    assert single.stdout.count("\n") == n_loci + 1 and len({ln.split("\t")[0] for ln in single.stdout.splitlines()[1:]}) == 5  # five contigs
+    out, sdir = tmp_path / "dist.inq", tmp_path / "stats"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", "-m", "inquistr_amd.call_dist", prefix + ".bam", "-R", prefix + ".bed", "-t", "4", "-u",
+           "--sample-name", "S", "--backend", "gloo", "--same-device", "--frontend", "device", "-o", str(out), "--stats-dir", str(sdir)]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.read_text() == single.stdout
+    st = [json.load(open(sdir / f"rank{k}.json")) for k in range(4)]
+    assert sum(s["loci"] for s in st) == n_loci and all(s["world"] == 4 for s in st)
+    read = [s["bam_bytes_read"] for s in st]
+    mean = sum(read) / 4
+    assert mean > 100e6, read  # every rank went through the device front end
+    assert all(abs(b - mean) <= 0.15 * mean for b in read), f"BAM bytes per rank {read} (mean {mean:.0f})"
+    # what the ranks read together is the file once, plus what neighbours both need at the three cuts
+    assert sum(read) < 1.1 * os.path.getsize(prefix + ".bam")

@@ -501,6 +501,29 @@ def test_nccl_gather_is_available():
         dist.destroy_process_group()
 
 
+def test_bench_two_ranks_report_every_ranks_clock_and_the_gathers_tail():
+    """bench.py --gpus 2 rehearsed on this box's one GPU (gloo for the gather, both ranks on device 0; with pytest's own process
+    three processes on the card): the line carries every rank's own ms_per_step, the part of its gathers nothing overlapped, and its
+    wait at the closing barrier - so that the first real scaling run explains itself - next to the contract's fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29653",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "phased10k", "--backend", "gloo", "--same-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak" and line["value"] > 0
+    assert [p["rank"] for p in line["per_rank"]] == [0, 1]
+    for p in line["per_rank"]:
+        assert 0 < p["kernels_ms_per_step"] <= p["ms_per_step"] <= line["ms_per_step"] * 1.0001
+        assert p["gather_exposed_ms_total"] >= 0 and p["barrier_wait_ms"] >= 0
+    assert line["gather"]["collectives"] == 2 and line["gather"]["bytes_per_rank_per_collective"] == 4 * 2 * 10_000 * 8
+
+
 def test_superset_of_candidates_changes_nothing(ctx):
     """The ABI lets the host offer more reads than fetch() would yield (one sweep over the file instead
     of an index query per locus): the device applies htslib's overlap rule.  Offering every locus the
