@@ -184,6 +184,8 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * "inflate_ahead" = 1 (default since round 4): inq_span_stage inflates a span right behind its upload, on a stream of its own, so
  * that the inflate of span k + 1 runs next to span k's record scan, gather and join (costs one inflated buffer per staging slot:
  * device allocations cost microseconds, tools/alloc_probe.hip); 0 = the span is inflated when it is called;
+ * "gather_nt" = 1 (default) / 0: the device front end's CIGAR gather stores with the non-temporal policy (the batch it builds is
+ * read by a later launch); "batch_loci_hint" = N: inq_call_span_deferred sizes the batch's buffers for N loci from its first span;
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);

@@ -154,7 +154,7 @@ void inq_ctx_destroy(inq_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->span) span_state_destroy(c->span);
     purge_retired(c);
-    for (DevBuf *b : {&c->worklist, &c->sval, &c->smeta, &c->cigar, &c->reads, &c->pair_read, &c->off, &c->lstart,
+    for (DevBuf *b : {&c->worklist, &c->sval, &c->smeta, &c->deep, &c->cigar, &c->reads, &c->pair_read, &c->off, &c->lstart,
                       &c->lend, &c->p1, &c->p2, &c->pcall, &c->pbits, &c->ovalues, &c->olen, &c->oflags, &c->okeep, &c->otrans})
         if (b->p) (void)hipFree(b->p);
     for (auto &e : c->ev_pool) {
@@ -214,6 +214,11 @@ static int enqueue_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, vo
     if ((rc = ensure(c, c->worklist, (size_t)shard_cap * kListShards * 2 * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->sval, (size_t)b->n_pairs * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->smeta, (size_t)b->n_pairs)) != INQ_OK) return rc;
+    // loci of more than kGridSelectMin reads are reduced over the whole grid (deep_select.hip): a state of ~45 KB each, and there
+    // cannot be more of them than n_pairs / kGridSelectMin; nothing is allocated or launched when the depth hint rules them out
+    const uint32_t hint0 = c->call_hint ? c->call_hint : c->max_reads_hint;
+    const bool deep_possible = b->n_pairs > kGridSelectMin && !(hint0 && hint0 <= kGridSelectMin);
+    if (deep_possible && (rc = ensure(c, c->deep, deep_select_scratch_bytes(b->n_pairs))) != INQ_OK) return rc;
 
     KArgs a;
     a.cigar4 = (const uint4 *)b->cigar;
@@ -257,7 +262,7 @@ static int enqueue_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, vo
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->e0, s));
     }
-    launch_locus_call(a, b->unphased != 0, nt, grid_small, c->grid_medium, c->grid_big, s, ev ? ev->e1 : nullptr);
+    launch_locus_call(a, b->unphased != 0, nt, grid_small, c->grid_medium, c->grid_big, s, ev ? ev->e1 : nullptr, deep_possible ? c->deep.p : nullptr);
     HIP_TRY(c, hipGetLastError());
     if (ev) HIP_TRY(c, hipEventRecord(ev->e2, s));
     return INQ_OK;
@@ -502,6 +507,10 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     }
     if (std::strcmp(key, "inflate_ahead") == 0) {
         c->inflate_ahead = value != 0;
+        return INQ_OK;
+    }
+    if (std::strcmp(key, "batch_loci_hint") == 0) {
+        c->batch_loci_hint = value < 0 ? 0u : (uint64_t)value;
         return INQ_OK;
     }
     if (std::strcmp(key, "gather_nt") == 0) {

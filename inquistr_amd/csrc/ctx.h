@@ -31,7 +31,7 @@ struct inq_ctx {
     std::string backend, last_err;
     inq::DevStatus *d_status = nullptr;
     inq::DevStatus *h_status = nullptr;  // pinned mirror for the host-buffer entry
-    inq::DevBuf worklist, sval, smeta;
+    inq::DevBuf worklist, sval, smeta, deep;
     // staging for the host-buffer entry
     inq::DevBuf cigar, reads, pair_read, off, lstart, lend, p1, p2, pcall, pbits;
     inq::DevBuf ovalues, olen, oflags, okeep, otrans;  // inq_outlier_rows
@@ -56,6 +56,7 @@ struct inq_ctx {
     // the gather's stores bypass the caches (bam_scan.hip): the batch it builds is read by a later launch, not by this one; the locus
     // kernels behind it run at 5.4 - 6.2 instead of 4.9 - 5.3 TB/s of algorithmic bytes (profiles/r04_results/locus_kernels_in_the_cli.txt)
     bool gather_nt = true;
+    uint64_t batch_loci_hint = 0;  // inq_call_span_deferred: loci the caller lets a batch collect before it flushes (0 = no word)
     uint32_t inflate_algo = 2;  // 0 = workgroup per BGZF block, 1 = lane per block, 2 = the quicker one (0 since round 2)
     // Buffers that were outgrown.  Growing one used to mean hipDeviceSynchronize + hipFree + hipMalloc on the spot; both calls wait for
     // EVERY stream of the device - in the span loop that is the 5 ms upload of the next span on the copy stream, ten times per file

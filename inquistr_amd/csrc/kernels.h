@@ -44,7 +44,14 @@ struct KArgs {
     uint32_t max_reads_hint;  // caller's promise (0 = none): no locus is offered more reads than this
 };
 
+// deep_scratch: deep_select_scratch_bytes(n_pairs) of ctx scratch for the loci the grid-wide select takes (may be null when the
+// depth hint rules them out)
 void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,
-                       uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid);
+                       uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid, void *deep_scratch);
+
+// deep_select.hip: loci with more offered reads than this are reduced by launches over the whole grid instead of one workgroup
+constexpr uint32_t kGridSelectMin = 65536;
+size_t deep_select_scratch_bytes(uint64_t n_pairs);
+void launch_deep_select(const KArgs &k, bool unphased, void *scratch, uint64_t n_pairs, hipStream_t s);
 
 }  // namespace inq

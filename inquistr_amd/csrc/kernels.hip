@@ -651,6 +651,7 @@ __global__ __launch_bounds__(256) void locus_call_big_reduce(KArgs a) {
         constexpr uint32_t kLow = CAP == 2048 ? 0u : CAP == 8192 ? 2048u : 8192u;  // this launch takes (kLow, CAP]
         if (n <= kLow || (CAP != 16384 && n > (uint32_t)CAP)) continue;
         if (n > (uint32_t)CAP) {  // only the last class: deeper than any sort can hold
+            if (n > kGridSelectMin) continue;  // ... and deeper than one workgroup should reduce: the grid-wide select behind this launch (deep_select.hip)
             reduce_deep_select<UNPHASED>(a, j, p0, n, sh);
             continue;
         }
@@ -737,7 +738,7 @@ __global__ void clear_lists(KArgs a) {
 // ---- launchers (called from capi.hip) ----
 template <bool UNPHASED, int AUX>
 static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, uint32_t grid_big, hipStream_t s,
-                     hipEvent_t ev_mid) {
+                     hipEvent_t ev_mid, void *deep_scratch) {
     if (grid_small) hipLaunchKernelGGL((locus_call_small<UNPHASED, AUX>), dim3(grid_small), dim3(256), 0, s, a);
     if (ev_mid) (void)hipEventRecord(ev_mid, s);
     // launches a promised depth makes pointless are skipped (a broken promise is flagged by locus_call_small)
@@ -749,22 +750,23 @@ static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, 
         hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 2048>), dim3(grid_big), dim3(256), 0, s, a);
         if (!(h && h <= 2048u)) hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 8192>), dim3(grid_big), dim3(256), 0, s, a);
         if (!(h && h <= 8192u)) hipLaunchKernelGGL((locus_call_big_reduce<UNPHASED, 16384>), dim3(256), dim3(256), 0, s, a);
+        if (!(h && h <= kGridSelectMin) && deep_scratch) launch_deep_select(a, UNPHASED, deep_scratch, a.n_pairs, s);
     }
     hipLaunchKernelGGL((clear_lists), dim3(1), dim3(64), 0, s, a);
 }
 
 void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,
-                       uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid) {
+                       uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid, void *deep_scratch) {
     if (unphased) {
         if (nt_loads)
-            launch_t<true, 2>(a, grid_small, grid_medium, grid_big, s, ev_mid);
+            launch_t<true, 2>(a, grid_small, grid_medium, grid_big, s, ev_mid, deep_scratch);
         else
-            launch_t<true, 0>(a, grid_small, grid_medium, grid_big, s, ev_mid);
+            launch_t<true, 0>(a, grid_small, grid_medium, grid_big, s, ev_mid, deep_scratch);
     } else {
         if (nt_loads)
-            launch_t<false, 2>(a, grid_small, grid_medium, grid_big, s, ev_mid);
+            launch_t<false, 2>(a, grid_small, grid_medium, grid_big, s, ev_mid, deep_scratch);
         else
-            launch_t<false, 0>(a, grid_small, grid_medium, grid_big, s, ev_mid);
+            launch_t<false, 0>(a, grid_small, grid_medium, grid_big, s, ev_mid, deep_scratch);
     }
 }
 

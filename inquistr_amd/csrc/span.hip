@@ -132,10 +132,10 @@ int span_state(inq_ctx *c, SpanState **out) {
 
 // grows b to `bytes`, keeping its first `used` bytes (the accumulated batch): the copy is ordered on the stream behind everything
 // that wrote the old buffer and in front of everything that will read the new one; the old buffer is retired (ctx.h), nothing waits
-int ensure_keep(inq_ctx *c, DevBuf &b, size_t bytes, size_t used, hipStream_t s) {
+int ensure_keep(inq_ctx *c, DevBuf &b, size_t bytes, size_t used, hipStream_t s, size_t reserve = 0) {
     if (bytes <= b.cap && b.p) return INQ_OK;
     void *np = nullptr;
-    const size_t want = bytes + bytes / 2 + (1u << 20);
+    const size_t want = std::max(bytes + bytes / 2 + (1u << 20), reserve);
     HIP_TRY(c, hipMalloc(&np, want));
     if (b.p) {
         if (used) {
@@ -407,9 +407,19 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
             if (stats) stats->front_status = FS_TOO_BIG;
             return INQ_ERR_BAM;
         }
-        if ((rc = ensure_keep(c, A.cigar, (A.n_units + n_units) * 16, A.n_units * 16, s)) != INQ_OK) return rc;
+        // The first span of a batch says what a locus of this file weighs: with the caller's word on how many loci a batch will
+        // hold ("batch_loci_hint": the driver flushes at that many) the buffers are made for the whole batch at once, instead of
+        // being outgrown span after span - every growth copies what is there (0.7 GB for a CIGAR-only span) with ordinary stores
+        // right in front of the locus kernels that stream the batch (profiles/r04_results/locus_kernels_in_the_cli.txt)
+        size_t res_units = 0, res_reads = 0;
+        if (A.n_spans == 0 && c->batch_loci_hint > nl && nl) {
+            const double spans = std::min(64.0, (double)c->batch_loci_hint / (double)nl + 1.0) * 1.08;
+            res_units = (size_t)std::min((double)(12ull << 30), (double)n_units * 16.0 * spans);
+            res_reads = (size_t)std::min((double)(4ull << 30), (double)n_valid * (double)sizeof(inq_read_t) * spans);
+        }
+        if ((rc = ensure_keep(c, A.cigar, (A.n_units + n_units) * 16, A.n_units * 16, s, res_units)) != INQ_OK) return rc;
         wall("  batch CIGAR buffer ready");
-        if ((rc = ensure_keep(c, A.reads, (A.n_reads + n_valid) * sizeof(inq_read_t), A.n_reads * sizeof(inq_read_t), s)) != INQ_OK) return rc;
+        if ((rc = ensure_keep(c, A.reads, (A.n_reads + n_valid) * sizeof(inq_read_t), A.n_reads * sizeof(inq_read_t), s, res_reads)) != INQ_OK) return rc;
         wall("  batch read buffer ready");
         a.cigar = (uint32_t *)A.cigar.p + A.n_units * 4;
         a.unit_base = (uint32_t)A.n_units;
@@ -464,7 +474,10 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     };
     if (defer) {
         if (A.n_pairs + n_pairs >= (1ull << 40) || A.n_loci + nl >= 0xfffffff0ull) return INQ_ERR_ARG;
-        if ((rc = ensure_keep(c, A.pair_read, (A.n_pairs + n_pairs) * 4, A.n_pairs * 4, s)) != INQ_OK) return rc;
+        size_t res_pairs = 0;
+        if (A.n_spans == 0 && c->batch_loci_hint > nl && nl)
+            res_pairs = (size_t)std::min((double)(4ull << 30), (double)n_pairs * 4.0 * std::min(64.0, (double)c->batch_loci_hint / (double)nl + 1.0) * 1.08);
+        if ((rc = ensure_keep(c, A.pair_read, (A.n_pairs + n_pairs) * 4, A.n_pairs * 4, s, res_pairs)) != INQ_OK) return rc;
         if ((rc = ensure_keep(c, A.off, (A.n_loci + nl + 1) * 8, (A.n_loci + 1) * 8, s)) != INQ_OK) return rc;
         if ((rc = ensure_keep(c, A.lstart, (A.n_loci + nl) * 4, A.n_loci * 4, s)) != INQ_OK) return rc;
         if ((rc = ensure_keep(c, A.lend, (A.n_loci + nl) * 4, A.n_loci * 4, s)) != INQ_OK) return rc;

@@ -396,6 +396,7 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
                 actx.wait();
                 joined = true;
                 if (hrc == INQ_OK) inq_call_discard(ctx);  // a session's context: nothing of a file that failed half-way stays behind
+                if (hrc == INQ_OK) (void)inq_ctx_set_option(ctx, "batch_loci_hint", (int64_t)std::min<size_t>(kFlushLoci, V.targets.size()));
             }
             if (hrc != INQ_OK) {
                 set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));

@@ -451,7 +451,7 @@ def test_four_ranks_on_one_gpu_share_the_bytes_and_print_the_same_rows(tmp_path,
     from tools import make_synth_bam
 
     monkeypatch.setattr(make_synth_bam, "LOCI_PER_CONTIG", 700)
-    monkeypatch.setattr(make_synth_bam, "CONTIG_LEN", 50_000 + 20_000 * 700 + 400_000)
+    monkeypatch.setattr(make_synth_bam, "CONTIG_LEN", 50_000 + 20_000 * 10_000 + 400_000)  # (a locus' position comes from its number in the workload)
     prefix = str(tmp_path / "w")
     n_loci = 3_000
     make_synth_bam.write_native("unphased100k", n_loci, prefix, seq=True, level=6)

@@ -280,6 +280,49 @@ def test_one_locus_of_100000_reads(ctx, orc, unphased, support):
     assert dt < 2.0, f"{dt:.2f} s for the host-buffer call (upload + kernels + download)"
 
 
+_MILLION = {}
+
+
+@pytest.mark.parametrize("unphased,support", [(False, 3), (True, 3), (False, 100_000), (True, 100_000)])
+def test_one_locus_of_a_million_reads(ctx, orc, unphased, support):
+    """One locus offered 1 000 000 reads, next to a 70 000-read one and two ordinary loci: beyond 65 536 reads the reduce is no
+    longer one workgroup's (csrc/deep_select.hip: every pass of the radix selects is a launch over the whole grid; the unphased
+    split's file-order tie rule a prefix over per-slice counts).  Exact against the oracle, per-pair outputs included; support =
+    100 000 makes `spanning <= support` true at this depth, so the clip rule of median_str_length (src/call.rs:509-513) picks
+    soft-clipped Calls by value, ties at the threshold included.  The whole launch sequence (walk + every reduce) is timed."""
+    import random
+
+    if "reads" not in _MILLION:  # the same reads for the four cases: only the scalars of the batch differ
+        rng = random.Random(1234)
+        start, end = 700_000, 700_150
+        shapes = gen.random_locus_reads(rng, start, end, 400, long_every=17)
+        _MILLION["reads"] = [(shapes[rng.randrange(len(shapes))], rng.choice([9, 30, 60, 60, 60]), rng.choice([None, 0, 1, 1, 2, 2]), k % 13 == 0)
+                             for k in range(1_000_000)]
+        _MILLION["win"] = (start, end)
+    start, end = _MILLION["win"]
+    bb = B.BatchBuilder(minlen=5, support=support, unphased=unphased)
+    deep = [bb.add_read(r.pos, B.encode_cigar(r.cigar), mapq=mq, phase=ph, reverse=bool(r.flag & 0x10), is_2d=twod) for r, mq, ph, twod in _MILLION["reads"]]
+    order = sorted(range(len(deep)), key=lambda i: (bb._reads[deep[i]][2], i))  # file order: by position, then insertion
+    bb.add_locus(start - 4000, start - 3900, deep[:40])
+    bb.add_locus(start, end, [deep[i] for i in order])
+    bb.add_locus(start + 20, end + 20, [deep[i] for i in order[:70_000]])
+    bb.add_locus(start + 9000, start + 9050, deep[100:130])
+    batch = bb.build()
+    ctx.call_batch(batch)  # allocations
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    rc, got = ctx.call_batch(batch, debug=True)
+    seq_ms, launches = ctx.timing_read(0)
+    ctx.timing_enable(False)
+    oc, want = orc.call_batch(batch, debug=True, threads=8)
+    assert rc == oc == 0
+    _assert_same(got, want, f"a million reads unphased={unphased} support={support}")
+    assert not np.isnan(got.phase2[1]), "the deepest locus must yield a number for the test to mean anything"
+    assert np.isnan(got.phase2[2]) == (support > 3)  # the 70 000-read locus: a number, or (fewer Calls per group than `support`) NaN
+    print(f"1 000 000-read locus, unphased={unphased} support={support}: launch sequence {seq_ms:.2f} ms")
+    assert launches == 1 and seq_ms < 5.0, f"{seq_ms:.2f} ms for walk + reduce of the batch"
+
+
 def test_domain_errors(ctx, orc):
     def one(**kw):
         bb = B.BatchBuilder(**{k: v for k, v in kw.items() if k in ("minlen", "support", "unphased")})
