@@ -576,7 +576,7 @@ def main():
     ap.add_argument("--l2-seq-large-loci", type=int, default=-1,
                     help="loci of the large SEQ / QUAL-bearing BAM of the default line's l2_seq_large block (0.32 GB per 1 000 loci; north_star's "
                          "configuration is 100 000 = 32 GB); -1 = the largest size up to 100 000 that disk, page cache and --l2-seq-large-gen-budget admit; 0 skips it")
-    ap.add_argument("--l2-seq-large-gen-budget", type=float, default=80.0, help="seconds the default line may spend WRITING the large file")
+    ap.add_argument("--l2-seq-large-gen-budget", type=float, default=130.0, help="seconds the default line may spend WRITING the large file")
     ap.add_argument("--l2-level", type=int, default=6, help="zlib level of the BAMs the l2 blocks are timed on (6 = htslib's default)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: the workload's n_loci are split over the ranks (config #4: --workload shard500k --scaling strong)")
