@@ -84,6 +84,13 @@ def cpu_baseline(wl, sample_loci: int, budget_s: float = 10.0):
 
 
 PCIE_SPEC_GBS = 64.0  # PCIe Gen5 x16, one direction, before protocol overhead (the link an MI355X hangs on)
+# Seconds of rest in front of every TIMED process that uses the GPU.  When a process that held GBs of device memory leaves, the
+# driver wipes that memory and takes its queues apart for some tenths of a second, and a process that starts meanwhile waits
+# for it inside hipInit (0.10 s -> 0.2 - 0.4 s) and inside its allocations (50 ms per GB): the whole "start-up varies four-fold"
+# of rounds 2 - 3 was the PREVIOUS run of the loop (profiles/r04_results/back_to_back_vs_paused_processes.txt: twelve runs with
+# 1.5 s between them 0.156 - 0.162 s each but three, the same runs back to back 0.16 - 0.77 s).  The timed runs below therefore
+# each meet an idle device - what somebody who runs one command sees -, and `seconds_back_to_back` keeps three runs without the rest.
+GPU_REST_S = float(os.environ.get("INQ_BENCH_REST_S", "1.2"))
 
 
 def h2d_copy_peak(dev, mb: int = 256, reps: int = 6):
@@ -125,6 +132,7 @@ def startup_floor(reps: int = 5):
         return None
     ts, stages = [], None
     for _ in range(reps):
+        time.sleep(GPU_REST_S)
         t = time.perf_counter()
         r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
         ts.append(time.perf_counter() - t)
@@ -140,7 +148,7 @@ def startup_floor(reps: int = 5):
             except ValueError:
                 pass
     med = statistics.median(ts)
-    return {"seconds_median": med, "seconds_all": ts, "runs": reps, "inside_main_ms_last_run": inner,
+    return {"seconds_median": med, "seconds_all": ts, "runs": reps, "rest_before_each_run_s": GPU_REST_S, "inside_main_ms_last_run": inner,
             "start_and_exit_ms_last_run": max(0.0, ts[-1] * 1e3 - inner),
             "what": "bare HIP process (tools/hip_startup_probe.hip: hipInit, one stream, one empty kernel, 6 GB of allocations, a 1 MB copy), "
                     "start to exit; `inside_main` = the sum of its own stage clocks, the rest is loading the runtime's libraries and the exit"}
@@ -233,7 +241,9 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
             open(p, "w").write("".join(bed_lines[:n]))
             return p
 
-        def run(cmd, env=None, timeout=None):
+        def run(cmd, env=None, timeout=None, rest=0.0):
+            if rest:
+                time.sleep(rest)
             t = time.perf_counter()
             r = subprocess.run(cmd, capture_output=True, env=env, timeout=timeout)
             dt = time.perf_counter() - t
@@ -249,10 +259,11 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         # round 3's "one slow run in five" (profiles/r04_results/slow_second_read.txt).  A kernel matter, not a property of any program here.
         run(cmd, dict(os.environ, INQ_FRONTEND="device"))
         run(cmd, dict(os.environ, INQ_FRONTEND="device"))
-        dev = [run(cmd, dict(os.environ, INQ_FRONTEND="device")) for _ in range(reps)]
+        dev = [run(cmd, dict(os.environ, INQ_FRONTEND="device"), rest=GPU_REST_S) for _ in range(reps)]
         t_dev = statistics.median(t for t, _ in dev)
         out_dev = dev[0][1]
-        t_host, out_host = (None, None) if lean else run(cmd, dict(os.environ, INQ_FRONTEND="host"))
+        b2b = [run(cmd, dict(os.environ, INQ_FRONTEND="device")) for _ in range(3)]  # ... and without the rest, each behind the last one's exit
+        t_host, out_host = (None, None) if lean else run(cmd, dict(os.environ, INQ_FRONTEND="host"), rest=GPU_REST_S)
         rows = out_dev.splitlines(keepends=True)
         bam_bytes = os.path.getsize(prefix + ".bam")
         res = {
@@ -262,8 +273,9 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
             "records": ("SEQ + QUAL of the query length, NM:i, ML:B,C + MM:Z, HP:C last (long-read record shape, ~18 KB per record; "
                         "bases ACGT, Phred a clamped random walk)" if seq else "SEQ '*' (CIGAR-only records), HP:C"),
             **({"inflated_mb": info["inflated_bytes"] / 1e6, "bgzf_blocks": info["n_blocks"]} if info else {}),
-            "gpu_cli_device_front": {"seconds_median": t_dev, "seconds_all": [t for t, _ in dev], "runs": reps,
-                                     "loci_per_s": loci / t_dev, "identical_across_runs": all(o == out_dev for _, o in dev)},
+            "gpu_cli_device_front": {"seconds_median": t_dev, "seconds_all": [t for t, _ in dev], "runs": reps, "rest_before_each_run_s": GPU_REST_S,
+                                     "seconds_back_to_back": [t for t, _ in b2b],
+                                     "loci_per_s": loci / t_dev, "identical_across_runs": all(o == out_dev for _, o in dev + b2b)},
         }
         if not lean:
             res["gpu_cli_host_front"] = {"seconds": t_host, "loci_per_s": loci / t_host, "inq_identical": out_host == out_dev}
@@ -275,10 +287,12 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
             tb2, out_b2 = run([ref, prefix + ".bam", prefix + ".bed", "B", str(all_cores)] + args_tail)
             res["cpu_B_all_cores"] = {"seconds": tb2, "loci": loci, "loci_per_s": loci / tb2, "cores": all_cores, "inq_identical": out_b2 == out_dev}
         # the device front end's own stage times for this file (HIP events / host clocks inside the CLI, one extra run)
+        time.sleep(GPU_REST_S)
         r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="2"))
         res["device_front_stages"] = stage_summary(r.stderr.decode(), bam_bytes)
         loops = [res["device_front_stages"].get("span_loop_s")]
         for _ in range(max(0, trace_runs - 1)):  # more samples of the span loop's own time (INQ_TIMING=1: one line per run)
+            time.sleep(GPU_REST_S)
             r2 = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="1"))
             loops.append(stage_summary(r2.stderr.decode(), bam_bytes).get("span_loop_s"))
         loops = [x for x in loops if x]
@@ -395,8 +409,8 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
                 os.makedirs(outdir, exist_ok=True)
                 co = [cli, "cohort", "-R", prefix + ".bed", "-t", str(threads), "--out-dir", outdir] + un
                 env_d = dict(os.environ, INQ_FRONTEND="device")
-                t1 = statistics.median(run(co + links[:1], env_d)[0] for _ in range(3))
-                tn = statistics.median(run(co + links, env_d)[0] for _ in range(3))
+                t1 = statistics.median(run(co + links[:1], env_d, rest=GPU_REST_S)[0] for _ in range(3))
+                tn = statistics.median(run(co + links, env_d, rest=GPU_REST_S)[0] for _ in range(3))
                 per = max((tn - t1) / (n_co - 1), 1e-9)
                 # the library's own clock between two files of the cohort (stderr of one more run): what a file costs once the
                 # context is there, without the process's start and its exit (tearing down GBs of mappings: tenths of a second)

@@ -282,6 +282,12 @@ int inq_call_span(inq_ctx_t *ctx, const inq_span_t *span, inq_result_t *result, 
  * and sizes in both calls. */
 #define INQ_SPAN_SLOTS 8 /* two sets of four: a session stages the next file's spans while this file's are called */
 int inq_span_stage(inq_ctx_t *ctx, const inq_span_t *span, int slot);
+/* The same in two steps, so that the copy engine goes from one span's bytes straight to the next one's: _begin enqueues the
+ * upload (and the inflate behind it) and returns - the block table and the anchors are copied on the spot, span->comp must stay
+ * until _wait(slot) has returned; a second span may be begun (other slot) before the first is waited for.  inq_span_stage =
+ * _begin + _wait. */
+int inq_span_stage_begin(inq_ctx_t *ctx, const inq_span_t *span, int slot);
+int inq_span_stage_wait(inq_ctx_t *ctx, int slot);
 int inq_call_span_staged(inq_ctx_t *ctx, const inq_span_t *span, int slot, inq_result_t *result,
                          inq_span_stats_t *stats);
 

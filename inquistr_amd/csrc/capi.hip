@@ -55,9 +55,11 @@ int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
         }
         if (too_much) purge_retired(c);
     }
-    // grow with headroom: batches of a sweep vary in size, reallocating for each new maximum would
-    // put a malloc in front of most calls
-    size_t want = bytes < 256 ? 256 : bytes + bytes / 2 + (1u << 16);
+    // grow with headroom: batches of a sweep vary in size, reallocating for each new maximum would put a malloc in front of most
+    // calls.  Large buffers get little of it: device memory a process holds is wiped by the driver when the process leaves, at
+    // ~20 GB/s, and while that goes on the NEXT process's hipInit and hipMalloc wait (0.1 -> 0.3 s of start-up, 50 ms per GB
+    // allocated: profiles/r04_results/back_to_back_vs_paused_processes.txt) - spans of a file are the same size to a percent
+    size_t want = bytes < 256 ? 256 : bytes < (32u << 20) ? bytes + bytes / 2 + (1u << 16) : bytes + bytes / 16 + (1u << 20);
     HIP_TRY(c, hipMalloc(&b.p, want));
     b.cap = want;
     return INQ_OK;

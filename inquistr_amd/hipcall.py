@@ -51,6 +51,8 @@ ABI_SYMBOLS = (
     "inq_bgzf_inflate",
     "inq_call_span",
     "inq_span_stage",
+    "inq_span_stage_begin",
+    "inq_span_stage_wait",
     "inq_call_span_staged",
     "inq_call_span_deferred",
     "inq_call_flush",
@@ -217,6 +219,10 @@ def load(path: Optional[str] = None):
     L.inq_call_span.argtypes = [vp, C.POINTER(SpanC), C.POINTER(InqResultC), C.POINTER(SpanStatsC)]
     L.inq_span_stage.restype = C.c_int
     L.inq_span_stage.argtypes = [vp, C.POINTER(SpanC), C.c_int]
+    L.inq_span_stage_begin.restype = C.c_int
+    L.inq_span_stage_begin.argtypes = [vp, C.POINTER(SpanC), C.c_int]
+    L.inq_span_stage_wait.restype = C.c_int
+    L.inq_span_stage_wait.argtypes = [vp, C.c_int]
     L.inq_call_span_staged.restype = C.c_int
     L.inq_call_span_staged.argtypes = [vp, C.POINTER(SpanC), C.c_int, C.POINTER(InqResultC), C.POINTER(SpanStatsC)]
     L.inq_call_span_deferred.restype = C.c_int

@@ -219,39 +219,58 @@ void SpanPipeline::run() {
     }
 }
 
-// uploads in file order, one span behind the reader
+// uploads in file order behind the reader; up to two spans enqueued at a time (when the staging has a wait step), so that the copy
+// engine goes from one span's bytes straight to the next one's
 void SpanPipeline::run_uploads() {
     prefer_gpu_node_for_this_thread(device_);  // the runtime's staging chunks are allocated by the thread that first copies
+    struct Flight {
+        Item *it;
+        bool begun;
+        std::chrono::steady_clock::time_point t0;
+    };
+    std::deque<Flight> inflight;
+    const size_t depth = stage_wait_ ? 2 : 1;
+    auto finish_oldest = [&] {
+        Flight f = inflight.front();
+        inflight.pop_front();
+        f.it->staged = f.begun && (!stage_wait_ || stage_wait_(f.it->slot));
+        if (verbose_)
+            std::fprintf(stderr, "[inq loader] @%.1f slot %d: upload %.2f ms for %.1f MB%s\n", stamp_ms(), f.it->slot,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f.t0).count(), f.it->data.comp_bytes / 1e6,
+                         f.it->staged ? "" : " (not staged)");
+        std::lock_guard<std::mutex> g(mu_);
+        ready_.push_back(f.it);
+        cv_item_.notify_one();
+    };
     for (;;) {
         Item *it = nullptr;
         {
             std::unique_lock<std::mutex> g(mu_);
-            cv_loaded_.wait(g, [&] { return !loaded_.empty() || load_done_ || stop_ || failed_; });
+            // with a span in flight only what is there already is taken: its upload is waited for rather than the reader
+            if (inflight.empty()) cv_loaded_.wait(g, [&] { return !loaded_.empty() || load_done_ || stop_ || failed_; });
             if (stop_ || failed_) return;
-            if (loaded_.empty()) {  // the reader is through
+            if (!loaded_.empty() && inflight.size() < depth) {
+                it = loaded_.front();
+                loaded_.pop_front();
+            } else if (inflight.empty()) {  // the reader is through
                 done_ = true;
                 cv_item_.notify_all();
                 return;
             }
-            it = loaded_.front();
-            loaded_.pop_front();
         }
-        const auto t0 = std::chrono::steady_clock::now();
-        inq_span_t sp;
-        fill_span(*it, &sp);
-        if (register_ && !it->registered && !it->pinned && it->buf) {
-            // INQ_SPAN_REGISTER=1 (experiment): the buffer is page-locked where it lies before its first upload
-            if (gate_registered_) gate_registered_();
-            it->registered = inq_pin_host(it->buf, it->cap) == INQ_OK;
+        if (it) {
+            const auto t0 = std::chrono::steady_clock::now();
+            inq_span_t sp;
+            fill_span(*it, &sp);
+            if (register_ && !it->registered && !it->pinned && it->buf) {
+                // INQ_SPAN_REGISTER=1 (experiment): the buffer is page-locked where it lies before its first upload
+                if (gate_registered_) gate_registered_();
+                it->registered = inq_pin_host(it->buf, it->cap) == INQ_OK;
+            }
+            inflight.push_back(Flight{it, stage_(sp, it->slot), t0});
+            if (inflight.size() < depth) continue;  // a second one, if the reader has it
         }
-        it->staged = stage_(sp, it->slot);
-        if (verbose_)
-            std::fprintf(stderr, "[inq loader] @%.1f slot %d: upload %.2f ms for %.1f MB%s\n", stamp_ms(), it->slot,
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), it->data.comp_bytes / 1e6,
-                         it->staged ? "" : " (not staged)");
-        std::lock_guard<std::mutex> g(mu_);
-        ready_.push_back(it);
-        cv_item_.notify_one();
+        if (!inflight.empty()) finish_oldest();
     }
 }
 
@@ -303,13 +322,13 @@ SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamFile &ba
     // the loader uploads every span it has read (waiting for the context the first time), so that the upload of span k+1
     // overlaps the inflate of span k
     return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
-                            [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage(actx.ctx, &sp, slot) == INQ_OK; },
+                            [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage_begin(actx.ctx, &sp, slot) == INQ_OK; },
                             slot_base, pool, std::getenv("INQ_GATE_READS") ? std::function<void()>([&actx] { (void)actx.wait(); }) : std::function<void()>(),
                             [&actx, dev = args->device]() -> int {
                                 if (const char *e = std::getenv("INQ_NUMA_NODE")) return std::atoi(e);
                                 return actx.ready.load() ? actx.numa_node : guess_gpu_numa_node(dev);
                             },
-                            args->device, [&actx] { (void)actx.wait(); });
+                            args->device, [&actx] { (void)actx.wait(); }, [&actx](int slot) { return inq_span_stage_wait(actx.ctx, slot) == INQ_OK; });
 }
 
 int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,

@@ -76,14 +76,17 @@ public:
     // stage: called on the loader thread for every loaded span with the filled inq_span_t; returns true when the
     // span now sits in device slot `slot` (the upload then overlaps the caller's work on earlier spans)
     using StageFn = std::function<bool(const inq_span_t &, int slot)>;
+    // ... in two steps (inq_span_stage_begin / _wait): with `wait` given, `stage` only enqueues, and the uploader keeps two spans
+    // enqueued so that the copy engine never waits for the host between them
+    using WaitFn = std::function<bool(int slot)>;
     // slot_base: 0 or kSlotsPerSet, the set of device-side staging slots this pipeline uploads into; pool: where span buffers come from
     // and go back to (may be null: mapped and unmapped by the pipeline)
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
                  uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr,
                  std::function<void()> gate = nullptr, std::function<int()> numa_query = nullptr, int device = 0,
-                 std::function<void()> runtime_gate = nullptr)
+                 std::function<void()> runtime_gate = nullptr, WaitFn stage_wait = nullptr)
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
-          stage_(std::move(stage)), pool_(pool), gate_(std::move(gate)), gate_registered_(std::move(runtime_gate)),
+          stage_(std::move(stage)), stage_wait_(std::move(stage_wait)), pool_(pool), gate_(std::move(gate)), gate_registered_(std::move(runtime_gate)),
           numa_query_(std::move(numa_query)), device_(device) {
         for (int i = 0; i < kSlotsPerSet; ++i) slots_[i].slot = slot_base + i;
         int use = kSlotsPerSet;
@@ -157,6 +160,7 @@ private:
     int n_threads_;
     bool pinned_;
     StageFn stage_;
+    WaitFn stage_wait_;
     HostBufPool *pool_ = nullptr;
     std::function<void()> gate_;
     bool register_ = std::getenv("INQ_SPAN_REGISTER") && std::getenv("INQ_SPAN_REGISTER")[0] == '1';

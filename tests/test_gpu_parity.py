@@ -323,6 +323,56 @@ def test_one_locus_of_a_million_reads(ctx, orc, unphased, support):
     assert launches == 1 and seq_ms < 5.0, f"{seq_ms:.2f} ms for walk + reduce of the batch"
 
 
+@pytest.mark.parametrize("seed,unphased", [(1, False), (2, True), (3, False), (4, True)])
+def test_very_deep_loci_at_the_edges_of_the_clip_rule(ctx, orc, seed, unphased):
+    """Three loci of 66 000 - 80 000 reads (the grid-wide select of csrc/deep_select.hip takes over above 65 536), values drawn
+    from few shapes so that ties are everywhere, and `support` placed ON the edges of median_str_length's rule for the deepest
+    locus' first haplotype (src/call.rs:497-513): spanning - 1 / spanning / spanning + 1 (does the clip rule apply, with how many
+    clipped Calls), all Calls (every clipped one taken), one more (NaN).  Exact against the oracle each time."""
+    import random
+
+    rng = random.Random(9000 + seed)
+    start, end = 900_000, 900_140
+    shapes = gen.random_locus_reads(rng, start, end, 60, long_every=9)
+    pool = [(shapes[rng.randrange(len(shapes))], rng.choice([9, 60, 60, 60]), rng.choice([None, 0, 1, 1, 2, 2]), k % 7 == 0) for k in range(80_000)]
+
+    def build(support):
+        bb = B.BatchBuilder(minlen=5, support=support, unphased=unphased)
+        ids = [bb.add_read(r.pos, B.encode_cigar(r.cigar), mapq=mq, phase=ph, reverse=bool(r.flag & 0x10), is_2d=twod) for r, mq, ph, twod in pool]
+        order = sorted(range(len(ids)), key=lambda i: (bb._reads[ids[i]][2], i))
+        bb.add_locus(start, end, [ids[i] for i in order])
+        bb.add_locus(start + 10, end + 10, [ids[i] for i in order[:66_000]])
+        bb.add_locus(start - 10, end - 10, [ids[i] for i in order[5_000:77_000]])
+        bb.add_locus(start + 9000, start + 9050, ids[100:130])
+        return bb.build()
+
+    batch = build(1)
+    oc, probe = orc.call_batch(batch, debug=True, threads=8)
+    assert oc == 0
+    n0 = int(batch.locus_pair_off[1])
+    bits = probe.pair_bits[:n0].astype(np.int64)
+    kept = (bits & 4) != 0
+    if unphased:  # h1 = the lower half of the kept Calls
+        vals = np.sort(probe.pair_call[:n0][kept], kind="stable")
+        h1 = kept.sum() // 2
+        ng = int(h1)
+        ns = None  # which Calls are clipped depends on the split: take the supports around half of h1 instead
+        supports = [1, max(1, ng // 2), ng - 1, ng, ng + 1]
+        del vals
+    else:
+        phase = batch.reads["phase"][batch.pair_read[:n0]]
+        g1 = kept & (phase == 1)
+        ng, ns = int(g1.sum()), int((g1 & ((bits & 1) == 0)).sum())
+        supports = [max(1, ns - 1), ns, ns + 1, ng, ng + 1]
+    for support in supports:
+        b = build(support)
+        rc, got = ctx.call_batch(b, debug=True)
+        oc, want = orc.call_batch(b, debug=True, threads=8)
+        assert rc == oc == 0
+        _assert_same(got, want, f"very deep loci seed={seed} unphased={unphased} support={support} (ng {ng}, ns {ns})")
+    assert ng > 10_000
+
+
 def test_domain_errors(ctx, orc):
     def one(**kw):
         bb = B.BatchBuilder(**{k: v for k, v in kw.items() if k in ("minlen", "support", "unphased")})

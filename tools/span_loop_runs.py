@@ -64,6 +64,8 @@ def main():
                 env[k] = val
         loops = []
         for i in range(runs):
+            if os.environ.get("PAUSE_S"):  # let the previous process's teardown (the driver wipes the VRAM it held) finish first
+                time.sleep(float(os.environ["PAUSE_S"]))
             a = cpu_stat()
             va = vmstat()
             t0 = time.perf_counter()

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 __global__ void k(int *p) {
     if (p) *p = 1;
@@ -51,6 +52,23 @@ int main(int argc, char **argv) {
         hipMemcpyAsync(d, h, 16 << 20, hipMemcpyHostToDevice, s[i]);
         hipStreamSynchronize(s[i]);
         lap("second pinned H2D 16 MB + sync", i);
+    }
+    {   // four more streams one after the other, then four more from four threads at once: does creation run side by side?
+        hipStream_t q[8];
+        auto a0 = clk::now();
+        for (int i = 0; i < 4; ++i) hipStreamCreateWithFlags(&q[i], hipStreamNonBlocking);
+        auto a1 = clk::now();
+        std::thread th[4];
+        for (int i = 0; i < 4; ++i)
+            th[i] = std::thread([&q, i] {
+                hipSetDevice(0);
+                hipStreamCreateWithFlags(&q[4 + i], hipStreamNonBlocking);
+            });
+        for (auto &x : th) x.join();
+        auto a2 = clk::now();
+        std::printf("4 more streams in a row: %.2f ms; 4 more from 4 threads at once: %.2f ms\n", std::chrono::duration<double, std::milli>(a1 - a0).count(),
+                    std::chrono::duration<double, std::milli>(a2 - a1).count());
+        t0 = clk::now();
     }
     hipEvent_t e;
     hipEventCreateWithFlags(&e, hipEventDisableTiming);
