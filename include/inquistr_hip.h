@@ -140,6 +140,10 @@ typedef struct inq_ctx inq_ctx_t;
 /* Opens HIP device `device_id` (must be gfx950), creates the library's stream and
  * scratch.  One ctx per device; a ctx serves one caller at a time. */
 int inq_ctx_create(int device_id, inq_ctx_t **out);
+/* The same in a hurry: *ctx is set and *stage_ready raised (release store) as soon as inq_span_stage / _begin / _wait may be called
+ * on it from another thread, ~30 ms before the function returns; every other entry point only after it has returned INQ_OK.  A
+ * context that was published stays valid until inq_ctx_destroy, whatever the return value (the caller destroys it). */
+int inq_ctx_create_early(int device_id, inq_ctx_t **ctx, volatile int *stage_ready);
 void inq_ctx_destroy(inq_ctx_t *ctx);
 
 /* Host-buffer entry: batch and result point to HOST memory (pinned for best H2D).

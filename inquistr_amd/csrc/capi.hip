@@ -102,9 +102,15 @@ const char *inq_strerror(int code) {
     }
 }
 
-int inq_ctx_create(int device_id, inq_ctx_t **out) {
+// The context in two steps for a caller that is in a hurry: *out is set and *stage_ready raised as soon as the staging entry points
+// (inq_span_stage_begin / _wait / inq_span_stage) may be used - the runtime is up, the copy and inflate streams and the staging
+// slots exist - while the rest (status buffers, code objects: ~30 ms) is still being made; a process whose spans are already in
+// memory starts uploading that much earlier.  Everything else may be called once the function has returned INQ_OK.  Whatever it
+// returns, a context it has published stays valid until inq_ctx_destroy (the caller destroys it, also after a failure).
+int inq_ctx_create_early(int device_id, inq_ctx_t **out, volatile int *stage_ready) {
     if (!out) return INQ_ERR_ARG;
     *out = nullptr;
+    if (stage_ready) *stage_ready = 0;
     int n = 0;
     // INQ_TIMING=2: where the start-up goes (the runtime's own initialisation is most of a short run)
     const char *tenv = std::getenv("INQ_TIMING");
@@ -126,28 +132,39 @@ int inq_ctx_create(int device_id, inq_ctx_t **out) {
     if (!c) return INQ_ERR_NOMEM;
     c->device = device_id;
     c->backend = std::string("hip:") + prop.gcnArchName + ":" + prop.name;
+    bool published = false;
     auto fail = [&](int code) {
-        inq_ctx_destroy(c);
+        if (!published) inq_ctx_destroy(c);  // (a published context is the caller's to destroy: another thread may be using it)
         return code;
     };
     lap("device properties");
     if (hipSetDevice(device_id) != hipSuccess) return fail(INQ_ERR_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(INQ_ERR_HIP);
     lap("hipSetDevice + first stream");
+    if (span_state_init(c) != INQ_OK) return fail(INQ_ERR_HIP);
+    lap("span state (events, streams)");
+    *out = c;
+    if (stage_ready) {
+        published = true;
+        __atomic_store_n(stage_ready, 1, __ATOMIC_RELEASE);
+    }
     if (hipMalloc((void **)&c->d_status, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_NOMEM);
     if (hipMemset(c->d_status, 0, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_HIP);
     if (hipHostMalloc((void **)&c->h_status, sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) return fail(INQ_ERR_NOMEM);
     lap("status buffers");
-    if (span_state_init(c) != INQ_OK) return fail(INQ_ERR_HIP);
-    lap("span state (events, streams)");
     // load the code objects while the caller is still busy opening its input
     preload_locus(c->stream);
     preload_inflate(c->stream);
     preload_scan(c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(INQ_ERR_HIP);
     lap("code objects (3 empty launches)");
-    *out = c;
     return INQ_OK;
+}
+
+int inq_ctx_create(int device_id, inq_ctx_t **out) {
+    const int rc = inq_ctx_create_early(device_id, out, nullptr);
+    if (rc != INQ_OK && out) *out = nullptr;  // (nothing was published: the context is gone already)
+    return rc;
 }
 
 void inq_ctx_destroy(inq_ctx_t *c) {

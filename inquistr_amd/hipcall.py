@@ -51,6 +51,7 @@ ABI_SYMBOLS = (
     "inq_bgzf_inflate",
     "inq_call_span",
     "inq_span_stage",
+    "inq_ctx_create_early",
     "inq_span_stage_begin",
     "inq_span_stage_wait",
     "inq_call_span_staged",

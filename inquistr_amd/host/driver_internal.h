@@ -84,18 +84,29 @@ struct AsyncCtx {
     int hrc = INQ_OK;
     int numa_node = -1;
     std::atomic<bool> ready{false};  // ctx / hrc / numa_node are final
+    // raised by inq_ctx_create_early as soon as spans may be STAGED on ctx (uploads, inflates), ~30 ms before the context is
+    // complete: the uploader thread starts on the spans the loader has read by then
+    volatile int stage_ready = 0;
     std::thread th;
     bool leak = false;  // set after a clean run when the process is about to exit (INQ_FAST_EXIT)
     void start(int device) {
         th = std::thread([this, device] {
             prefer_gpu_node_for_this_thread(device);  // what the runtime allocates while it starts
             const double a = stamp_ms();
-            hrc = inq_ctx_create(device, &ctx);
+            hrc = inq_ctx_create_early(device, &ctx, &stage_ready);
             numa_node = hrc == INQ_OK ? inq_ctx_numa_node(ctx) : -1;
             ready.store(true);
             const char *e = std::getenv("INQ_TIMING");
             if (e && e[0] == '2') std::fprintf(stderr, "[inq ctx] @%.1f device context ready (inq_ctx_create %.1f ms), GPU on NUMA node %d\n", stamp_ms(), stamp_ms() - a, numa_node);
         });
+    }
+    // any thread: true once spans may be staged on ctx (false: the context could not be made)
+    bool wait_stage() {
+        while (!__atomic_load_n(&stage_ready, __ATOMIC_ACQUIRE)) {
+            if (ready.load()) return hrc == INQ_OK || __atomic_load_n(&stage_ready, __ATOMIC_ACQUIRE) != 0;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        return true;
     }
     std::mutex mu;
     bool wait() {  // any thread

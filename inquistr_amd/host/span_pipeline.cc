@@ -322,7 +322,7 @@ SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamFile &ba
     // the loader uploads every span it has read (waiting for the context the first time), so that the upload of span k+1
     // overlaps the inflate of span k
     return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
-                            [&actx](const inq_span_t &sp, int slot) { return actx.wait() && inq_span_stage_begin(actx.ctx, &sp, slot) == INQ_OK; },
+                            [&actx](const inq_span_t &sp, int slot) { return actx.wait_stage() && inq_span_stage_begin(actx.ctx, &sp, slot) == INQ_OK; },
                             slot_base, pool, std::getenv("INQ_GATE_READS") ? std::function<void()>([&actx] { (void)actx.wait(); }) : std::function<void()>(),
                             [&actx, dev = args->device]() -> int {
                                 if (const char *e = std::getenv("INQ_NUMA_NODE")) return std::atoi(e);
