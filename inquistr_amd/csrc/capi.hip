@@ -139,15 +139,18 @@ int inq_ctx_create_early(int device_id, inq_ctx_t **out, volatile int *stage_rea
     };
     lap("device properties");
     if (hipSetDevice(device_id) != hipSuccess) return fail(INQ_ERR_HIP);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(INQ_ERR_HIP);
-    lap("hipSetDevice + first stream");
+    // the streams of the staging path first (the process's first stream costs 18 - 170 ms, every further one 8): uploads and the
+    // inflates behind them start while the rest of the context is still being made
     if (span_state_init(c) != INQ_OK) return fail(INQ_ERR_HIP);
-    lap("span state (events, streams)");
+    lap("hipSetDevice + copy / inflate streams, slots");
     *out = c;
     if (stage_ready) {
         published = true;
         __atomic_store_n(stage_ready, 1, __ATOMIC_RELEASE);
     }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(INQ_ERR_HIP);
+    if (span_state_init_rest(c) != INQ_OK) return fail(INQ_ERR_HIP);
+    lap("main stream, span state");
     if (hipMalloc((void **)&c->d_status, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_NOMEM);
     if (hipMemset(c->d_status, 0, sizeof(DevStatus)) != hipSuccess) return fail(INQ_ERR_HIP);
     if (hipHostMalloc((void **)&c->h_status, sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) return fail(INQ_ERR_NOMEM);

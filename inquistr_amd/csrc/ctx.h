@@ -89,7 +89,8 @@ void purge_retired(inq_ctx *c);  // hipFree of everything retired (waits for the
 int call_batch_device_impl(inq_ctx *c, const inq_batch_t *b, inq_result_t *r, void *hip_stream);
 int status_to_code(uint32_t st);
 void span_state_destroy(SpanState *s);
-int span_state_init(inq_ctx *c);  // device front end state; called by inq_ctx_create
+int span_state_init(inq_ctx *c);       // device front end state, the part staging needs (streams, slots); called by inq_ctx_create
+int span_state_init_rest(inq_ctx *c);  // ... and the part the calls need
 void preload_locus(hipStream_t s);
 void preload_inflate(hipStream_t s);
 void preload_scan(hipStream_t s);

@@ -58,7 +58,8 @@ struct SpanState {
     } stage[INQ_SPAN_SLOTS];  // two sets of four: the spans of the NEXT file of a cohort are staged while this file's are still being called
     hipStream_t copy_stream = nullptr;
     hipStream_t ahead_stream = nullptr;  // the inflates launched at staging time
-    hipStream_t warm_stream = nullptr;  // the one warm-up copy below: the copy stream may be busy uploading the next span
+    hipEvent_t ev_warm = nullptr;  // behind the one warm-up copy below (it goes on the ahead stream: a stream of its own cost 8 ms of start-up)
+    bool warm_pending = false;
     // the batch the last inq_call_span built
     uint64_t n_reads = 0, n_cigar_words = 0, n_pairs = 0, n_loci = 0;
     bool last_from_acc = false;
@@ -95,7 +96,7 @@ void span_state_destroy(SpanState *S) {
     for (DevBuf *b : {&S->acc.cigar, &S->acc.reads, &S->acc.pair_read, &S->acc.off, &S->acc.lstart, &S->acc.lend})
         if (b->p) (void)hipFree(b->p);
     if (S->copy_stream) (void)hipStreamDestroy(S->copy_stream);
-    if (S->warm_stream) (void)hipStreamDestroy(S->warm_stream);
+    if (S->ev_warm) (void)hipEventDestroy(S->ev_warm);
     if (S->d_st) (void)hipFree(S->d_st);
     if (S->h) (void)hipHostFree(S->h);
     if (S->h_rows) (void)hipHostFree(S->h_rows);
@@ -112,12 +113,8 @@ int inq::span_state_init(inq_ctx *c) {
     SpanState *S = new (std::nothrow) SpanState();
     if (!S) return INQ_ERR_NOMEM;
     c->span = S;
-    HIP_TRY(c, hipMalloc((void **)&S->d_st, sizeof(FrontStatus)));
-    HIP_TRY(c, hipHostMalloc((void **)&S->h, sizeof(SpanState::Host), hipHostMallocDefault));
-    for (auto &e : S->ev) HIP_TRY(c, hipEventCreate(&e));
-    S->have_ev = true;
+    // what STAGING needs, and nothing else: inq_ctx_create_early publishes the context right behind this function
     HIP_TRY(c, hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&S->warm_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&S->ahead_stream, hipStreamNonBlocking));
     if (const char *e = std::getenv("INQ_INFLATE_AHEAD")) c->inflate_ahead = std::atoi(e) != 0;  // A/B and tests; the option is "inflate_ahead"
     if (const char *e = std::getenv("INQ_GATHER_NT")) c->gather_nt = std::atoi(e) != 0;            // A/B; the option is "gather_nt"
@@ -127,6 +124,17 @@ int inq::span_state_init(inq_ctx *c) {
         HIP_TRY(c, hipEventCreate(&g.ev_inf0));
         HIP_TRY(c, hipEventCreate(&g.ev_inf1));
     }
+    return INQ_OK;
+}
+
+// the rest of the span state: what the calls (not the staging) need
+int inq::span_state_init_rest(inq_ctx *c) {
+    SpanState *S = c->span;
+    HIP_TRY(c, hipMalloc((void **)&S->d_st, sizeof(FrontStatus)));
+    HIP_TRY(c, hipHostMalloc((void **)&S->h, sizeof(SpanState::Host), hipHostMallocDefault));
+    for (auto &e : S->ev) HIP_TRY(c, hipEventCreate(&e));
+    S->have_ev = true;
+    HIP_TRY(c, hipEventCreateWithFlags(&S->ev_warm, hipEventDisableTiming));
     return INQ_OK;
 }
 
@@ -355,7 +363,9 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     if (!S->copy_path_warm && u_bytes >= (512u << 10)) {
         // the first device-to-host copy of this size costs the host ~8 ms inside the runtime; spent here, on another stream,
         // it hides behind the inflate that was just enqueued instead of sitting behind the last kernel of the span
-        HIP_TRY(c, hipMemcpyAsync(S->h_rows, ahead ? staged->u.p : S->u.p, 512u << 10, hipMemcpyDeviceToHost, S->warm_stream));
+        HIP_TRY(c, hipMemcpyAsync(S->h_rows, ahead ? staged->u.p : S->u.p, 512u << 10, hipMemcpyDeviceToHost, S->ahead_stream));
+        HIP_TRY(c, hipEventRecord(S->ev_warm, S->ahead_stream));
+        S->warm_pending = true;
         S->copy_path_warm = true;
     }
     HIP_TRY(c, hipMemcpyAsync(&S->h->val[0], a.anchor_base + na, 8, hipMemcpyDeviceToHost, s));
@@ -535,7 +545,10 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     c->call_hint = std::max<uint32_t>(S->h->st.max_reads, 1u);
     if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(S->ev[5], s));
-    HIP_TRY(c, hipStreamSynchronize(S->warm_stream));  // the warm-up copy (long done) must not land in the rows
+    if (S->warm_pending) {  // the warm-up copy (long done) must not land in the rows
+        HIP_TRY(c, hipEventSynchronize(S->ev_warm));
+        S->warm_pending = false;
+    }
     HIP_TRY(c, hipMemcpyAsync(S->h_rows, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(S->h_rows + nl, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&S->h->ks, c->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
@@ -627,7 +640,10 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
         (void)hipEventElapsedTime(&ms2, S->ev[0], S->ev[1]);
         std::fprintf(stderr, "[inq call] the same %llu loci again: locus kernels %.3f ms\n", (unsigned long long)nl, (double)ms2);
     }
-    HIP_TRY(c, hipStreamSynchronize(S->warm_stream));
+    if (S->warm_pending) {
+        HIP_TRY(c, hipEventSynchronize(S->ev_warm));
+        S->warm_pending = false;
+    }
     HIP_TRY(c, hipMemcpyAsync(S->h_rows, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(S->h_rows + nl, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&S->h->ks, c->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
