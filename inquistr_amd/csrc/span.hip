@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "ctx.h"
@@ -652,7 +653,14 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
     HIP_TRY(c, hipStreamSynchronize(s));
     std::memcpy(r->phase1, S->h_rows, nl * 8);
     std::memcpy(r->phase2, S->h_rows + nl, nl * 8);
-    if (c->retired_bytes > (2ull << 30)) purge_retired(c);  // (an unlocked look: a stale value only moves the purge to the next flush)
+    {
+        bool much;
+        {
+            std::lock_guard<std::mutex> g(c->retired_mu);
+            much = c->retired_bytes > (2ull << 30);
+        }
+        if (much) purge_retired(c);
+    }
     if (ms_call) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, S->ev[4], S->ev[5]);
@@ -681,7 +689,10 @@ int span_stage_begin_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
     SpanState *S;
     if ((rc = span_state(c, &S)) != INQ_OK) return rc;
     SpanState::Stage &g = S->stage[slot];
-    if (g.pending) return INQ_ERR_ARG;  // begun twice without a wait in between
+    if (g.pending) {  // begun and never waited for (a run that was torn down half-way): that upload is long over or about to be
+        (void)hipEventSynchronize(g.ev_up);
+        g.pending = false;
+    }
     g.valid = false;
     constexpr size_t kPad = 64;
     hipStream_t s = S->copy_stream;

@@ -230,6 +230,16 @@ void SpanPipeline::run_uploads() {
     };
     std::deque<Flight> inflight;
     const size_t depth = stage_wait_ ? 2 : 1;
+    // whichever way this thread leaves (the file is through, a failure elsewhere, the pipeline torn down early): no upload may still
+    // be reading a span buffer when the buffers are given back
+    struct Drain {
+        std::deque<Flight> &q;
+        WaitFn &wait;
+        ~Drain() {
+            for (auto &f : q)
+                if (f.begun && wait) (void)wait(f.it->slot);
+        }
+    } drain{inflight, stage_wait_};
     auto finish_oldest = [&] {
         Flight f = inflight.front();
         inflight.pop_front();

@@ -6,6 +6,7 @@
 #   profiles              rocprofv3 summaries: hot kernel (tools/profile_round.sh) and device front end (tools/profile_front.sh)
 #   loop [loci] [level]   span loop of a SEQ-bearing file: runs with the CLI's own clocks, /proc/vmstat and cpu.stat beside them
 #   cig [runs]            the same on the 0.8 GB CIGAR-only file, back to back and with rests between the processes
+#   soak                  damaged deflate streams, random BAMs through both front ends (new seeds)
 #   probes                what allocations, streams, synchronisations cost; hipMalloc back to back
 # Results go to gpurun_out/<what>/ (scratch); what is quoted in DESIGN.md is copied to profiles/r04_results/.
 set -o pipefail
@@ -48,6 +49,10 @@ cig)
   SHOW_CALLS=1 timeout -k 10 300 python3 tools/span_loop_runs.py $D/cig ${1:-12} --unphased - 2>&1 | tee -a $OUT/cig_runs.txt
   echo "--- 1.5 s between runs" | tee -a $OUT/cig_runs.txt
   PAUSE_S=1.5 timeout -k 10 300 python3 tools/span_loop_runs.py $D/cig ${1:-12} --unphased - 2>&1 | tee -a $OUT/cig_runs.txt ;;
+soak)
+  INQ_SOAK_SEED=${1:-740400} timeout -k 10 420 python3 tools/soak_inflate.py 250 3 > $OUT/soak_inflate.txt 2>&1; echo "soak_inflate rc $?" | tee -a $OUT/soak_inflate.txt; tail -2 $OUT/soak_inflate.txt
+  timeout -k 10 420 python3 tools/soak_e2e.py --cases 400 --frontend device --seed0 ${2:-818000} > $OUT/soak_e2e_device.txt 2>&1; echo "soak_e2e device rc $?" | tee -a $OUT/soak_e2e_device.txt; tail -2 $OUT/soak_e2e_device.txt
+  timeout -k 10 120 python3 tools/soak_e2e.py --cases 80 --frontend host --seed0 ${3:-919000} > $OUT/soak_e2e_host.txt 2>&1; echo "soak_e2e host rc $?" | tee -a $OUT/soak_e2e_host.txt; tail -2 $OUT/soak_e2e_host.txt ;;
 probes)
   for x in alloc_probe stream_probe; do [ -x inquistr_amd/lib/$x ] || /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -pthread -Wno-unused-result tools/$x.hip -o inquistr_amd/lib/$x; done
   timeout -k 10 60 inquistr_amd/lib/alloc_probe 2>&1 | tee $OUT/alloc_probe.txt
