@@ -54,7 +54,7 @@ soak)
   timeout -k 10 420 python3 tools/soak_e2e.py --cases 400 --frontend device --seed0 ${2:-818000} > $OUT/soak_e2e_device.txt 2>&1; echo "soak_e2e device rc $?" | tee -a $OUT/soak_e2e_device.txt; tail -2 $OUT/soak_e2e_device.txt
   timeout -k 10 120 python3 tools/soak_e2e.py --cases 80 --frontend host --seed0 ${3:-919000} > $OUT/soak_e2e_host.txt 2>&1; echo "soak_e2e host rc $?" | tee -a $OUT/soak_e2e_host.txt; tail -2 $OUT/soak_e2e_host.txt ;;
 probes)
-  for x in alloc_probe stream_probe; do [ -x inquistr_amd/lib/$x ] || /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -pthread -Wno-unused-result tools/$x.hip -o inquistr_amd/lib/$x; done
+  for x in alloc_probe stream_probe; do [ -x inquistr_amd/lib/$x ] || /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -pthread -Wno-unused-value tools/$x.hip -o inquistr_amd/lib/$x; done
   timeout -k 10 60 inquistr_amd/lib/alloc_probe 2>&1 | tee $OUT/alloc_probe.txt
   timeout -k 10 60 inquistr_amd/lib/stream_probe 5 2>&1 | tee $OUT/stream_probe.txt
   for i in 1 2 3; do timeout -k 10 60 inquistr_amd/lib/alloc_probe 2>&1 | grep -E "hipMalloc (1024|4096) MB"; done | tee $OUT/alloc_back_to_back.txt
