@@ -342,9 +342,30 @@ class Context:
             self._raise(rc)
         return rc, p1, p2, int(res.n_tie_loci), stats
 
+    def span_stage_begin(self, comp, blocks, anchors, anchor_stop, slot: int, check: bool = True) -> int:
+        """inq_span_stage_begin: the upload (and the inflate behind it) of a span is enqueued into `slot`; `comp` must stay alive and
+        unchanged until span_stage_wait(slot).  Block table and anchors are copied on the spot."""
+        comp = np.frombuffer(comp, dtype=np.uint8)
+        blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK_DTYPE)
+        anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
+        stops = np.ascontiguousarray(anchor_stop, dtype=np.uint64)
+        sp = SpanC(comp.ctypes.data, comp.size, blocks.ctypes.data, len(blocks), anchors.ctypes.data, stops.ctypes.data,
+                   len(anchors), None, None, None, 0, 5, 3, 0, 0)
+        rc = self._L.inq_span_stage_begin(self._h, C.byref(sp), slot)
+        if rc != INQ_OK and check:
+            self._raise(rc)
+        return rc
+
+    def span_stage_wait(self, slot: int, check: bool = True) -> int:
+        rc = self._L.inq_span_stage_wait(self._h, slot)
+        if rc != INQ_OK and check:
+            self._raise(rc)
+        return rc
+
     def call_span_deferred(self, comp, blocks, anchors, anchor_stop, locus_tid, locus_start, locus_end, minlen: int = 5, support: int = 3,
-                           unphased: bool = False, check: bool = True, stage_slot: Optional[int] = None):
-        """inq_call_span_deferred: appends the span's batch to the deferred one; returns (code, stats).  Rows: call_flush()."""
+                           unphased: bool = False, check: bool = True, stage_slot: Optional[int] = None, prestaged: bool = False):
+        """inq_call_span_deferred: appends the span's batch to the deferred one; returns (code, stats).  Rows: call_flush().
+        prestaged: the span already sits in stage_slot (span_stage_begin + span_stage_wait): it is not staged again."""
         comp = np.frombuffer(comp, dtype=np.uint8)
         blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK_DTYPE)
         anchors = np.ascontiguousarray(anchors, dtype=np.uint64)
@@ -356,7 +377,7 @@ class Context:
                    len(anchors), lt.ctypes.data, ls.ctypes.data, le.ctypes.data, len(ls), minlen, support, 1 if unphased else 0, 0)
         stats = SpanStatsC()
         rc = INQ_OK
-        if stage_slot is not None:
+        if stage_slot is not None and not prestaged:
             rc = self._L.inq_span_stage(self._h, C.byref(sp), stage_slot)
         if rc == INQ_OK:
             rc = self._L.inq_call_span_deferred(self._h, C.byref(sp), -1 if stage_slot is None else stage_slot, C.byref(stats))

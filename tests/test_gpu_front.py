@@ -259,6 +259,57 @@ def test_call_span_matches_oracle_and_host_emulation(ctx, tmp_path, monkeypatch,
     sp.close()
 
 
+@pytest.mark.parametrize("seed,unphased", [(21, False), (22, True)])
+def test_two_spans_enqueued_before_the_first_is_waited_for(ctx, tmp_path, seed, unphased):
+    """inq_span_stage_begin / _wait as the driver's uploader uses them (round 4): two spans are ENQUEUED (upload + the inflate behind
+    it) into two of the eight slots before the first is waited for, so that the copy engine goes from one span's bytes straight to
+    the next one's; the slots rotate, the tables travel through the slot's page-locked buffer (the caller's are scribbled over right
+    after _begin), a slot that was begun and never waited for is usable again.  Rows = the Python restatement's."""
+    from inquistr_amd import call
+    from tests import gen
+    from tests.test_host_frontend import _expected, _make_case
+
+    minlen, support = 5, 2
+    bam, bed, loci, recs = _make_case(tmp_path, seed, n_loci=70)
+    sp = call.Spans(bam, region_file=bed, minlen=minlen, support=support, threads=2, unphased=unphased, max_comp_bytes=4_000)
+    spans = []
+    for span in sp.spans():  # (the iterator reuses its buffers: keep copies)
+        spans.append({k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else bytes(v) if k == "comp" else v) for k, v in span.items()})
+    sp.close()
+    assert len(spans) >= 5
+    # a slot begun and abandoned: the next _begin on it goes through
+    s0 = spans[0]
+    ctx.span_stage_begin(s0["comp"], s0["blocks"], s0["anchors"], s0["anchor_stop"], 7)
+    got1 = np.full(len(loci), np.nan)
+    got2 = np.full(len(loci), np.nan)
+    order = []
+
+    def begin(k):
+        s = spans[k]
+        blocks, anchors, stops = s["blocks"].copy(), s["anchors"].copy(), s["anchor_stop"].copy()
+        ctx.span_stage_begin(s["comp"], blocks, anchors, stops, (k * 3 + 7) % 8)
+        blocks[...] = 0  # the library has its own copy
+        anchors[...] = 0
+        stops[...] = 0
+
+    begin(0)
+    for k in range(len(spans)):
+        if k + 1 < len(spans):
+            begin(k + 1)  # the second one in flight
+        slot = (k * 3 + 7) % 8
+        ctx.span_stage_wait(slot)
+        s = spans[k]
+        rc, _stats = ctx.call_span_deferred(s["comp"], s["blocks"], s["anchors"], s["anchor_stop"], s["locus_tid"], s["locus_start"], s["locus_end"],
+                                            minlen, support, unphased, stage_slot=slot, prestaged=True)
+        assert rc == 0
+        order.extend(int(i) for i in s["locus_index"])
+    rc, p1, p2, _ties, _ms = ctx.call_flush()
+    assert rc == 0 and len(p1) == len(order)
+    got1[order], got2[order] = p1, p2
+    want1, want2 = _expected(loci, recs, unphased, minlen, support)
+    assert gen.same_f64(got1, want1) and gen.same_f64(got2, want2)
+
+
 @pytest.mark.parametrize("seed,unphased,span_bytes,gap,flush_every", [(1, False, 3_000, None, 0), (2, True, 20_000, None, 3), (3, False, 3_000, None, 2),
                                                                       (6, True, 30_000, 0, 0), (7, False, 1, None, 5)])
 def test_deferred_spans_equal_span_by_span_calls(ctx, tmp_path, monkeypatch, seed, unphased, span_bytes, gap, flush_every):
