@@ -550,6 +550,43 @@ def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str =
             "note": "CPU modes = oracle/ref_shaped_call: CPU restatement of the reference's control flow, not the Rust binary"}
 
 
+def live_traffic(workload: str, per_gpu: int):
+    """HBM bytes per launch of the hot kernel from the PMC counters, collected IN THIS RUN: two child processes under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domains, as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes) run this very script's timed loop for a few steps; FETCH_SIZE is doubled (gfx950 counts a wide coalesced stream at
+    half), WRITE_SIZE taken as is, KiB -> bytes, mean over the kernel's dispatches.  None if the profiler is not there or fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="inq_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2",
+                   "--workload", workload, "--loci-per-gpu", str(per_gpu), "--no-cpu-baseline", "--no-l2", "--no-read-peak", "--no-live-pmc"]
+            r = subprocess.run(cmd, capture_output=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "locus_call_small" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None
+            out[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception:  # noqa: BLE001
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_kib, write_kib = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return {"hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024, "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
+            "dispatches": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]]}
+
+
 def measured_read_peak():
     """SURVEY 8(d) prices the kernel against the 8 TB/s spec peak AND against what a pure streaming read reaches on the box:
     tools/hbm_read_peak.hip (built by __graft_entry__.build()) reads 2.4 GB with the hot kernel's access shape - one wave per
@@ -583,6 +620,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-l2", action="store_true", help="skip the end-to-end block of the default N=1 line")
     ap.add_argument("--no-read-peak", action="store_true", help="skip the pure-read ceiling run (a child process; not wanted under a profiler)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from profiles/pmc_latest.json instead of two rocprofv3 --pmc child runs of this script")
     ap.add_argument("--l2-default-loci", type=int, default=100_000, help="loci of the BAM the default line's l2 block is timed on")
     ap.add_argument("--l2-seq-default-loci", type=int, default=6_000,
                     help="loci of the SEQ / QUAL-bearing BAM the default line's l2_seq block is timed on (30 reads x ~18 KB each per locus)")
@@ -795,6 +833,12 @@ def main():
                     pmc_note = {"kind": "stored", "source": pmc.get("source"), "commit": pmc.get("commit"), "profile": pmc.get("profile")}
             except Exception:
                 traffic = None
+        if world == 1 and not args.no_live_pmc:
+            lt = live_traffic(wl.name, per_gpu)
+            if lt:
+                traffic = lt["hbm_bytes_per_launch"]
+                pmc_note = {"kind": "live", "how": "two child runs of this script under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
+                            "2 x FETCH_SIZE (gfx950 wide-stream correction) + WRITE_SIZE, KiB -> bytes, mean over the kernel's dispatches", **lt}
         line = {
             "metric": "loci/sec genotyped (inquiSTR call hot path, device-resident batch = L0)",
             "value": total_loci * args.steps / dt_max,

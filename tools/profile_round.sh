@@ -7,11 +7,11 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-l2 --no-read-peak $*"
+BENCH="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-l2 --no-read-peak --no-live-pmc $*"
 # kernel trace: the driver's own command line (python bench.py, default steps / warmup) minus the legs that start other
 # programs (cpu_baseline builds the oracle with make, l2 runs the CLI: no child processes under the profiler), so the average
 # duration in kernel_stats.csv is directly comparable with roofline.avg_kernel_ms of the default command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-l2 --no-read-peak $* > $OUT/trace.log 2>&1 || { tail -20 $OUT/trace.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-l2 --no-read-peak --no-live-pmc $* > $OUT/trace.log 2>&1 || { tail -20 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $BENCH > $OUT/pmc_fetch.log 2>&1 || { tail -20 $OUT/pmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $BENCH > $OUT/pmc_write.log 2>&1 || { tail -20 $OUT/pmc_write.log; exit 1; }
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -- python3 $BENCH > $OUT/pmc_sq.log 2>&1 || { tail -20 $OUT/pmc_sq.log; }
