@@ -569,7 +569,17 @@ def live_traffic(workload: str, per_gpu: int):
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2",
                    "--workload", workload, "--loci-per-gpu", str(per_gpu), "--no-cpu-baseline", "--no-l2", "--no-read-peak", "--no-live-pmc"]
-            r = subprocess.run(cmd, capture_output=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240)
+            # (its own process group, so that a profiler that hangs is ended together with the program it started)
+            pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), start_new_session=True)
+            try:
+                pr.communicate(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.communicate()
+                return None
+            r = pr
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
