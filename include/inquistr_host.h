@@ -182,6 +182,10 @@ int inq_host_bai_stats(const char *bai_path, uint32_t *n_ref, int32_t tid, uint6
 /* Compressed BAM bytes this process has handed to the device front end so far (all calls, all files): what a rank of the
  * one-process-per-GPU run read for its share of the targets (inq_run_partition promises every rank about the same). */
 uint64_t inq_host_span_bytes_read(void);
+/* Self-check of the reader-thread pool the span loader copies file bytes with (host/span_planner.h IoPool): `rounds` runs of `n_jobs`
+ * jobs on `n_threads` threads (bound to the L3 domains of NUMA node `numa_node`, -1 = the machine, when pin != 0); every job adds
+ * its index + 1 to a sum.  Returns the sum over all rounds (= rounds * n_jobs * (n_jobs + 1) / 2 when every job ran exactly once). */
+uint64_t inq_host_iopool_selftest(int n_threads, int numa_node, int pin, uint64_t n_jobs, uint64_t rounds);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ HOST_ABI_SYMBOLS = (
     "inq_host_parse_region",
     "inq_host_bai_stats",
     "inq_host_span_bytes_read",
+    "inq_host_iopool_selftest",
     "inq_host_bai_file_offset",
     "inq_host_bai_scan_start",
     "inq_host_plan_spans",
@@ -182,6 +183,8 @@ def load():
                                           C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
         L.inq_host_bam_tid.restype = C.c_int
         L.inq_host_bam_tid.argtypes = [C.c_char_p, C.c_char_p]
+        L.inq_host_iopool_selftest.restype = C.c_uint64
+        L.inq_host_iopool_selftest.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64]
         L.inq_host_span_bytes_read.restype = C.c_uint64
         L.inq_host_span_bytes_read.argtypes = []
         L.inq_host_bai_stats.restype = C.c_int

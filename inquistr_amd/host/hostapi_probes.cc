@@ -6,6 +6,13 @@ using namespace inqhost;
 
 extern "C" {
 
+uint64_t inq_host_iopool_selftest(int n_threads, int numa_node, int pin, uint64_t n_jobs, uint64_t rounds) {
+    IoPool pool(n_threads, numa_node, pin != 0);
+    std::atomic<uint64_t> sum{0};
+    for (uint64_t r = 0; r < rounds; ++r) pool.run((size_t)n_jobs, [&](size_t k) { sum.fetch_add((uint64_t)k + 1u, std::memory_order_relaxed); });
+    return sum.load();
+}
+
 size_t inq_host_format_f64(double v, char *buf, size_t cap) { return (size_t)std::snprintf(buf, cap, "%s", format_f64(v).c_str()); }
 size_t inq_host_format_row(const char *chrom, uint32_t start, uint32_t end, double p1, double p2, char *buf, size_t cap) {
     return (size_t)std::snprintf(buf, cap, "%s", format_row(chrom, start, end, p1, p2).c_str());

@@ -100,3 +100,17 @@ def test_spans_errors(tmp_path):
     with pytest.raises(call.CallError) as e:
         call.Spans(str(tmp_path / "missing.bam"), region="chr1:100-200")
     assert e.value.status == 1
+
+
+@pytest.mark.parametrize("threads,pin", [(1, 0), (2, 1), (5, 1), (16, 1), (16, 0), (33, 1)])
+def test_reader_pool_runs_every_job_exactly_once(threads, pin):
+    """The pool of reader threads the span loader copies file bytes with (made once per file, bound in turn to the L3 domains of
+    a NUMA node where sysfs shows any): many rounds of few and of many jobs, fewer jobs than threads, none at all - every job runs
+    exactly once per round, whatever the thread count and the binding (node 0, the machine, a node that does not exist)."""
+    from inquistr_amd import call
+
+    L = call.load()
+    for node in (0, -1, 77):
+        for n_jobs, rounds in ((0, 3), (1, 50), (3, 200), (64, 100), (1000, 20)):
+            want = rounds * n_jobs * (n_jobs + 1) // 2
+            assert L.inq_host_iopool_selftest(threads, node, pin, n_jobs, rounds) == want, (threads, pin, node, n_jobs, rounds)
