@@ -476,3 +476,32 @@ def test_four_ranks_on_one_gpu_share_the_bytes_and_print_the_same_rows(tmp_path,
     assert all(abs(b - mean) <= 0.15 * mean for b in read), f"BAM bytes per rank {read} (mean {mean:.0f})"
     # what the ranks read together is the file once, plus what neighbours both need at the three cuts
     assert sum(read) < 1.1 * os.path.getsize(prefix + ".bam")
+
+
+@pytest.mark.parametrize("workload,n_loci,seq", [("unphased100k", 20_000, False), ("phased10k", 10_000, False), ("expansion50k", 1_500, True)])
+def test_file_scale_rows_equal_the_cpu_program_whatever_the_span_size(tmp_path, workload, n_loci, seq):
+    """At file scale (BASELINE's configs #3, #2 and #5 cut to 10 - 20 000 loci, zlib level 6; config #5 with SEQ / QUAL-bearing
+    records): the `.inq` of the product CLI is the same for 256 MB, 16 MB and 3 MB spans (how the file is cut, how many spans are in
+    flight, how often the batch is flushed must not show), the same through the host front end, and byte for byte what
+    oracle/ref_shaped_call prints - the reference's control flow on the CPU oracle with its OWN BGZF / BAM / BAI reader (zlib), no
+    code shared with the product."""
+    from inquistr_amd import synth
+    from tools import make_synth_bam
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
+    ref = os.path.join(root, "oracle", "ref_shaped_call")
+    wl = synth.WORKLOADS[workload]
+    prefix = str(tmp_path / "f")
+    make_synth_bam.write_native(workload, n_loci, prefix, level=6, seq=seq)
+    un = ["-u"] if wl.unphased else []
+    cmd = [call.CLI_PATH, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", "8", "--sample-name", "S", "-m", str(wl.minlen), "-s", str(wl.support)] + un
+    want = subprocess.run([ref, prefix + ".bam", prefix + ".bed", "B", "8", str(int(wl.unphased)), str(wl.minlen), str(wl.support), "S"],
+                          capture_output=True)
+    assert want.returncode == 0, want.stderr[-500:]
+    assert want.stdout.count(b"\n") == n_loci + 1
+    for env in ({"INQ_FRONTEND": "device"}, {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "16", "INQ_FLUSH_LOCI": "3000"},
+                {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "3", "INQ_INFLATE_AHEAD": "0"}, {"INQ_FRONTEND": "host"}):
+        r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-500:]
+        assert r.stdout == want.stdout, f"rows differ with {env}"
