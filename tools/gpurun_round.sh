@@ -50,8 +50,8 @@ cig)
   echo "--- 1.5 s between runs" | tee -a $OUT/cig_runs.txt
   PAUSE_S=1.5 timeout -k 10 300 python3 tools/span_loop_runs.py $D/cig ${1:-12} --unphased - 2>&1 | tee -a $OUT/cig_runs.txt ;;
 soak)
-  INQ_SOAK_SEED=${1:-740400} timeout -k 10 420 python3 tools/soak_inflate.py 250 3 > $OUT/soak_inflate.txt 2>&1; echo "soak_inflate rc $?" | tee -a $OUT/soak_inflate.txt; tail -2 $OUT/soak_inflate.txt
-  timeout -k 10 420 python3 tools/soak_e2e.py --cases 400 --frontend device --seed0 ${2:-818000} > $OUT/soak_e2e_device.txt 2>&1; echo "soak_e2e device rc $?" | tee -a $OUT/soak_e2e_device.txt; tail -2 $OUT/soak_e2e_device.txt
+  INQ_SOAK_SEED=${1:-740400} timeout -k 10 420 python3 tools/soak_inflate.py ${4:-250} 3 > $OUT/soak_inflate.txt 2>&1; echo "soak_inflate rc $?" | tee -a $OUT/soak_inflate.txt; tail -2 $OUT/soak_inflate.txt
+  timeout -k 10 420 python3 tools/soak_e2e.py --cases ${5:-400} --frontend device --seed0 ${2:-818000} > $OUT/soak_e2e_device.txt 2>&1; echo "soak_e2e device rc $?" | tee -a $OUT/soak_e2e_device.txt; tail -2 $OUT/soak_e2e_device.txt
   timeout -k 10 120 python3 tools/soak_e2e.py --cases 80 --frontend host --seed0 ${3:-919000} > $OUT/soak_e2e_host.txt 2>&1; echo "soak_e2e host rc $?" | tee -a $OUT/soak_e2e_host.txt; tail -2 $OUT/soak_e2e_host.txt ;;
 probes)
   for x in alloc_probe stream_probe; do [ -x inquistr_amd/lib/$x ] || /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -pthread -Wno-unused-value tools/$x.hip -o inquistr_amd/lib/$x; done
