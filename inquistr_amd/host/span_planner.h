@@ -89,9 +89,10 @@ struct SpanData {
 
 // The threads that copy file bytes into a span buffer (pread from the page cache): made once per file, not once per span, and
 // spread over the L3 domains (CCDs) of the NUMA node the GPU hangs on.  Why spread: a copy is bound by memory bandwidth, and on
-// the two-socket EPYC hosts measured a CCD's link to memory carries a fraction of the socket's - when the scheduler happened to
-// start a process's sixteen readers inside ONE CCD every span took 13 - 20 ms to read instead of 4 (the same bytes for five times
-// the CPU time: one run in five, profiles/r04_results/slow_run_in_five.txt).  Threads are bound to a CCD's CPUs, not to one CPU.
+// the two-socket EPYC hosts measured a CCD's link to memory carries a fraction of the socket's; left to the scheduler, sixteen
+// fresh threads per span land where the loader thread is.  Measured on the 12.8 GB file (profiles/r04_results/
+// span_loop_12.8GB_after_changes.txt): span loop 51 - 54 GB/s bound, 37 - 53 (median 45) unbound.  Threads are bound to a CCD's
+// CPUs, not to one CPU.  (Round 3's "one slow run in five" is NOT this: it is the second read of a freshly written file)
 class IoPool {
 public:
     // numa_node < 0: every CPU this process may use; pin = false: plain threads (INQ_IO_PIN=0)
