@@ -49,9 +49,10 @@ struct inq_ctx {
     // off unless asked for (1 = on, -1 = on where the sampled block headers say match-heavy, 0 = off)
     int inflate_tokens = 0;
     int inflate_lit_pairs = -1;  // workgroup inflate's symbol loop: 1 = a second literal from the same peek, 0 = not, -1 = by the data (deflate_probe.h)
-    // a staged span (inq_span_stage) is inflated right behind its upload, on a stream of its own: the device's time per span call drops
-    // by a third, but a staging slot then holds an inflated buffer and token scratch of its own (4 GB more to allocate and to give back
-    // for a 1 GB file: +0.3 s for a one-file process), and with the device out of the way the loop is bound by the host's reads: off
+    // a staged span (inq_span_stage_begin) is inflated right behind its upload, on a stream of its own: the inflate of span k + 1 runs
+    // beside span k's record scan, gather and join.  A staging slot then holds an inflated buffer of its own.  Round 3 left this off
+    // for "+0.3 s for a one-file process"; round 4 found that figure to be the driver's teardown of the PREVIOUS process in the
+    // timing loop, not the allocations (hipMalloc: 10 - 200 us whatever the size): on
     int inflate_ahead = 1;
     // the gather's stores bypass the caches (bam_scan.hip): the batch it builds is read by a later launch, not by this one; the locus
     // kernels behind it run at 5.4 - 6.2 instead of 4.9 - 5.3 TB/s of algorithmic bytes (profiles/r04_results/locus_kernels_in_the_cli.txt)
