@@ -157,7 +157,8 @@ void SpanPipeline::run() {
     // INQ_GATE_READS=1: the first read waits for the device context.  Tried because the runtime's start-up looked longer
     // while the loader was reading (two boxes, 102 vs 221 ms); five runs each way on a third box showed the start-up
     // varying between 108 and 431 ms with and without early reads alike (profiles/r03_results/loader_gate_ab.txt): it
-    // is hipInit itself that varies (57 - 224 ms), so reads start at once - the spans are there when the context is.
+    // is hipInit itself that varies (57 - 224 ms: round 4 found the cause - the driver still taking the PREVIOUS process of the timing
+    // loop apart), so reads start at once - the spans are there when the context is.
     if (have && gate_) gate_();
     while (have) {
         Item *it = nullptr;
