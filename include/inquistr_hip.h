@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define INQ_ABI_VERSION 4
+#define INQ_ABI_VERSION 5
 
 /* ---- error codes (0 = ok, negative = failure; never throws / aborts) ---- */
 enum {
@@ -144,6 +144,12 @@ int inq_ctx_create(int device_id, inq_ctx_t **out);
  * on it from another thread, ~30 ms before the function returns; every other entry point only after it has returned INQ_OK.  A
  * context that was published stays valid until inq_ctx_destroy, whatever the return value (the caller destroys it). */
 int inq_ctx_create_early(int device_id, inq_ctx_t **ctx, volatile int *stage_ready);
+/* The list form ("inq_ctx_create(device_ids, n, &ctx)"; the reference's counterpart is rayon's pool of workers,
+ * src/call.rs:104-118): one context per entry of device_ids - an ordinal may repeat -, made concurrently (each on a thread of
+ * its own: the runtime's start-up is paid once, the per-device parts side by side); ctxs[0 .. n) receive them.  All or nothing: on
+ * failure every context that was made is destroyed again, ctxs[] is all NULL and the first failing entry's code is returned.  Each
+ * context is then driven by its own host thread (a ctx serves one caller at a time; distinct ctxs are independent). */
+int inq_ctx_create_multi(const int *device_ids, int n, inq_ctx_t **ctxs);
 void inq_ctx_destroy(inq_ctx_t *ctx);
 
 /* Host-buffer entry: batch and result point to HOST memory (pinned for best H2D).

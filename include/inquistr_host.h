@@ -64,6 +64,41 @@ int inq_genotype_repeats_rows(const inq_call_args_t *args, const uint32_t *targe
 int inq_host_partition(const inq_call_args_t *args, uint64_t world, uint32_t *order, uint64_t order_cap, uint64_t *cuts, uint64_t *n_targets,
                        char *errbuf, size_t errcap);
 
+/* ---- several GPUs of one node from ONE process (north_star: "Partition loci across the 8 GPUs of one node ... a trivial gather of
+ * per-shard .inq rows"; the reference's counterpart is the rayon loop over loci, src/call.rs:103-145).  The command of
+ * inq_genotype_repeats on the HIP devices device_ids[0 .. n_devices): the targets, in file order, are cut into n_devices contiguous
+ * parts of about equal compressed BAM bytes (as inq_run_partition), part r runs whole - its own reader pool, uploads, spans, locus
+ * kernels - on a thread and a device context of its own on device_ids[r], the rows land in this process's arrays (the gather is a
+ * scatter in host memory: no collective, no torch) and the calling thread writes the ordered .inq to out_fd.  An ordinal may appear
+ * more than once (a rehearsal of N parts on one GPU).  args->device is ignored.  stats (may be NULL): [n_devices], one entry per part.
+ * Byte for byte the output of inq_genotype_repeats; same exit statuses (the first failing part's, its message prefixed "part r of N").
+ * The host's cores are dealt among the parts: each reader pool takes granted cores / n_devices threads (at least 2). */
+typedef struct inq_part_stats {
+    int32_t device;          /* device_ids[r]                                                          */
+    int32_t status;          /* this part's exit status                                                */
+    uint64_t loci;           /* targets of the part                                                    */
+    uint64_t spans;          /* spans its device front end was handed (0: host sweep, or nothing to read) */
+    uint64_t bam_bytes_read; /* compressed BAM bytes of those spans                                    */
+    double rows_s;           /* the part's thread, start to rows                                       */
+    double span_loop_s;      /* first span handed to the device -> last flush                          */
+    double wait_loader_s;    /* of which waiting for the loader / uploader                             */
+    double device_calls_s;   /* ... and inside inq_call_span_deferred / inq_call_flush                 */
+    int32_t front;           /* 1 = host sweep, 2 = device spans                                       */
+    int32_t io_threads;      /* reader threads of its span pipeline                                    */
+} inq_part_stats_t;
+int inq_genotype_repeats_devices(const inq_call_args_t *args, const int32_t *device_ids, size_t n_devices, int out_fd, inq_part_stats_t *stats,
+                                 char *errbuf, size_t errcap);
+/* How many processes (or device parts) share this host's cores with this one, and which of them it is (0 .. sharers - 1): sizes the
+ * reader pool of every later call (granted cores / sharers, bound to L3 domains from a different start per sharer).  Default:
+ * LOCAL_WORLD_SIZE / LOCAL_RANK of the environment (torch.distributed.run exports them), else 1 / 0.  sharers <= 0 = that default. */
+void inq_host_set_local_share(int sharers, int index);
+int inq_host_granted_cpus(void); /* CPUs of the affinity mask, cut by the cgroup's CPU quota */
+int inq_host_span_io_threads(uint64_t threads, int sharers); /* the reader pool size a call with -t threads would take */
+/* tests (no GPU involved): the control flow of inq_genotype_repeats_devices with rows that name their target and their part; a device
+ * context that fails in a chosen way (host/multi_device.cc) */
+int inq_host_devices_selftest(const inq_call_args_t *args, size_t n_parts, int fail_part, int out_fd, uint64_t *cuts, char *errbuf, size_t errcap);
+void inq_host_test_ctx_creator(int mode, long timeout_ms);
+
 /* ---- a prepared run: what get_targets + get_bam_reader leave behind (src/call.rs:146-147,182-202), kept open ----
  * The BAM header, its index and the target list are read ONCE; the handle then serves the work split, this process's rows and
  * the output stage of a multi-process run (inquistr_amd/call_dist.py), so that rank 0 neither re-opens the BAM nor re-parses

@@ -23,6 +23,12 @@ CLI_PATH = os.path.join(_PKG, "lib", "inquistr")
 HOST_ABI_SYMBOLS = (
     "inq_genotype_repeats",
     "inq_genotype_repeats_rows",
+    "inq_genotype_repeats_devices",
+    "inq_host_set_local_share",
+    "inq_host_granted_cpus",
+    "inq_host_span_io_threads",
+    "inq_host_devices_selftest",
+    "inq_host_test_ctx_creator",
     "inq_host_partition",
     "inq_run_open",
     "inq_run_n_targets",
@@ -84,6 +90,23 @@ class CallArgsC(C.Structure):
     ]
 
 
+class PartStatsC(C.Structure):
+    """inq_part_stats_t: what one device part of inq_genotype_repeats_devices reports"""
+    _fields_ = [
+        ("device", C.c_int32),
+        ("status", C.c_int32),
+        ("loci", C.c_uint64),
+        ("spans", C.c_uint64),
+        ("bam_bytes_read", C.c_uint64),
+        ("rows_s", C.c_double),
+        ("span_loop_s", C.c_double),
+        ("wait_loader_s", C.c_double),
+        ("device_calls_s", C.c_double),
+        ("front", C.c_int32),
+        ("io_threads", C.c_int32),
+    ]
+
+
 class OutlierArgsC(C.Structure):
     _fields_ = [
         ("combined", C.c_char_p),
@@ -120,6 +143,18 @@ def load():
         L.inq_genotype_repeats.argtypes = [C.POINTER(CallArgsC), C.c_int, C.c_char_p, C.c_size_t]
         L.inq_genotype_repeats_rows.restype = C.c_int
         L.inq_genotype_repeats_rows.argtypes = [C.POINTER(CallArgsC), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.inq_genotype_repeats_devices.restype = C.c_int
+        L.inq_genotype_repeats_devices.argtypes = [C.POINTER(CallArgsC), C.POINTER(C.c_int32), C.c_size_t, C.c_int, C.POINTER(PartStatsC), C.c_char_p, C.c_size_t]
+        L.inq_host_set_local_share.restype = None
+        L.inq_host_set_local_share.argtypes = [C.c_int, C.c_int]
+        L.inq_host_granted_cpus.restype = C.c_int
+        L.inq_host_granted_cpus.argtypes = []
+        L.inq_host_span_io_threads.restype = C.c_int
+        L.inq_host_span_io_threads.argtypes = [C.c_uint64, C.c_int]
+        L.inq_host_devices_selftest.restype = C.c_int
+        L.inq_host_devices_selftest.argtypes = [C.POINTER(CallArgsC), C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.inq_host_test_ctx_creator.restype = None
+        L.inq_host_test_ctx_creator.argtypes = [C.c_int, C.c_long]
         L.inq_host_partition.restype = C.c_int
         L.inq_host_partition.argtypes = [C.POINTER(CallArgsC), C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         L.inq_run_open.restype = C.c_int
@@ -238,6 +273,38 @@ def genotype_repeats(bamp: str, region: Optional[str], region_file: Optional[str
     rc = L.inq_genotype_repeats(C.byref(a), fd, err, len(err))
     if rc != 0:
         raise CallError(rc, err.value.decode(errors="replace"))
+
+
+def genotype_repeats_devices(bamp: str, region: Optional[str], region_file: Optional[str], devices, minlen: int = 5, support: int = 3,
+                             threads: int = 1, unphased: bool = False, sample_name: Optional[str] = None, out=None,
+                             frontend: Optional[str] = None):
+    """inq_genotype_repeats_devices: the same command on several HIP devices from this one process (one thread + one device
+    context per entry of `devices`; an ordinal may repeat).  Returns the per-part statistics as a list of dicts."""
+    L = load()
+    a = _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, None, 0, frontend)
+    ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    st = (PartStatsC * len(devices))()
+    err = C.create_string_buffer(2048)
+    out = sys.stdout if out is None else out
+    out.flush()
+    rc = L.inq_genotype_repeats_devices(C.byref(a), ids, len(devices), out.fileno(), st, err, len(err))
+    if rc != 0:
+        raise CallError(rc, err.value.decode(errors="replace"))
+    return [{f: getattr(x, f) for f, _ in PartStatsC._fields_} for x in st]
+
+
+def devices_selftest(bamp: str, region: Optional[str], region_file: Optional[str], n_parts: int, out, threads: int = 1, fail_part: int = -1):
+    """inq_host_devices_selftest (no GPU): partition, one thread per part, scatter and ordered text of the multi-device entry with
+    rows phase1 = position of the target in the list, phase2 = the part that called it.  Returns the cut points."""
+    L = load()
+    a = _args(bamp, region, region_file, 5, 3, threads, False, "S", None)
+    cuts = np.zeros(n_parts + 1, dtype=np.uint64)
+    err = C.create_string_buffer(2048)
+    out.flush()
+    rc = L.inq_host_devices_selftest(C.byref(a), n_parts, fail_part, out.fileno(), cuts.ctypes.data, err, len(err))
+    if rc != 0:
+        raise CallError(rc, err.value.decode(errors="replace"))
+    return cuts.astype(np.int64)
 
 
 def genotype_repeats_rows(bamp: str, region: Optional[str], region_file: Optional[str], target_index, minlen: int = 5, support: int = 3,

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/inquistr_hip.h"
@@ -168,6 +169,32 @@ int inq_ctx_create(int device_id, inq_ctx_t **out) {
     const int rc = inq_ctx_create_early(device_id, out, nullptr);
     if (rc != INQ_OK && out) *out = nullptr;  // (nothing was published: the context is gone already)
     return rc;
+}
+
+int inq_ctx_create_multi(const int *device_ids, int n, inq_ctx_t **ctxs) {
+    if (!device_ids || !ctxs || n <= 0 || n > 64) return INQ_ERR_ARG;
+    for (int i = 0; i < n; ++i) ctxs[i] = nullptr;
+    try {
+        std::vector<int> rc((size_t)n, INQ_OK);
+        std::vector<std::thread> th;
+        for (int i = 0; i < n; ++i) th.emplace_back([&, i] { rc[(size_t)i] = inq_ctx_create(device_ids[i], &ctxs[i]); });
+        for (auto &t : th) t.join();
+        for (int i = 0; i < n; ++i)
+            if (rc[(size_t)i] != INQ_OK) {
+                for (int k = 0; k < n; ++k) {
+                    inq_ctx_destroy(ctxs[k]);
+                    ctxs[k] = nullptr;
+                }
+                return rc[(size_t)i];
+            }
+        return INQ_OK;
+    } catch (...) {
+        for (int k = 0; k < n; ++k) {
+            inq_ctx_destroy(ctxs[k]);
+            ctxs[k] = nullptr;
+        }
+        return INQ_ERR_NOMEM;
+    }
 }
 
 void inq_ctx_destroy(inq_ctx_t *c) {

@@ -52,6 +52,7 @@ ABI_SYMBOLS = (
     "inq_call_span",
     "inq_span_stage",
     "inq_ctx_create_early",
+    "inq_ctx_create_multi",
     "inq_span_stage_begin",
     "inq_span_stage_wait",
     "inq_call_span_staged",
@@ -180,6 +181,8 @@ def load(path: Optional[str] = None):
     vp = C.c_void_p
     L.inq_ctx_create.restype = C.c_int
     L.inq_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.inq_ctx_create_multi.restype = C.c_int
+    L.inq_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.inq_ctx_destroy.restype = None
     L.inq_ctx_destroy.argtypes = [vp]
     L.inq_call_batch.restype = C.c_int
@@ -250,13 +253,28 @@ def strerror(code: int) -> str:
 class Context:
     """One HIP device context (inq_ctx_t).  Raises InqError(INQ_ERR_NO_DEVICE) without an MI355X."""
 
-    def __init__(self, device_id: int = 0, lib=None):
+    def __init__(self, device_id: int = 0, lib=None, _handle=None):
         self._L = lib if lib is not None else load()
         self._h = C.c_void_p()
+        if _handle is not None:  # made by Context.create_multi
+            self._h = C.c_void_p(_handle)
+            return
         rc = self._L.inq_ctx_create(device_id, C.byref(self._h))
         if rc != INQ_OK:
             self._h = C.c_void_p()
             raise InqError(rc, strerror(rc))
+
+    @classmethod
+    def create_multi(cls, device_ids, lib=None):
+        """inq_ctx_create_multi: one context per entry of device_ids, made concurrently; all or nothing."""
+        L = lib if lib is not None else load()
+        n = len(device_ids)
+        ids = (C.c_int * n)(*[int(d) for d in device_ids])
+        hs = (C.c_void_p * n)()
+        rc = L.inq_ctx_create_multi(ids, n, hs)
+        if rc != INQ_OK:
+            raise InqError(rc, strerror(rc))
+        return [cls(lib=L, _handle=hs[i]) for i in range(n)]
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

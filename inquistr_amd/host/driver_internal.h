@@ -79,45 +79,129 @@ int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg, BedCache *b
 // The device context is created on its own thread from the first instruction of the command: HIP start-up
 // (0.1 - 0.3 s) is the longest fixed cost of a run and overlaps opening the BAM, the BED, the .bai and the
 // first reads of the file.
+//
+// Every wait for that thread is BOUNDED (ctx_timeout_s(): 60 s, INQ_CTX_TIMEOUT_S overrides).  Round 4 lost a GPU box to the case it
+// was not: a profiler's tool library aborted (glog FATAL -> SIGABRT) inside the runtime's first call, ON the context thread
+// (gpurun_out/prof_cli_locus/p2.log: inq_ctx_create_early <- AsyncCtx::start), its signal handler then "finalized" there for ever, and
+// the process stayed: the uploader polled `stage_ready` without end, the caller sat in SpanPipeline::next() behind it, and a join of the
+// context thread would have sat there too.  Now the thread's state lives in a block it shares with its owner; whoever waits gives up
+// after the time-out, the context counts as failed (INQ_ERR_HIP, "did not come up"), the thread is left behind (detached: it may
+// be stuck inside a signal handler or the driver) and the call ends with INQ_EXIT_ERROR.
+double ctx_timeout_s();
+typedef int (*CtxCreateFn)(int device, inq_ctx_t **ctx, volatile int *stage_ready);
+CtxCreateFn ctx_create_fn();  // inq_ctx_create_early, or what inq_host_test_ctx_creator put in its place (tests)
 struct AsyncCtx {
-    inq_ctx_t *ctx = nullptr;
-    int hrc = INQ_OK;
-    int numa_node = -1;
-    std::atomic<bool> ready{false};  // ctx / hrc / numa_node are final
-    // raised by inq_ctx_create_early as soon as spans may be STAGED on ctx (uploads, inflates), ~30 ms before the context is
-    // complete: the uploader thread starts on the spans the loader has read by then
-    volatile int stage_ready = 0;
+    struct State {
+        inq_ctx_t *ctx = nullptr;
+        int hrc = INQ_OK;
+        int numa_node = -1;
+        std::atomic<bool> ready{false};  // ctx / hrc / numa_node are final
+        // raised by inq_ctx_create_early as soon as spans may be STAGED on ctx (uploads, inflates), ~30 ms before the context is
+        // complete: the uploader thread starts on the spans the loader has read by then
+        volatile int stage_ready = 0;
+        std::atomic<bool> gave_up{false};  // a waiter ran into the time-out: hrc is the waiter's verdict, the thread's result is ignored
+        std::mutex mu;
+        std::condition_variable cv;
+    };
+    std::shared_ptr<State> st = std::make_shared<State>();
+    inq_ctx_t *&ctx = st->ctx;
+    int &hrc = st->hrc;
+    int &numa_node = st->numa_node;
+    std::atomic<bool> &ready = st->ready;
     std::thread th;
+    bool started = false;
     bool leak = false;  // set after a clean run when the process is about to exit (INQ_FAST_EXIT)
+    std::chrono::steady_clock::time_point t_start;
+    AsyncCtx() = default;
+    AsyncCtx(const AsyncCtx &) = delete;
     void start(int device) {
-        th = std::thread([this, device] {
+        t_start = std::chrono::steady_clock::now();
+        started = true;
+        std::shared_ptr<State> s = st;  // the thread keeps the block alive, whatever becomes of this object
+        CtxCreateFn create = ctx_create_fn();
+        th = std::thread([s, device, create] {
             prefer_gpu_node_for_this_thread(device);  // what the runtime allocates while it starts
             const double a = stamp_ms();
-            hrc = inq_ctx_create_early(device, &ctx, &stage_ready);
-            numa_node = hrc == INQ_OK ? inq_ctx_numa_node(ctx) : -1;
-            ready.store(true);
+            inq_ctx_t *c = nullptr;
+            // (the early form publishes through these two words; they are read by wait_stage() only)
+            const int rc = create(device, &s->ctx, &s->stage_ready);
+            c = s->ctx;
+            const int node = rc == INQ_OK ? inq_ctx_numa_node(c) : -1;
+            {
+                std::lock_guard<std::mutex> g(s->mu);
+                if (!s->gave_up.load()) s->hrc = rc, s->numa_node = node;
+                s->ready.store(true);
+            }
+            s->cv.notify_all();
             const char *e = std::getenv("INQ_TIMING");
-            if (e && e[0] == '2') std::fprintf(stderr, "[inq ctx] @%.1f device context ready (inq_ctx_create %.1f ms), GPU on NUMA node %d\n", stamp_ms(), stamp_ms() - a, numa_node);
+            if (e && e[0] == '2') std::fprintf(stderr, "[inq ctx] @%.1f device context ready (inq_ctx_create %.1f ms), GPU on NUMA node %d\n", stamp_ms(), stamp_ms() - a, node);
         });
     }
-    // any thread: true once spans may be staged on ctx (false: the context could not be made)
+    // marks the context as failed because its thread did not finish in time; the thread is left to itself
+    void give_up_locked() {
+        if (st->gave_up.exchange(true)) return;
+        st->hrc = INQ_ERR_HIP;
+        st->numa_node = -1;
+        if (th.joinable()) th.detach();
+    }
+    double seconds_left() const {
+        return ctx_timeout_s() - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    }
+    // any thread: true once spans may be staged on ctx (false: the context could not be made, or not in time)
     bool wait_stage() {
-        while (!__atomic_load_n(&stage_ready, __ATOMIC_ACQUIRE)) {
-            if (ready.load()) return hrc == INQ_OK || __atomic_load_n(&stage_ready, __ATOMIC_ACQUIRE) != 0;
+        while (!__atomic_load_n(&st->stage_ready, __ATOMIC_ACQUIRE)) {
+            if (ready.load()) return hrc == INQ_OK && !st->gave_up.load() && __atomic_load_n(&st->stage_ready, __ATOMIC_ACQUIRE) != 0;
+            if (st->gave_up.load()) return false;
+            if (seconds_left() <= 0) {
+                std::lock_guard<std::mutex> g(st->mu);
+                if (!ready.load()) give_up_locked();
+                return false;
+            }
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
-        return true;
+        return ctx != nullptr && !st->gave_up.load();
     }
-    std::mutex mu;
-    bool wait() {  // any thread
-        std::lock_guard<std::mutex> g(mu);
-        if (th.joinable()) th.join();
-        return hrc == INQ_OK;
+    std::mutex join_mu;
+    bool wait() {  // any thread: the context is complete (true) or there is none (false); never longer than the time-out
+        if (!started) return false;
+        {
+            std::unique_lock<std::mutex> g(st->mu);
+            while (!ready.load() && !st->gave_up.load()) {
+                const double left = seconds_left();
+                if (left <= 0) {
+                    give_up_locked();
+                    break;
+                }
+                st->cv.wait_for(g, std::chrono::duration<double>(std::min(left, 0.25)));
+            }
+        }
+        std::lock_guard<std::mutex> g(join_mu);
+        if (!st->gave_up.load() && th.joinable()) th.join();
+        return hrc == INQ_OK && !st->gave_up.load();
     }
+    bool timed_out() const { return st->gave_up.load(); }
     ~AsyncCtx() {
-        if (th.joinable()) th.join();
-        if (!leak) inq_ctx_destroy(ctx);
+        if (started) (void)wait();
+        // a context whose thread was given up on is never touched again (the thread may still be inside its constructor)
+        if (!leak && !st->gave_up.load()) inq_ctx_destroy(ctx);
     }
+};
+
+// How many processes / device parts share this host's cores with the caller, and which of them it is: the reader pool of a span
+// pipeline takes the granted cores (sched_getaffinity, cut by the cgroup's CPU quota) divided by that number, and binds its threads to
+// L3 domains starting at a different one per sharer.  Default: LOCAL_WORLD_SIZE / LOCAL_RANK as torch.distributed.run exports them
+// (one process per GPU), else 1 / 0; inq_host_set_local_share overrides; the one-process --devices entry passes its own per part.
+int granted_cpus();
+void local_share(int *sharers, int *index);
+void set_local_share(int sharers, int index);
+void set_ctx_creator_for_tests(CtxCreateFn f, long timeout_ms);  // f = nullptr: the real one; timeout_ms < 0: the default
+
+// what a device part of a multi-device call reports (inq_part_stats_t of include/inquistr_host.h is filled from it)
+struct PartStats {
+    uint64_t spans = 0, comp_bytes = 0;
+    double span_loop_s = 0, wait_loader_s = 0, device_calls_s = 0;
+    int front = 0;  // 1 = host sweep, 2 = device spans
+    int io_threads = 0;
 };
 
 // what one call works on: the opened BAM (header + index), the targets it was asked for, the options
@@ -136,6 +220,8 @@ struct SessionHooks {
     HostBufPool *pool = nullptr;
     int slot_base = 0;
     int front = 0;  // 0 = decide here, 1 = host sweep, 2 = device spans (decided when the pipeline was started)
+    int sharers = 0, share_index = 0;  // > 0: this call is one of `sharers` device parts of one process (else: local_share())
+    PartStats *stats = nullptr;        // may be null
 };
 
 // rows instead of text: the targets named by idx[] (positions in the parsed target list) are called, their rows go to p1 / p2
@@ -147,9 +233,10 @@ struct RowsOut {
 };
 
 bool use_device_front(const inq_call_args_t *args, const BamFile &bam, const std::vector<RepeatInterval> &targets);
-int span_io_threads(const inq_call_args_t *args);
+std::string ctx_failure_message(AsyncCtx &actx);
+int span_io_threads(const inq_call_args_t *args, int sharers);
 SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamFile &bam, const std::vector<RepeatInterval> &targets, AsyncCtx &actx,
-                                  int slot_base, HostBufPool *pool);
+                                  int slot_base, HostBufPool *pool, int sharers = 0, int share_index = 0);
 int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1, std::vector<double> &p2,
                      char *errbuf, size_t errcap, double *t_front, double *t_dev, const SessionHooks &hooks = SessionHooks());
 int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepared &P, int out_fd, char *errbuf, size_t errcap, const RowsOut &rows,

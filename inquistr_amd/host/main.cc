@@ -3,6 +3,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,7 @@ static void usage(FILE *f) {
         "      --sample-name <SAMPLE_NAME>  sample name to use in output\n"
         "      --reference <REFERENCE>      reference fasta for cram decoding\n"
         "      --device <N>                 HIP device ordinal [default: 0]\n"
+        "      --devices <N,N,...>          several HIP devices: the loci are split among them by BAM bytes, same output\n"
         "  -h, --help                       Print help\n",
         f);
 }
@@ -222,6 +224,7 @@ int main(int argc, char **argv) {
     a.support = 3;
     a.threads = 1;
     std::string bam;
+    std::vector<int32_t> devices;  // --devices: one part of the targets per entry (an ordinal may repeat: N parts on one GPU)
     auto need = [&](int &i) -> const char * {
         if (i + 1 >= argc) {
             std::fprintf(stderr, "error: a value is required for '%s' but none was supplied\n", argv[i]);
@@ -257,6 +260,14 @@ int main(int argc, char **argv) {
         else if (key == "--sample-name" || key == "--sample_name") a.sample_name = val();
         else if (key == "--reference") a.reference = val();
         else if (key == "--device") a.device = (int32_t)num(val(), "--device");
+        else if (key == "--devices") {
+            const std::string list = val();
+            for (size_t b = 0; b <= list.size();) {
+                const size_t e = std::min(list.find(',', b), list.size());
+                devices.push_back((int32_t)num(list.substr(b, e - b).c_str(), "--devices"));
+                b = e + 1;
+            }
+        }
         else if (key == "-h" || key == "--help") { usage(stdout); return 0; }
         else if (!s.empty() && s[0] == '-' && s.size() > 1) {
             std::fprintf(stderr, "error: unexpected argument '%s' found\n", s.c_str());
@@ -272,6 +283,28 @@ int main(int argc, char **argv) {
         return 2;
     }
     a.bam = bam.c_str();
+    if (devices.size() == 1) a.device = devices[0], devices.clear();
+    if (!devices.empty()) {
+        // one process, one thread + one device context per listed device (host/multi_device.cc); a server holds ONE device
+        char err[1024] = {0};
+        ::setenv("INQ_FAST_EXIT", "1", 0);
+        std::vector<inq_part_stats_t> st(devices.size());
+        int rc = inq::host_api().genotype_repeats_devices(&a, devices.data(), devices.size(), 1 /* stdout */, st.data(), err, sizeof err);
+        if (rc != 0) std::fprintf(stderr, rc == INQ_EXIT_PANIC ? "thread 'main' panicked:\n%s\n" : "%s\n", err);
+        if (std::getenv("INQ_TIMING"))
+            for (size_t r = 0; r < st.size(); ++r)
+                std::fprintf(stderr,
+                             "[inq part] %zu of %zu on device %d: status %d, %llu loci, %llu spans, %.1f MB of BAM read by %d reader threads, rows %.3f s "
+                             "(span loop %.3f s = %.2f GB/s, waiting for the loader %.3f s, device calls %.3f s), front end %s\n",
+                             r, st.size(), st[r].device, st[r].status, (unsigned long long)st[r].loci, (unsigned long long)st[r].spans,
+                             st[r].bam_bytes_read / 1e6, st[r].io_threads, st[r].rows_s, st[r].span_loop_s,
+                             st[r].span_loop_s > 0 ? st[r].bam_bytes_read / 1e9 / st[r].span_loop_s : 0.0, st[r].wait_loader_s, st[r].device_calls_s,
+                             st[r].front == 2 ? "device" : st[r].front == 1 ? "host" : "-");
+        std::fflush(nullptr);
+        const char *fast = std::getenv("INQ_FAST_EXIT");
+        if (fast && fast[0] == '1') std::_Exit(rc);
+        return rc;
+    }
     if (const char *server_env = std::getenv("INQ_SERVER"); server_env && *server_env) {
         // INQ_SERVER=auto: this user's server for the device, started (detached; it leaves after INQ_SERVER_IDLE seconds without a
         // call, 120 by default) when none is running - the first call of a batch pays the start-up, the others find the context there

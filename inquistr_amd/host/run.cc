@@ -129,6 +129,7 @@ int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepared &P, 
 
     const auto t_open = clk::now();
     const bool device_front = hooks.front ? hooks.front == 2 : use_device_front(args, V.bam, V.targets);
+    if (hooks.stats) hooks.stats->front = device_front ? 2 : 1;
     if (device_front) {
         const auto t_choice = clk::now();
         int drc = run_device_front(args, V, actx, p1, p2, errbuf, errcap, &t_front, &t_dev, hooks);
@@ -154,7 +155,7 @@ int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepared &P, 
             ctx_ready = true;
         }
         if (hrc != INQ_OK) {
-            set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
+            set_err(errbuf, errcap, ctx_failure_message(actx));
             return false;
         }
         return true;

@@ -149,7 +149,7 @@ void SpanPipeline::run() {
     if (!loader.open(path_, &e)) return fail(e);
     // the reader threads of this file (span_planner.h: spread over the L3 domains of the GPU's NUMA node)
     const char *pin_env = std::getenv("INQ_IO_PIN");
-    IoPool pool(n_threads_, guess_gpu_numa_node(device_), !(pin_env && pin_env[0] == '0'));
+    IoPool pool(n_threads_, guess_gpu_numa_node(device_), !(pin_env && pin_env[0] == '0'), io_group_offset_);
     if (verbose_) std::fprintf(stderr, "[inq loader] @%.1f %s\n", stamp_ms(), pool.layout().c_str());
     // span k + 1 is planned (index searches for some 25 000 loci: ~4 ms) on a helper thread while span k is being read
     SpanPlan ahead;
@@ -318,28 +318,112 @@ bool use_device_front(const inq_call_args_t *args, const BamFile &bam, const std
     return bytes >= kDeviceFrontMinBytesPerThread * std::max<uint64_t>(1, std::min<uint64_t>(args->threads, 16));
 }
 
+static std::atomic<int> g_sharers{0}, g_share_index{0};  // inq_host_set_local_share; 0 = not set
+
+// ---- the device context's thread: its time-out, what creates the context (tests put a failing creator there)
+static std::atomic<long> g_ctx_timeout_ms{-1};
+static std::atomic<CtxCreateFn> g_ctx_create{nullptr};
+double ctx_timeout_s() {
+    const long forced = g_ctx_timeout_ms.load();
+    if (forced >= 0) return forced / 1e3;
+    if (const char *e = std::getenv("INQ_CTX_TIMEOUT_S")) {
+        const double v = std::atof(e);
+        if (v > 0) return v;
+    }
+    return 60.0;
+}
+CtxCreateFn ctx_create_fn() {
+    CtxCreateFn f = g_ctx_create.load();
+    return f ? f : &inq_ctx_create_early;
+}
+void set_ctx_creator_for_tests(CtxCreateFn f, long timeout_ms) {
+    g_ctx_create.store(f);
+    g_ctx_timeout_ms.store(timeout_ms);
+}
+std::string ctx_failure_message(AsyncCtx &actx) {
+    if (actx.timed_out()) {
+        char b[160];
+        std::snprintf(b, sizeof b, "cannot open HIP device: the device context did not come up within %.0f s (its thread is left behind)", ctx_timeout_s());
+        return b;
+    }
+    return std::string("cannot open HIP device: ") + inq_strerror(actx.hrc);
+}
+void set_local_share(int sharers, int index) {
+    g_sharers.store(sharers);
+    g_share_index.store(index);
+}
+
 // fills p1 / p2 through the device front end; returns an exit status
 
-int span_io_threads(const inq_call_args_t *args) {
-    // -t counts the reference's calling workers; here the host only copies file bytes, which a few pread
-    // streams do best whatever -t says (bounded by the machine)
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return (int)std::min<uint64_t>(std::max<uint64_t>(args->threads, 8), std::min<uint64_t>(hw, 32));
+// The cores this process may really use: its affinity mask, cut by the cgroup's CPU quota when one is set (a container on a 256-thread
+// host is typically granted 16: std::thread::hardware_concurrency() says 256 there).
+int granted_cpus() {
+    cpu_set_t have;
+    CPU_ZERO(&have);
+    int n = sched_getaffinity(0, sizeof have, &have) == 0 ? CPU_COUNT(&have) : (int)std::max(1u, std::thread::hardware_concurrency());
+    auto read_pair = [](const char *path, long long *a, long long *b) -> bool {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return false;
+        char x[64] = {0}, y[64] = {0};
+        const int got = std::fscanf(f, "%63s %63s", x, y);
+        std::fclose(f);
+        if (got < 1 || std::strcmp(x, "max") == 0) return false;
+        *a = std::atoll(x);
+        *b = got == 2 ? std::atoll(y) : 0;
+        return true;
+    };
+    long long q = 0, per = 0;
+    if (read_pair("/sys/fs/cgroup/cpu.max", &q, &per) && q > 0 && per > 0) n = (int)std::min<long long>(n, std::max<long long>(1, q / per));
+    else if (read_pair("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q, &per) && q > 0) {
+        long long p2 = 0, dummy = 0;
+        if (read_pair("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &p2, &dummy) && p2 > 0) n = (int)std::min<long long>(n, std::max<long long>(1, q / p2));
+    }
+    return std::max(1, n);
+}
+
+void local_share(int *sharers, int *index) {
+    int n = g_sharers.load(), k = g_share_index.load();
+    if (n <= 0) {  // one process per GPU under torch.distributed.run: it exports both
+        const char *w = std::getenv("LOCAL_WORLD_SIZE"), *r = std::getenv("LOCAL_RANK");
+        n = w ? std::atoi(w) : 1;
+        k = r ? std::atoi(r) : 0;
+    }
+    if (n < 1) n = 1;
+    if (k < 0 || k >= n) k = 0;
+    *sharers = n;
+    *index = k;
+}
+
+int span_io_threads(const inq_call_args_t *args, int sharers) {
+    // -t counts the reference's calling workers; here the host only copies file bytes, which a few pread streams do best whatever -t
+    // says - bounded by this caller's SHARE of the cores the process was granted: eight ranks on one host must not start 8 x 32
+    // readers on the cores of one socket, and a container's quota is not the machine (hardware_concurrency())
+    int idx = 0;
+    if (sharers <= 0) local_share(&sharers, &idx);
+    const int share = std::max(2, granted_cpus() / std::max(1, sharers));
+    return (int)std::min<uint64_t>(std::max<uint64_t>(args->threads, 8), (uint64_t)std::min(share, 32));
 }
 
 SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamFile &bam, const std::vector<RepeatInterval> &targets,
-                                         AsyncCtx &actx, int slot_base, HostBufPool *pool) {
-    const char *pin_env = std::getenv("INQ_SPAN_PINNED");
+                                         AsyncCtx &actx, int slot_base, HostBufPool *pool, int sharers, int share_index) {
+    if (sharers <= 0) local_share(&sharers, &share_index);
+    bool pinned = false;
+    std::function<void()> gate;
+#ifdef INQ_DEBUG_ENV  // A/B switches of rounds 2 - 3, kept for experiments only: not in the shipped library
+    if (const char *pin_env = std::getenv("INQ_SPAN_PINNED")) pinned = pin_env[0] == '1';
+    if (std::getenv("INQ_GATE_READS")) gate = [&actx] { (void)actx.wait(); };
+#endif
     // the loader uploads every span it has read (waiting for the context the first time), so that the upload of span k+1
     // overlaps the inflate of span k
-    return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args), pin_env ? pin_env[0] == '1' : false,
+    return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args, sharers), pinned,
                             [&actx](const inq_span_t &sp, int slot) { return actx.wait_stage() && inq_span_stage_begin(actx.ctx, &sp, slot) == INQ_OK; },
-                            slot_base, pool, std::getenv("INQ_GATE_READS") ? std::function<void()>([&actx] { (void)actx.wait(); }) : std::function<void()>(),
+                            slot_base, pool, gate,
                             [&actx, dev = args->device]() -> int {
                                 if (const char *e = std::getenv("INQ_NUMA_NODE")) return std::atoi(e);
                                 return actx.ready.load() ? actx.numa_node : guess_gpu_numa_node(dev);
                             },
-                            args->device, [&actx] { (void)actx.wait(); }, [&actx](int slot) { return inq_span_stage_wait(actx.ctx, slot) == INQ_OK; });
+                            args->device, [&actx] { (void)actx.wait(); },
+                            [&actx](int slot) { return !actx.timed_out() && inq_span_stage_wait(actx.ctx, slot) == INQ_OK; }, share_index);
 }
 
 int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &actx, std::vector<double> &p1,
@@ -365,8 +449,9 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
             ~PipeHolder() {
                 if (owned && !leak) delete p;
             }
-        } holder{hooks.early_pipe ? hooks.early_pipe : start_span_pipeline(args, V.bam, V.targets, actx, hooks.slot_base, hooks.pool), leak_all,
-                 hooks.early_pipe == nullptr};
+        } holder{hooks.early_pipe ? hooks.early_pipe
+                                  : start_span_pipeline(args, V.bam, V.targets, actx, hooks.slot_base, hooks.pool, hooks.sharers, hooks.share_index),
+                 leak_all, hooks.early_pipe == nullptr};
         SpanPipeline &pipe = *holder.p;
         bool joined = false;
         // loci whose batches wait on the device (inq_call_span_deferred), in the order they were appended
@@ -429,7 +514,7 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
                 if (hrc == INQ_OK) (void)inq_ctx_set_option(ctx, "batch_loci_hint", (int64_t)std::min<size_t>(kFlushLoci, V.targets.size()));
             }
             if (hrc != INQ_OK) {
-                set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
+                set_err(errbuf, errcap, ctx_failure_message(actx));
                 return INQ_EXIT_ERROR;
             }
             inq_span_t sp;
@@ -475,6 +560,12 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
             int frc = flush();
             if (frc != INQ_EXIT_OK) return frc;
         }
+        if (hooks.stats && loop_spans) {
+            hooks.stats->spans = loop_spans, hooks.stats->comp_bytes = loop_comp_bytes;
+            hooks.stats->span_loop_s = secs(t_loop0, clk::now());
+            hooks.stats->wait_loader_s = *t_front, hooks.stats->device_calls_s = *t_dev;
+            hooks.stats->io_threads = pipe.io_threads();
+        }
         if (timing && loop_spans) {
             const double loop_s = secs(t_loop0, clk::now());
             std::fprintf(stderr, "[inq timing] span loop: %llu spans, %.1f MB compressed, %.4f s from the first span's call to the last flush = %.2f GB/s\n",
@@ -503,7 +594,7 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
     }
     if (timing) std::fprintf(stderr, "[inq timing] loader joined at %.3fs\n", secs(t_begin, clk::now()));
     if (hrc != INQ_OK) {  // no GPU is an error even for an empty target list
-        set_err(errbuf, errcap, std::string("cannot open HIP device: ") + inq_strerror(hrc));
+        set_err(errbuf, errcap, ctx_failure_message(actx));
         return INQ_EXIT_ERROR;
     }
     return INQ_EXIT_OK;

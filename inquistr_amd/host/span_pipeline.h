@@ -56,7 +56,7 @@ struct HostBufPool {
 // Device front end, host half: a loader thread plans the spans, reads their compressed bytes (parallel pread;
 // into pageable memory by default: pinning a few hundred MB costs more than the staged copy it saves,
 // INQ_SPAN_PINNED=1 switches) and builds block tables and anchors, two spans ahead
-// of the caller, who feeds inq_call_span().
+// of the caller, who feeds inq_call_span().  (INQ_SPAN_PINNED exists only in builds with -DINQ_DEBUG_ENV.)
 class SpanPipeline {
 public:
     // span buffers (and device staging slots) per file: one being read, one being uploaded, one being inflated / scanned, and one of
@@ -84,10 +84,10 @@ public:
     SpanPipeline(const std::string &bam_path, const BamFile &hdr, const std::vector<RepeatInterval> &targets,
                  uint64_t max_comp_bytes, int n_threads, bool pinned, StageFn stage = nullptr, int slot_base = 0, HostBufPool *pool = nullptr,
                  std::function<void()> gate = nullptr, std::function<int()> numa_query = nullptr, int device = 0,
-                 std::function<void()> runtime_gate = nullptr, WaitFn stage_wait = nullptr)
+                 std::function<void()> runtime_gate = nullptr, WaitFn stage_wait = nullptr, int io_group_offset = 0)
         : path_(bam_path), planner_(hdr, targets, max_comp_bytes), n_threads_(std::max(n_threads, 1)), pinned_(pinned),
           stage_(std::move(stage)), stage_wait_(std::move(stage_wait)), pool_(pool), gate_(std::move(gate)), gate_registered_(std::move(runtime_gate)),
-          numa_query_(std::move(numa_query)), device_(device) {
+          numa_query_(std::move(numa_query)), device_(device), io_group_offset_(io_group_offset) {
         for (int i = 0; i < kSlotsPerSet; ++i) slots_[i].slot = slot_base + i;
         int use = kSlotsPerSet;
         if (const char *e = std::getenv("INQ_SPAN_BUFFERS")) use = std::min(kSlotsPerSet, std::max(2, std::atoi(e)));  // A/B only
@@ -140,6 +140,7 @@ public:
         free_.push_back(it);
         cv_free_.notify_one();
     }
+    int io_threads() const { return n_threads_; }
 
 private:
     void release_buf(Item &it);
@@ -167,6 +168,7 @@ private:
     std::function<void()> gate_registered_;  // waits for the runtime before the first registration
     std::function<int()> numa_query_;  // the GPU's NUMA node, kNumaUnknown while the context is not there yet, -1 = do not place
     int device_ = 0;
+    int io_group_offset_ = 0;  // which L3 domain the first reader thread is bound to: sharers of one host start at different ones
     bool verbose_ = std::getenv("INQ_TIMING") && std::getenv("INQ_TIMING")[0] == '2';
     Item slots_[kSlotsPerSet];
     std::vector<Item *> free_;

@@ -73,7 +73,7 @@ std::vector<std::vector<int>> l3_groups(int node) {
 
 }  // namespace
 
-IoPool::IoPool(int n_threads, int numa_node, bool pin) {
+IoPool::IoPool(int n_threads, int numa_node, bool pin, int group_offset) {
     const int n = std::max(n_threads, 1);
     std::vector<std::vector<int>> groups;
     if (pin) groups = l3_groups(numa_node);
@@ -85,7 +85,7 @@ IoPool::IoPool(int n_threads, int numa_node, bool pin) {
     for (int i = 1; i < n; ++i) {
         workers_.emplace_back([this, i] { work(i); });
         if (!groups.empty()) {
-            const std::vector<int> &g = groups[(size_t)i % groups.size()];
+            const std::vector<int> &g = groups[((size_t)i + (size_t)std::max(group_offset, 0) * (size_t)n) % groups.size()];
             cpu_set_t set;
             CPU_ZERO(&set);
             for (int k : g) CPU_SET(k, &set);

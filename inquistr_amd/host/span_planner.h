@@ -96,7 +96,9 @@ struct SpanData {
 class IoPool {
 public:
     // numa_node < 0: every CPU this process may use; pin = false: plain threads (INQ_IO_PIN=0)
-    IoPool(int n_threads, int numa_node, bool pin);
+    // group_offset: thread i is bound to L3 domain (i + group_offset * n_threads) modulo their number, so that several pools on one
+    // host (one per rank / device part) start on different domains
+    IoPool(int n_threads, int numa_node, bool pin, int group_offset = 0);
     ~IoPool();
     IoPool(const IoPool &) = delete;
     // fn(k) for every k < n_jobs, on the pool's threads and the caller's; returns when all have run

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     L = hipcall.load()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.inq_abi_version() == 4
+    assert L.inq_abi_version() == 5
     assert b"no CPU fallback" in L.inq_strerror(B.INQ_ERR_NO_DEVICE)
 
 
@@ -40,6 +40,19 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(hipcall.InqError) as e:
         hipcall.Context(0)
     assert e.value.code == B.INQ_ERR_NO_DEVICE
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_list_form_fails_loudly_without_gpu_and_leaves_nothing_behind():
+    with pytest.raises(hipcall.InqError) as e:
+        hipcall.Context.create_multi([0, 1])
+    assert e.value.code == B.INQ_ERR_NO_DEVICE
+    L = hipcall.load()
+    import ctypes as C
+
+    hs = (C.c_void_p * 2)(1, 1)
+    assert L.inq_ctx_create_multi((C.c_int * 2)(0, 0), 2, hs) == B.INQ_ERR_NO_DEVICE and not hs[0] and not hs[1]
+    assert L.inq_ctx_create_multi(None, 2, hs) == B.INQ_ERR_ARG and L.inq_ctx_create_multi((C.c_int * 2)(0, 0), 0, hs) == B.INQ_ERR_ARG
 
 
 def test_struct_layout_matches_header():

@@ -505,3 +505,70 @@ def test_file_scale_rows_equal_the_cpu_program_whatever_the_span_size(tmp_path, 
         r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-500:]
         assert r.stdout == want.stdout, f"rows differ with {env}"
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+def test_native_devices_entry_on_one_gpu_equals_the_single_device_call(tmp_path, monkeypatch, devices):
+    """`inquistr call --devices 0,0[,0,0]` (inq_genotype_repeats_devices: ONE process, one thread + one device context per listed
+    device, no torch, no collective) over the multi-contig long-read-shaped file: the .inq equals the single-device CLI's byte for
+    byte, every part went through the device front end on about the same number of BAM bytes, and the parts' reader pools share the
+    granted cores."""
+    import re
+
+    from tools import make_synth_bam
+
+    monkeypatch.setattr(make_synth_bam, "LOCI_PER_CONTIG", 700)
+    monkeypatch.setattr(make_synth_bam, "CONTIG_LEN", 50_000 + 20_000 * 10_000 + 400_000)
+    prefix = str(tmp_path / "w")
+    n_loci = 3_000
+    make_synth_bam.write_native("unphased100k", n_loci, prefix, seq=True, level=6)
+    base = [call.CLI_PATH, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", "4", "--sample-name", "S", "-u"]
+    env = dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="1")
+    single = subprocess.run(base, capture_output=True, text=True, env=env)
+    assert single.returncode == 0, single.stderr
+    multi = subprocess.run(base + ["--devices", devices], capture_output=True, text=True, env=env, timeout=600)
+    assert multi.returncode == 0, multi.stderr[-2000:]
+    assert multi.stdout == single.stdout and multi.stdout.count("\n") == n_loci + 1
+    n = devices.count(",") + 1
+    parts = re.findall(r"\[inq part\] (\d+) of (\d+) on device 0: status 0, (\d+) loci, (\d+) spans, ([\d.]+) MB of BAM read by (\d+) reader threads", multi.stderr)
+    assert len(parts) == n and all(int(p[1]) == n for p in parts)
+    assert sum(int(p[2]) for p in parts) == n_loci
+    read = [float(p[4]) for p in parts]
+    mean = sum(read) / n
+    assert mean > 100 and all(abs(b - mean) <= 0.15 * mean for b in read), read
+    assert sum(read) * 1e6 < 1.1 * os.path.getsize(prefix + ".bam")
+    granted = call.load().inq_host_granted_cpus()
+    assert all(int(p[5]) == min(8, max(2, granted // n)) for p in parts), (parts, granted)
+
+
+def test_native_devices_entry_phased(tmp_path):
+    """Phased mode (the reference's default, src/main.rs:55) through the library entry with three parts on the one GPU - a small
+    multi-contig file with nested loci, an ultra-long read, contigs without reads - against the single-device call and the
+    plain-Python restatement."""
+    bam, bed, loci, recs = _make_case(tmp_path, 77, n_loci=60, ultra_long=True)
+    single = tmp_path / "single.inq"
+    with open(single, "w") as f:
+        call.genotype_repeats(bam, None, bed, 5, 3, 4, False, "S", out=f, frontend="device")
+    multi = tmp_path / "multi.inq"
+    with open(multi, "w") as f:
+        st = call.genotype_repeats_devices(bam, None, bed, [0, 0, 0], threads=4, sample_name="S", out=f, frontend="device")
+    assert multi.read_text() == single.read_text() == _expected_text(loci, recs, False, 5, 3, "S", 4)
+    assert len(st) == 3 and sum(s["loci"] for s in st) == len(loci) and all(s["status"] == 0 and s["front"] == 2 for s in st)
+
+
+def test_ctx_create_multi_on_one_gpu():
+    """inq_ctx_create_multi (SURVEY 8b's list form): three contexts on the one device, made concurrently, each usable on its own."""
+    from inquistr_amd import hipcall, synth
+
+    ctxs = hipcall.Context.create_multi([0, 0, 0])
+    try:
+        assert len(ctxs) == 3 and all("gfx950" in c.backend for c in ctxs)
+        b = synth.generate_numpy(synth.WORKLOADS["phased10k"], 0, 64)
+        rows = [c.call_batch(b)[1] for c in ctxs]
+        for r in rows[1:]:
+            assert np.array_equal(np.nan_to_num(r.phase1, nan=-1e300), np.nan_to_num(rows[0].phase1, nan=-1e300))
+    finally:
+        for c in ctxs:
+            c.close()
+    with pytest.raises(hipcall.InqError):
+        hipcall.Context.create_multi([0, 99])  # all or nothing: the good context is taken back
