@@ -619,6 +619,195 @@ def measured_read_peak():
             "what": "pure read of 2.4 GB, one wave per 24 KB segment, 16 B per lane, non-temporal (the hot kernel's shape), best of 10, measured in this run"}
 
 
+def _gpu_visible_count() -> int:
+    import torch
+
+    return torch.cuda.device_count()  # (counting devices does not initialise the runtime on this image)
+
+
+def l2_dist(args):
+    """`bench.py --gpus N --l2-dist`: the END-TO-END path at N ranks - inquistr_amd.call_dist (one process per GPU, loci cut by BAM
+    bytes, rows gathered to rank 0 over RCCL from device memory) over one SEQ-bearing BAM (the l2_seq_large shape: north_star's
+    100k-locus / 30x long-read file is --l2-dist-loci 100000), strong scaling.  One step = the whole file through all ranks
+    (BAM + BED -> .inq text on rank 0); barrier + device synchronise on both sides of the K timed steps, max over ranks.  The line
+    carries every rank's loci, BAM bytes, seconds (rows, gather, span loop GB/s, waiting for its loader, reader threads), the check
+    that the .inq is byte-identical to the single-process CLI's, CPU mode B on the same file, and the same file through the
+    one-process form (`inquistr call --devices ...`).  What eight links feed from ONE host's page cache is the question this mode
+    answers: `host` holds the predicted bound."""
+    import statistics
+    import tempfile
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from inquistr_amd import call as hostcall
+    from inquistr_amd import call_dist, synth
+    from tools import make_synth_bam
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and not (world == 1 and args.gpus == 1):
+        raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    backend = args.backend
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    wl = synth.WORKLOADS[args.workload]
+    threads = args.l2_threads or host_threads()
+    # ---- the file: written once by rank 0 (all its cores), kept when --l2-keep names a directory
+    tmp = args.l2_keep or (tempfile.mkdtemp(prefix="inq_l2dist_") if rank == 0 else None)
+    box = [tmp]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    tmp = box[0]
+    loci = min(args.l2_dist_loci, wl.n_loci)
+    prefix = os.path.join(tmp, f"{wl.name}_{loci}_seq{args.l2_level}")
+    gen_s = 0.0
+    if rank == 0:
+        os.makedirs(tmp, exist_ok=True)
+        if not os.path.exists(prefix + ".bam"):
+            t0 = time.perf_counter()
+            make_synth_bam.write_native(wl.name, loci, prefix, threads=host_cores_available(), device=dev, seq=True, level=args.l2_level)
+            gen_s = time.perf_counter() - t0
+        for _ in range(2):  # page cache warm = read TWICE (the second read of a fresh file is the slow one: DESIGN.md 4)
+            with open(prefix + ".bam", "rb", buffering=0) as f:
+                while f.read(64 << 20):
+                    pass
+    if world > 1:
+        dist.barrier()
+    bam_bytes = os.path.getsize(prefix + ".bam")
+    un = wl.unphased
+    out_path = os.path.join(tmp, f"dist_rank0_{world}.inq")
+
+    def one_pass(stats):
+        with open(out_path if rank == 0 else os.devnull, "w") as f:
+            call_dist.genotype_repeats_distributed(prefix + ".bam", None, prefix + ".bed", wl.minlen, wl.support, threads, un, "S", out=f,
+                                                   rank=rank, world=world, device=local_rank, frontend="device", stats=stats)
+
+    for _ in range(args.warmup):
+        one_pass({})
+    per_step = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = {}
+        one_pass(st)
+        per_step.append(st)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt_max = float(tt.item())
+
+    def med(key):
+        v = [s[key] for s in per_step if s.get(key) is not None]
+        return statistics.median(v) if v else None
+
+    mine = {"rank": rank, "device": local_rank, "loci": per_step[-1].get("loci"), "bam_bytes_read": per_step[-1].get("bam_bytes_this_call"),
+            "rows_s": med("rows_s"), "gather_s": med("gather_s"), "span_loop_s": med("span_loop_s"), "span_loop_GBps": med("span_loop_GBps"),
+            "wait_loader_s": med("wait_loader_s"), "device_calls_s": med("device_calls_s"), "io_threads": per_step[-1].get("io_threads"),
+            "granted_cpus": per_step[-1].get("granted_cpus"), "rows_in": per_step[-1].get("rows_in"), "front": per_step[-1].get("front")}
+    allr = [None] * world
+    if world > 1:
+        dist.all_gather_object(allr, mine)
+    else:
+        allr = [mine]
+    if rank == 0:
+        cli = os.path.join(ROOT, "inquistr_amd", "lib", "inquistr")
+        ref = os.path.join(ROOT, "oracle", "ref_shaped_call")
+        text = open(out_path, "rb").read()
+        line = {
+            "metric": "loci/sec genotyped (inquiSTR call, BAM + BED -> .inq end to end = L2, one process per GPU)",
+            "value": loci * args.steps / dt_max, "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/i64",
+            "data": "synthetic",
+            "config": {"workload": f"{wl.name}: {loci} loci x {wl.reads_per_locus} reads of long-read-shaped records (SEQ + QUAL + ML / MM, HP last), "
+                                   f"{bam_bytes / 1e9:.1f} GB of BAM at zlib level {args.l2_level}, " + ("--unphased" if un else "phased (HP)") +
+                                   f", inquistr_amd.call_dist at {world} rank(s), {backend} gather of 16 B per locus to rank 0",
+                       "loci": loci, "bam_bytes": bam_bytes, "threads_per_rank": threads, "same_device": bool(args.same_device),
+                       "bam_gen_s": gen_s},
+            "seconds_per_file": dt_max / args.steps,
+            "per_rank": allr,
+        }
+        reads = [r["bam_bytes_read"] or 0 for r in allr]
+        loop = [r["span_loop_s"] for r in allr if r.get("span_loop_s")]
+        line["bam_bytes_read_all_ranks"] = int(sum(reads))
+        line["bam_bytes_read_over_file"] = sum(reads) / bam_bytes
+        if loop:
+            agg = sum(reads) / 1e9 / max(loop)
+            line["pcie"] = {"bound": "pcie", "achieved": agg, "unit": "GB/s", "peak": PCIE_SPEC_GBS * (1 if args.same_device else world),
+                            "frac": agg / (PCIE_SPEC_GBS * (1 if args.same_device else world)),
+                            "what": "compressed bytes all ranks handed to their devices / the longest rank's span loop (median over the timed steps); "
+                                    "peak = one Gen5 x16 link per rank" + (" (ranks share ONE device and link here)" if args.same_device else "")}
+        # the host side of N links: what page-cache reads + DMA reads ask of the host's memory per second at the achieved rate
+        line["host"] = {"granted_cpus": allr[0].get("granted_cpus"), "reader_threads_per_rank": allr[0].get("io_threads"),
+                        "host_memory_traffic_GBps_at_achieved_rate": (3 * line["pcie"]["achieved"]) if loop else None,
+                        "what": "every compressed byte is read from the page cache and written to a span buffer by pread (2 x), then read by the "
+                                "device's DMA (1 x): 3 x the aggregate link rate is asked of the host's memory (DESIGN.md 5 prices it at N = 2 / 4 / 8)"}
+        # ---- byte-identical to the single-process run, and the one-process form on the same devices
+        un_flag = ["-u"] if un else []
+        base = [cli, "call", prefix + ".bam", "-R", prefix + ".bed", "-t", str(threads), "--sample-name", "S"] + un_flag
+        env = dict(os.environ, INQ_FRONTEND="device")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+            env.pop(k, None)
+        time.sleep(GPU_REST_S)
+        t = time.perf_counter()
+        r1 = subprocess.run(base, capture_output=True, env=env, timeout=900)
+        t_single = time.perf_counter() - t
+        line["single_process_cli"] = {"seconds": t_single, "rc": r1.returncode}
+        line["inq_identical_to_single_process"] = bool(r1.returncode == 0 and r1.stdout == text)
+        line["speedup_vs_single_process_cli"] = t_single / (dt_max / args.steps)
+        if not args.no_l2_dist_native:
+            devs = ",".join(str(0 if args.same_device else d) for d in range(world)) if world > 1 else (args.native_devices or "0")
+            if "," in devs:
+                ts, ok = [], True
+                for _ in range(max(1, args.steps)):
+                    time.sleep(GPU_REST_S)
+                    t = time.perf_counter()
+                    rn = subprocess.run(base + ["--devices", devs], capture_output=True, env=dict(env, INQ_TIMING="1"), timeout=900)
+                    ts.append(time.perf_counter() - t)
+                    ok = ok and rn.returncode == 0 and rn.stdout == text
+                parts = [ln for ln in rn.stderr.decode().splitlines() if ln.startswith("[inq part]")]
+                line["native_devices"] = {"devices": devs, "seconds_median": statistics.median(ts), "seconds_all": ts, "loci_per_s": loci / statistics.median(ts),
+                                          "inq_identical": bool(ok), "parts": parts,
+                                          "what": "`inquistr call --devices " + devs + "`: ONE process, one thread + one device context per device, rows scattered in host "
+                                                  "memory (no torch, no collective); whole process start to exit"}
+        if not args.no_cpu_baseline:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
+            cores = host_cores_available()
+            t = time.perf_counter()
+            rb = subprocess.run([ref, prefix + ".bam", prefix + ".bed", "B", str(cores), str(int(un)), str(wl.minlen), str(wl.support), "S"],
+                                capture_output=True, timeout=3000)
+            tb = time.perf_counter() - t
+            line["cpu_baseline"] = {"value": loci / tb, "unit": "loci/s", "cores": cores, "kind": "port", "seconds": tb,
+                                    "inq_identical": bool(rb.returncode == 0 and rb.stdout == text),
+                                    "sample": f"the whole file once: oracle/ref_shaped_call mode B (one reader per worker, own BGZF / BAM / BAI reader on zlib) on "
+                                              f"{cores} threads - a CPU restatement of the reference's control flow, not the Rust binary"}
+            line["speedup_vs_B"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+        if not args.l2_keep:
+            import shutil
+
+            shutil.rmtree(tmp, ignore_errors=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -653,7 +842,17 @@ def main():
     ap.add_argument("--l2-keep", default="", help="directory to keep / reuse the generated BAM in")
     ap.add_argument("--l2-cpu-modes", default="CBA", help="which CPU baseline modes to time (A is slow on large inputs)")
     ap.add_argument("--l2-seq", action="store_true", help="records carry SEQ / QUAL / MM / ML like a real long-read BAM (~30 KB each)")
+    ap.add_argument("--l2-dist", action="store_true",
+                    help="END-TO-END at N ranks: inquistr_amd.call_dist over one SEQ-bearing BAM, strong scaling (see l2_dist()); --steps = passes over the file")
+    ap.add_argument("--l2-dist-loci", type=int, default=20_000, help="loci of that BAM (0.32 GB per 1 000; north_star's configuration: 100000)")
+    ap.add_argument("--no-l2-dist-native", action="store_true", help="skip the one-process `inquistr call --devices` run of --l2-dist")
+    ap.add_argument("--native-devices", default="", help="--l2-dist at one rank: the device list of the one-process run (e.g. 0,0,0,0 on a one-GPU box)")
     args = ap.parse_args()
+    if args.l2_dist:
+        if args.steps == 30 and args.warmup == 5:  # the defaults are the L0 loop's: a step here is a whole file
+            args.steps, args.warmup = 3, 1
+        l2_dist(args)
+        return
     if args.l2:
         print(json.dumps(l2_end_to_end(args.workload, args.l2_loci, args.l2_threads or host_threads(), 2, args.l2_keep, args.l2_cpu_modes, args.l2_seq)), flush=True)
         return

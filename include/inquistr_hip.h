@@ -311,6 +311,18 @@ int inq_call_span_staged(inq_ctx_t *ctx, const inq_span_t *span, int slot, inq_r
  * share a launch is not observable in the rows. */
 int inq_call_span_deferred(inq_ctx_t *ctx, const inq_span_t *span, int slot /* -1: not staged */, inq_span_stats_t *stats);
 int inq_call_flush(inq_ctx_t *ctx, inq_result_t *result, uint64_t n_loci, double *ms_call);
+/* inq_call_flush with the rows left ON THE DEVICE: row j of the flush goes to d_phase1[index[j]], d_phase2[index[j]] (DEVICE arrays of
+ * `cap` entries on the ctx's device; index: HOST, n_loci entries, every one < cap), only the tie count and the status come back.  For a
+ * caller whose rows travel on from device memory - one process per GPU: the RCCL gather of the per-shard rows to rank 0 (north_star;
+ * inquistr_amd/call_dist.py) reads them where the kernels' rows already are. */
+int inq_call_flush_device(inq_ctx_t *ctx, double *d_phase1, double *d_phase2, uint64_t cap, const uint32_t *index, uint64_t n_loci,
+                          uint64_t *n_tie_loci, double *ms_call);
+/* Row arrays in device memory for a host that does not link the HIP runtime itself: n f64, filled with quiet NaN (a locus no span
+ * holds prints NaN NaN); plain synchronous copies in and out. */
+int inq_dev_alloc_rows(inq_ctx_t *ctx, uint64_t n, double **out);
+void inq_dev_free_rows(inq_ctx_t *ctx, double *p);
+int inq_dev_write_rows(inq_ctx_t *ctx, double *dst_device, const double *src_host, uint64_t n);
+int inq_dev_read_rows(inq_ctx_t *ctx, double *dst_host, const double *src_device, uint64_t n);
 uint64_t inq_call_deferred_loci(const inq_ctx_t *ctx); /* loci appended since the last flush */
 void inq_call_discard(inq_ctx_t *ctx); /* forgets what was appended (a run that failed between two flushes; a flush, failed or not, does it too) */
 

@@ -92,6 +92,9 @@ int inq_genotype_repeats_devices(const inq_call_args_t *args, const int32_t *dev
  * reader pool of every later call (granted cores / sharers, bound to L3 domains from a different start per sharer).  Default:
  * LOCAL_WORLD_SIZE / LOCAL_RANK of the environment (torch.distributed.run exports them), else 1 / 0.  sharers <= 0 = that default. */
 void inq_host_set_local_share(int sharers, int index);
+/* what the last call that ended in this process did (spans, BAM bytes, span loop / loader / device seconds, front end, reader
+ * threads; device, status, loci and rows_s are not filled): a rank of the one-process-per-GPU run reports it next to its rows */
+void inq_host_last_call_stats(inq_part_stats_t *out);
 int inq_host_granted_cpus(void); /* CPUs of the affinity mask, cut by the cgroup's CPU quota */
 int inq_host_span_io_threads(uint64_t threads, int sharers); /* the reader pool size a call with -t threads would take */
 /* tests (no GPU involved): the control flow of inq_genotype_repeats_devices with rows that name their target and their part; a device
@@ -112,6 +115,14 @@ int inq_run_target(const inq_run_t *run, uint64_t i, const char **chrom, uint32_
 int inq_run_partition(inq_run_t *run, uint64_t world, uint32_t *order, uint64_t *cuts, char *errbuf, size_t errcap);
 /* as inq_genotype_repeats_rows (runs on the GPU) */
 int inq_run_rows(inq_run_t *run, const uint32_t *target_index, uint64_t n_index, double *phase1, double *phase2, char *errbuf, size_t errcap);
+/* as inq_run_rows, with the rows left in DEVICE memory: *d_phase1 / *d_phase2 receive arrays of `width` >= n_index f64 on args->device
+ * (row k = target target_index[k]; entries from n_index on are NaN; the two lie back to back: *d_phase2 = *d_phase1 + width, one
+ * [2][width] buffer), owned by the run and valid until the next call on it or
+ * inq_run_close.  For one process per GPU, whose RCCL gather of the per-shard rows (north_star) then reads them where the kernels'
+ * rows already are - `width` = the largest part of the work split, so that every rank's buffer has the collective's one shape.  The
+ * run keeps its device context from the first such call on. */
+int inq_run_rows_device(inq_run_t *run, const uint32_t *target_index, uint64_t n_index, uint64_t width, void **d_phase1, void **d_phase2,
+                        char *errbuf, size_t errcap);
 /* header + one row per target (phase1[i], phase2[i] = row of target i of the list; n_rows must equal inq_run_n_targets) to
  * out_fd: BED order for -t 1, (human_compare(chrom), start) order for -t >= 2 (src/call.rs:33-38,141).  No GPU involved. */
 int inq_run_write_inq(inq_run_t *run, const double *phase1, const double *phase2, uint64_t n_rows, int out_fd, char *errbuf, size_t errcap);

@@ -26,6 +26,7 @@ HOST_ABI_SYMBOLS = (
     "inq_genotype_repeats_devices",
     "inq_host_set_local_share",
     "inq_host_granted_cpus",
+    "inq_host_last_call_stats",
     "inq_host_span_io_threads",
     "inq_host_devices_selftest",
     "inq_host_test_ctx_creator",
@@ -36,6 +37,7 @@ HOST_ABI_SYMBOLS = (
     "inq_run_target",
     "inq_run_partition",
     "inq_run_rows",
+    "inq_run_rows_device",
     "inq_run_write_inq",
     "inq_run_close",
     "inq_session_open",
@@ -147,6 +149,8 @@ def load():
         L.inq_genotype_repeats_devices.argtypes = [C.POINTER(CallArgsC), C.POINTER(C.c_int32), C.c_size_t, C.c_int, C.POINTER(PartStatsC), C.c_char_p, C.c_size_t]
         L.inq_host_set_local_share.restype = None
         L.inq_host_set_local_share.argtypes = [C.c_int, C.c_int]
+        L.inq_host_last_call_stats.restype = None
+        L.inq_host_last_call_stats.argtypes = [C.POINTER(PartStatsC)]
         L.inq_host_granted_cpus.restype = C.c_int
         L.inq_host_granted_cpus.argtypes = []
         L.inq_host_span_io_threads.restype = C.c_int
@@ -169,6 +173,8 @@ def load():
         L.inq_run_partition.argtypes = [vp, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
         L.inq_run_rows.restype = C.c_int
         L.inq_run_rows.argtypes = [vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.inq_run_rows_device.restype = C.c_int
+        L.inq_run_rows_device.argtypes = [vp, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.c_char_p, C.c_size_t]
         L.inq_run_write_inq.restype = C.c_int
         L.inq_run_write_inq.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_char_p, C.c_size_t]
         L.inq_run_close.restype = None
@@ -293,6 +299,13 @@ def genotype_repeats_devices(bamp: str, region: Optional[str], region_file: Opti
     return [{f: getattr(x, f) for f, _ in PartStatsC._fields_} for x in st]
 
 
+def last_call_stats() -> dict:
+    """inq_host_last_call_stats: spans, BAM bytes, span-loop / loader / device seconds, front end, reader threads of the last call."""
+    st = PartStatsC()
+    load().inq_host_last_call_stats(C.byref(st))
+    return {f: getattr(st, f) for f in ("spans", "bam_bytes_read", "span_loop_s", "wait_loader_s", "device_calls_s", "front", "io_threads")}
+
+
 def devices_selftest(bamp: str, region: Optional[str], region_file: Optional[str], n_parts: int, out, threads: int = 1, fail_part: int = -1):
     """inq_host_devices_selftest (no GPU): partition, one thread per part, scatter and ordered text of the multi-device entry with
     rows phase1 = position of the target in the list, phase2 = the part that called it.  Returns the cut points."""
@@ -383,6 +396,17 @@ class Run:
         if rc != 0:
             raise CallError(rc, err.value.decode(errors="replace"))
         return p1, p2
+
+    def rows_device(self, target_index, width: int):
+        """inq_run_rows_device: the rows left in device memory - two device addresses of `width` f64 each (row k = target
+        target_index[k], NaN behind the last), owned by the run and valid until its next call or close()."""
+        idx = np.ascontiguousarray(target_index, dtype=np.uint32)
+        d1, d2 = C.c_void_p(), C.c_void_p()
+        err = C.create_string_buffer(2048)
+        rc = self._L.inq_run_rows_device(self._h, idx.ctypes.data, len(idx), int(width), C.byref(d1), C.byref(d2), err, len(err))
+        if rc != 0:
+            raise CallError(rc, err.value.decode(errors="replace"))
+        return int(d1.value), int(d2.value)
 
     def write_inq(self, phase1, phase2, out=None) -> None:
         """The output stage (src/call.rs:137-157) on rows in target-list order: one C call, whatever the row count."""

@@ -9,6 +9,12 @@ Each rank runs the C++ driver on its own contiguous slice of the (contig, start)
 only the part of the BAM that slice needs and inflates, scans and calls it on its own GPU (device front
 end), or sweeps it on the host for small inputs; the reference's counterpart is the
 rayon loop over loci (src/call.rs:115-136), which shares nothing but the output Vec.
+
+Where the rows are gathered from: on `nccl` (= RCCL) every rank's rows STAY in device memory (inq_run_rows_device:
+each flush of the locus kernels scatters its rows into the rank's [2][width] device buffer) and the one collective
+reads them there - no host -> device copy to satisfy the backend; rank 0 copies the gathered block down once.  On
+`gloo` (CPU rehearsal) the rows come back as host arrays and are gathered as they are.  The one-process form
+(`inquistr call --devices 0,1,...`, host/multi_device.cc) needs neither: its gather is a scatter in host memory.
 """
 from __future__ import annotations
 
@@ -21,6 +27,13 @@ from typing import Callable, List, Optional
 import numpy as np
 
 from . import call as hostcall
+
+
+class _DeviceArray:
+    """A device allocation of the C++ library as something torch.as_tensor wraps without copying."""
+
+    def __init__(self, ptr: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
 def _exchange_status(status: int, message: str, rank: int, world: int, group=None):
@@ -43,9 +56,10 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
                                  support: int = 3, threads: int = 1, unphased: bool = False,
                                  sample_name: Optional[str] = None, out=None, rank: int = 0, world: int = 1,
                                  device: int = 0, compute: Optional[Callable] = None, group=None,
-                                 frontend: Optional[str] = None, stats: Optional[dict] = None) -> None:
+                                 frontend: Optional[str] = None, stats: Optional[dict] = None, rows: Optional[str] = None) -> None:
     """Same arguments as call.genotype_repeats plus (rank, world).  Rank 0 writes header + rows.
-    Raises CallError (same status on every rank) if any rank fails.  stats (rank 0): seconds of the output stage."""
+    Raises CallError (same status on every rank) if any rank fails.  stats (rank 0): seconds of the output stage.
+    rows: "device" / "host" = where this rank's rows wait for the gather; None = device memory when the backend is nccl."""
     import torch
     import torch.distributed as dist
 
@@ -73,15 +87,29 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
     n = len(order)
     lo, hi = int(cuts[rank]), int(cuts[rank + 1])
     mine = order[lo:hi]
+    width = max(max(int(cuts[r + 1] - cuts[r]) for r in range(world)), 1)
+    if rows not in (None, "device", "host"):
+        raise ValueError("rows: 'device', 'host' or None")
+    # rows stay in device memory for the RCCL gather (world 1 + rows="device": the same path without a collective, for tests)
+    on_device = compute is None and (rows == "device" or (rows is None and world > 1 and dist.get_backend(group) == "nccl"))
+    if on_device and world > 1 and dist.get_backend(group) != "nccl":
+        raise ValueError("rows='device' needs the nccl backend")
     # ---- this rank's rows
     import time
 
     t_rows = time.perf_counter()
     p1 = np.full(len(mine), np.nan)
     p2 = np.full(len(mine), np.nan)
+    dev_buf = None
     st, msg = 0, ""
     try:
-        if len(mine) and compute is None:
+        if compute is None and on_device:
+            # every rank keeps an opened run: its device context and the device row buffer live in it until the gather is over
+            if run is None:
+                run = hostcall.Run(bamp, region, region_file, minlen, support, threads, unphased, sample_name, device=device, frontend=frontend)
+            d1, _d2 = run.rows_device(mine, width)
+            dev_buf = torch.as_tensor(_DeviceArray(d1, (2, width)), device=torch.device("cuda", device))
+        elif len(mine) and compute is None:
             # the product path: the C++ driver on this rank's share (inq_genotype_repeats_rows), which picks the device front end
             # (inflate + record scan + join on this rank's GPU) or the host sweep by the amount of BAM; rows come back as f64
             if run is not None:
@@ -113,34 +141,53 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
     if stats is not None:  # every rank: its share, its time, the BAM bytes its device front end was handed
         stats["rank"], stats["world"], stats["loci"] = rank, world, len(mine)
         stats["rows_s"] = time.perf_counter() - t_rows
+        stats["rows_in"] = "device memory" if on_device else "host memory"
         try:
-            stats["bam_bytes_read"] = int(hostcall.load().inq_host_span_bytes_read())
+            L = hostcall.load()
+            stats["bam_bytes_read"] = int(L.inq_host_span_bytes_read())
+            stats["granted_cpus"] = int(L.inq_host_granted_cpus())
+            last = hostcall.last_call_stats()  # this rank's call: its span loop, its loader waits, its reader pool
+            stats.update({k: last[k] for k in ("spans", "span_loop_s", "wait_loader_s", "device_calls_s", "io_threads")})
+            stats["front"] = {1: "host", 2: "device"}.get(last["front"], "-")
+            stats["bam_bytes_this_call"] = int(last["bam_bytes_read"])
+            stats["span_loop_GBps"] = last["bam_bytes_read"] / 1e9 / last["span_loop_s"] if last["span_loop_s"] > 0 else None
         except Exception:  # noqa: BLE001
             stats["bam_bytes_read"] = None
     st, msg, bad_rank = _exchange_status(st, msg, rank, world, group)
     if st != 0:
+        if run is not None and rank != 0:
+            run.close()
         raise hostcall.CallError(st, f"rank {bad_rank}: {msg}" if world > 1 else msg)
     # ---- the one exchange of the path: 2 x f64 per locus to rank 0
     if world > 1:
-        width = max(int(cuts[r + 1] - cuts[r]) for r in range(world))
-        gdev = torch.device("cuda", device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        buf = torch.full((2, max(width, 1)), float("nan"), dtype=torch.float64, device=gdev)
-        buf[0, : len(mine)] = torch.from_numpy(p1)
-        buf[1, : len(mine)] = torch.from_numpy(p2)
+        if on_device:
+            buf = dev_buf  # [2][width] in this rank's device memory, written by its flushes
+        else:
+            buf = torch.full((2, width), float("nan"), dtype=torch.float64)
+            buf[0, : len(mine)] = torch.from_numpy(p1)
+            buf[1, : len(mine)] = torch.from_numpy(p2)
         bufs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
         t_g = time.perf_counter()
         dist.gather(buf, bufs, dst=0, group=group)
+        if on_device:
+            torch.cuda.synchronize(device)  # (the collective is enqueued; the run's buffer must outlive it)
         if stats is not None:
             stats["gather_s"] = time.perf_counter() - t_g  # exposed: nothing overlaps it in a one-file call (16 B per locus)
         if rank != 0:
+            if run is not None:
+                run.close()
             return
         full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
+        got = torch.stack(bufs).cpu().numpy() if on_device else [b.numpy() for b in bufs]  # rank 0: ONE copy down
         for r in range(world):
             sl = order[int(cuts[r]) : int(cuts[r + 1])]
-            full1[sl] = bufs[r][0, : len(sl)].cpu().numpy()
-            full2[sl] = bufs[r][1, : len(sl)].cpu().numpy()
+            full1[sl] = got[r][0, : len(sl)]
+            full2[sl] = got[r][1, : len(sl)]
     else:
         full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
+        if on_device:
+            got = dev_buf.cpu().numpy()
+            p1, p2 = got[0, : len(mine)], got[1, : len(mine)]
         full1[mine], full2[mine] = p1, p2
     # ---- output (rank 0), src/call.rs:137-157: BED order for -t 1, (human chrom, start) order otherwise.  One call into the
     # host library on the f64 arrays (the code inq_genotype_repeats itself ends with): 500 000 rows take tens of milliseconds
@@ -167,6 +214,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-device", action="store_true", help="all ranks on device 0 (rehearsal on a one-GPU box)")
     ap.add_argument("--frontend", default=None, choices=["host", "device"], help="default: by the amount of BAM each rank reads")
+    ap.add_argument("--rows", default=None, choices=["device", "host"], help="where a rank's rows wait for the gather (default: device memory on nccl)")
     ap.add_argument("--stats-dir", default=None, help="every rank leaves rank<r>.json there: its loci, seconds, BAM bytes read, the gather's time")
     a = ap.parse_args(argv)
     import torch
@@ -186,7 +234,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     stats = {} if a.stats_dir else None
     try:
         genotype_repeats_distributed(a.bam, a.region, a.region_file, a.minlen, a.support, a.threads, a.unphased,
-                                     a.sample_name, out=out, rank=rank, world=world, device=device, frontend=a.frontend, stats=stats)
+                                     a.sample_name, out=out, rank=rank, world=world, device=device, frontend=a.frontend, stats=stats, rows=a.rows)
         if stats is not None:
             import json
 

@@ -542,6 +542,26 @@ void launch_offset_copy(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t
     hipLaunchKernelGGL(offset_copy_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dst, src, n, base);
 }
 
+// rows of a flush to their places in a run's device-resident row arrays (inq_call_flush_device)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const double *p1, const double *p2, const uint32_t *index, double *d1, double *d2, uint64_t n, uint64_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = index[i];
+    if ((uint64_t)k < cap) d1[k] = p1[i], d2[k] = p2[i];  // (the host checked every index against cap)
+}
+void launch_scatter_rows(const double *p1, const double *p2, const uint32_t *index, double *d1, double *d2, uint64_t n, uint64_t cap, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, p1, p2, index, d1, d2, n, cap);
+}
+__global__ __launch_bounds__(256) void fill_f64_kernel(double *p, uint64_t n, double v) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_f64(double *p, uint64_t n, double v, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(fill_f64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}
+
 void launch_scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *tmp, hipStream_t s) {
     run_scan<SumOp, LoadU32, true>(LoadU32{in}, out, n, tmp, s);
 }

@@ -95,6 +95,10 @@ void launch_join_fill(const ScanArgs &a, uint64_t n_valid, hipStream_t s);
 // dst[i] = src[i] + base, i < n (the CSR offsets of an appended span)
 void launch_offset_copy(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t s);
 
+// d1[index[i]] = p1[i], d2[index[i]] = p2[i] for i < n (index[i] < cap); p[i] = v
+void launch_scatter_rows(const double *p1, const double *p2, const uint32_t *index, double *d1, double *d2, uint64_t n, uint64_t cap, hipStream_t s);
+void launch_fill_f64(double *p, uint64_t n, double v, hipStream_t s);
+
 // exclusive prefix sums (out[n] = total) and the running maximum; `tmp` holds ceil(n / 4096) + 1 u64
 void launch_scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *tmp, hipStream_t s);
 // CIGAR sizes: units(i) = ceil(n_cigar / 4) for i < *n_valid, else 0

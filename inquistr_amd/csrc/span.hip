@@ -572,7 +572,13 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
 }
 
 // The locus kernels over everything inq_call_span_deferred appended; rows in the order the loci were appended.
-int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_call) {
+// dev: the rows stay on the device - row j of the flush goes to dev->d1[dev->index[j]], dev->d2[...] - and r only receives the tie count
+struct FlushToDevice {
+    double *d1, *d2;
+    const uint32_t *index;  // HOST, n_loci entries
+    uint64_t cap;           // entries of d1 / d2
+};
+int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_call, const FlushToDevice *dev = nullptr) {
     if (!c || !r) return INQ_ERR_ARG;
     SpanState *S;
     int rc;
@@ -585,7 +591,12 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
         A = SpanState::Acc{A.cigar, A.reads, A.pair_read, A.off, A.lstart, A.lend};
         return INQ_OK;
     }
-    if (!r->phase1 || !r->phase2) return INQ_ERR_ARG;
+    if (!dev && (!r->phase1 || !r->phase2)) return INQ_ERR_ARG;
+    if (dev) {
+        if (!dev->d1 || !dev->d2 || !dev->index) return INQ_ERR_ARG;
+        for (uint64_t j = 0; j < n_loci; ++j)
+            if ((uint64_t)dev->index[j] >= dev->cap) return INQ_ERR_ARG;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint64_t nl = A.n_loci;
@@ -645,14 +656,24 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
         HIP_TRY(c, hipEventSynchronize(S->ev_warm));
         S->warm_pending = false;
     }
-    HIP_TRY(c, hipMemcpyAsync(S->h_rows, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(S->h_rows + nl, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
+    if (dev) {  // the rows' places go up (4 B per locus, through the page-locked row staging), the rows stay where they are
+        if ((rc = ensure(c, S->tmp, std::max<size_t>(nl * 4, 64))) != INQ_OK) return rc;
+        std::memcpy(S->h_rows, dev->index, nl * 4);
+        HIP_TRY(c, hipMemcpyAsync(S->tmp.p, S->h_rows, nl * 4, hipMemcpyHostToDevice, s));
+        launch_scatter_rows(dr.phase1, dr.phase2, (const uint32_t *)S->tmp.p, dev->d1, dev->d2, nl, dev->cap, s);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(S->h_rows, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(S->h_rows + nl, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(c, hipMemcpyAsync(&S->h->ks, c->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemsetAsync(&c->d_status->err, 0, sizeof(unsigned int), s));
     HIP_TRY(c, hipMemsetAsync(&c->d_status->ties, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    std::memcpy(r->phase1, S->h_rows, nl * 8);
-    std::memcpy(r->phase2, S->h_rows + nl, nl * 8);
+    if (!dev) {
+        std::memcpy(r->phase1, S->h_rows, nl * 8);
+        std::memcpy(r->phase2, S->h_rows + nl, nl * 8);
+    }
     {
         bool much;
         {
@@ -868,6 +889,55 @@ int inq_call_flush(inq_ctx_t *c, inq_result_t *result, uint64_t n_loci, double *
     } catch (...) {
         return INQ_ERR_HIP;
     }
+}
+
+int inq_call_flush_device(inq_ctx_t *c, double *d_phase1, double *d_phase2, uint64_t cap, const uint32_t *index, uint64_t n_loci, uint64_t *n_tie_loci,
+                          double *ms_call) {
+    try {
+        inq_result_t r;
+        std::memset(&r, 0, sizeof r);
+        const FlushToDevice dev{d_phase1, d_phase2, index, cap};
+        const int rc = call_flush_impl(c, &r, n_loci, ms_call, &dev);
+        if (n_tie_loci) *n_tie_loci = r.n_tie_loci;
+        return rc;
+    } catch (const std::bad_alloc &) {
+        return INQ_ERR_NOMEM;
+    } catch (...) {
+        return INQ_ERR_HIP;
+    }
+}
+
+// device memory for a caller that does not link the runtime itself (the host library's device-resident row arrays)
+int inq_dev_alloc_rows(inq_ctx_t *c, uint64_t n, double **out) {
+    if (!c || !out) return INQ_ERR_ARG;
+    *out = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, std::max<size_t>((size_t)n * 8, 64)));
+    launch_fill_f64((double *)p, n, __builtin_nan(""), c->stream);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(p);
+        return INQ_ERR_HIP;
+    }
+    *out = (double *)p;
+    return INQ_OK;
+}
+void inq_dev_free_rows(inq_ctx_t *c, double *p) {
+    if (!c || !p) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(p);
+}
+int inq_dev_write_rows(inq_ctx_t *c, double *dst, const double *src_host, uint64_t n) {
+    if (!c || (n && (!dst || !src_host))) return INQ_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n) HIP_TRY(c, hipMemcpy(dst, src_host, (size_t)n * 8, hipMemcpyHostToDevice));
+    return INQ_OK;
+}
+int inq_dev_read_rows(inq_ctx_t *c, double *dst_host, const double *src, uint64_t n) {
+    if (!c || (n && (!dst_host || !src))) return INQ_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n) HIP_TRY(c, hipMemcpy(dst_host, src, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return INQ_OK;
 }
 
 uint64_t inq_call_deferred_loci(const inq_ctx_t *c) { return c && c->span ? c->span->acc.n_loci : 0; }

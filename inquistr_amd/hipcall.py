@@ -58,6 +58,11 @@ ABI_SYMBOLS = (
     "inq_call_span_staged",
     "inq_call_span_deferred",
     "inq_call_flush",
+    "inq_call_flush_device",
+    "inq_dev_alloc_rows",
+    "inq_dev_free_rows",
+    "inq_dev_write_rows",
+    "inq_dev_read_rows",
     "inq_call_deferred_loci",
     "inq_call_discard",
     "inq_span_fetch_batch",

@@ -204,6 +204,9 @@ struct PartStats {
     int io_threads = 0;
 };
 
+void publish_last_stats(const PartStats &s);
+PartStats last_stats();  // of the last call that ended in this process (any thread)
+
 // what one call works on: the opened BAM (header + index), the targets it was asked for, the options
 struct CallView {
     BamFile &bam;
@@ -222,14 +225,19 @@ struct SessionHooks {
     int front = 0;  // 0 = decide here, 1 = host sweep, 2 = device spans (decided when the pipeline was started)
     int sharers = 0, share_index = 0;  // > 0: this call is one of `sharers` device parts of one process (else: local_share())
     PartStats *stats = nullptr;        // may be null
+    // rows stay on the device (inq_run_rows_device): row of target k of the call -> dev_p1[k], dev_p2[k]
+    double *dev_p1 = nullptr, *dev_p2 = nullptr;
+    uint64_t dev_cap = 0;
 };
 
 // rows instead of text: the targets named by idx[] (positions in the parsed target list) are called, their rows go to p1 / p2
 struct RowsOut {
     const uint32_t *idx = nullptr;
     uint64_t n = 0;
-    double *p1 = nullptr, *p2 = nullptr;
+    double *p1 = nullptr, *p2 = nullptr;  // host arrays (null when the rows stay on the device)
     bool active = false;
+    double *d1 = nullptr, *d2 = nullptr;  // DEVICE arrays of dcap entries on the call's device: the rows are left there
+    uint64_t dcap = 0;
 };
 
 bool use_device_front(const inq_call_args_t *args, const BamFile &bam, const std::vector<RepeatInterval> &targets);

@@ -172,6 +172,15 @@ int inq_host_devices_selftest(const inq_call_args_t *args, size_t n_parts, int f
     INQ_GUARD(devices_selftest_impl(args, n_parts, fail_part, out_fd, cuts, errbuf, errcap), errbuf, errcap)
 }
 
+void inq_host_last_call_stats(inq_part_stats_t *out) {
+    if (!out) return;
+    const PartStats s = last_stats();
+    std::memset(out, 0, sizeof *out);
+    out->device = -1;
+    out->spans = s.spans, out->bam_bytes_read = s.comp_bytes;
+    out->span_loop_s = s.span_loop_s, out->wait_loader_s = s.wait_loader_s, out->device_calls_s = s.device_calls_s;
+    out->front = s.front, out->io_threads = s.io_threads;
+}
 void inq_host_set_local_share(int sharers, int index) { set_local_share(sharers, index); }
 int inq_host_granted_cpus(void) { return granted_cpus(); }
 int inq_host_span_io_threads(uint64_t threads, int sharers) {

@@ -121,18 +121,34 @@ int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepared &P, 
                      (uint32_t)std::min<uint64_t>(args->support, 0xffffffffull), args->unphased != 0};
     const size_t n = V.targets.size();
     std::vector<double> p1(n, NAN), p2(n, NAN);
+    const bool rows_on_device = rows.active && rows.d1 && rows.d2;
+    if (rows_on_device && rows.dcap < n) {
+        set_err(errbuf, errcap, "device row arrays smaller than the target list");
+        return INQ_EXIT_ERROR;
+    }
     auto emit = [&]() -> int {
         if (!rows.active) return write_rows(args->threads, V.targets, V.sample, p1.data(), p2.data(), out_fd, errbuf, errcap);
+        if (rows_on_device) return INQ_EXIT_OK;  // (device front end: they are there; host sweep: written below)
         if (n) std::memcpy(rows.p1, p1.data(), n * sizeof(double)), std::memcpy(rows.p2, p2.data(), n * sizeof(double));
         return INQ_EXIT_OK;
     };
 
     const auto t_open = clk::now();
     const bool device_front = hooks.front ? hooks.front == 2 : use_device_front(args, V.bam, V.targets);
-    if (hooks.stats) hooks.stats->front = device_front ? 2 : 1;
+    // what the call did, for whoever asks afterwards (a device part's inq_part_stats_t, inq_host_last_call_stats)
+    PartStats local_stats;
+    PartStats *ps = hooks.stats ? hooks.stats : &local_stats;
+    struct Publish {
+        PartStats *p;
+        ~Publish() { publish_last_stats(*p); }
+    } publish{ps};
+    ps->front = device_front ? 2 : 1;
     if (device_front) {
         const auto t_choice = clk::now();
-        int drc = run_device_front(args, V, actx, p1, p2, errbuf, errcap, &t_front, &t_dev, hooks);
+        SessionHooks dh = hooks;
+        dh.stats = ps;
+        if (rows_on_device) dh.dev_p1 = rows.d1, dh.dev_p2 = rows.d2, dh.dev_cap = rows.dcap;
+        int drc = run_device_front(args, V, actx, p1, p2, errbuf, errcap, &t_front, &t_dev, dh);
         if (drc != INQ_EXIT_OK) return drc;
         const auto t_run = clk::now();
         drc = emit();
@@ -248,6 +264,12 @@ int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepared &P, 
         pfe.recycle(std::move(item));
     }
     if (!need_ctx()) return INQ_EXIT_ERROR;  // no GPU is an error even for an empty target list
+    if (rows_on_device && n) {  // the sweep's rows came back batch by batch (small inputs): one copy up
+        if (inq_dev_write_rows(ctx, rows.d1, p1.data(), n) != INQ_OK || inq_dev_write_rows(ctx, rows.d2, p2.data(), n) != INQ_OK) {
+            set_err(errbuf, errcap, std::string("device call failed: ") + inq_last_error(ctx));
+            return INQ_EXIT_ERROR;
+        }
+    }
 
     {
         int wrc = emit();
@@ -263,6 +285,17 @@ int genotype_prepared(const inq_call_args_t *args, AsyncCtx &actx, Prepared &P, 
     return INQ_EXIT_OK;
 }
 
+
+static std::mutex g_last_mu;
+static PartStats g_last_stats;
+void publish_last_stats(const PartStats &s) {
+    std::lock_guard<std::mutex> g(g_last_mu);
+    g_last_stats = s;
+}
+PartStats last_stats() {
+    std::lock_guard<std::mutex> g(g_last_mu);
+    return g_last_stats;
+}
 
 int write_rows(uint64_t threads, const std::vector<RepeatInterval> &targets, const std::string &sample, const double *p1,
                       const double *p2, int out_fd, char *errbuf, size_t errcap) {
@@ -597,6 +630,13 @@ int inq_host_partition(const inq_call_args_t *args, uint64_t world, uint32_t *or
 struct inq_run {
     std::unique_ptr<OwnedArgs> args;
     Prepared P;
+    // inq_run_rows_device: the context outlives the call (its rows are read from device memory afterwards)
+    std::unique_ptr<AsyncCtx> actx;
+    double *d1 = nullptr, *d2 = nullptr;
+    uint64_t dcap = 0;
+    ~inq_run() {
+        if (actx && actx->wait()) inq_dev_free_rows(actx->ctx, d1);  // (d2 points into the same allocation)
+    }
 };
 
 static int inq_run_open_impl(const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap) {
@@ -647,6 +687,45 @@ static int inq_run_rows_impl(inq_run_t *r, const uint32_t *target_index, uint64_
 }
 int inq_run_rows(inq_run_t *r, const uint32_t *target_index, uint64_t n_index, double *phase1, double *phase2, char *errbuf, size_t errcap) {
     INQ_GUARD(inq_run_rows_impl(r, target_index, n_index, phase1, phase2, errbuf, errcap), errbuf, errcap)
+}
+static int inq_run_rows_device_impl(inq_run_t *r, const uint32_t *target_index, uint64_t n_index, uint64_t width, void **d_phase1, void **d_phase2,
+                                    char *errbuf, size_t errcap) {
+    if (!r || !d_phase1 || !d_phase2 || width < n_index || (n_index && !target_index)) {
+        set_err(errbuf, errcap, "null argument, or width below the number of targets");
+        return INQ_EXIT_ERROR;
+    }
+    *d_phase1 = *d_phase2 = nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    if (!r->actx) {
+        r->actx.reset(new AsyncCtx());
+        r->actx->start(r->args->a.device);
+    }
+    if (!r->actx->wait()) {
+        set_err(errbuf, errcap, ctx_failure_message(*r->actx));
+        return INQ_EXIT_ERROR;
+    }
+    // one array of 2 x width: phase1 row, phase2 row (one collective's buffer); made afresh per call - every entry starts as NaN, a
+    // device allocation costs microseconds (tools/alloc_probe.hip)
+    const uint64_t w = std::max<uint64_t>(width, 1);
+    inq_dev_free_rows(r->actx->ctx, r->d1);
+    r->d1 = r->d2 = nullptr, r->dcap = 0;
+    if (inq_dev_alloc_rows(r->actx->ctx, 2 * w, &r->d1) != INQ_OK) {
+        set_err(errbuf, errcap, "cannot allocate the device row arrays");
+        return INQ_EXIT_ERROR;
+    }
+    r->d2 = r->d1 + w, r->dcap = w;
+    RowsOut ro;
+    ro.idx = target_index, ro.n = n_index, ro.active = true, ro.d1 = r->d1, ro.d2 = r->d2, ro.dcap = r->dcap;
+    const bool keep_leak = r->actx->leak;
+    const int rc = genotype_prepared(&r->args->a, *r->actx, r->P, -1, errbuf, errcap, ro, t_start);
+    r->actx->leak = keep_leak;  // the context belongs to the run
+    if (rc != INQ_EXIT_OK) return rc;
+    *d_phase1 = r->d1, *d_phase2 = r->d2;
+    return INQ_EXIT_OK;
+}
+int inq_run_rows_device(inq_run_t *r, const uint32_t *target_index, uint64_t n_index, uint64_t width, void **d_phase1, void **d_phase2, char *errbuf,
+                        size_t errcap) {
+    INQ_GUARD(inq_run_rows_device_impl(r, target_index, n_index, width, d_phase1, d_phase2, errbuf, errcap), errbuf, errcap)
 }
 int inq_run_write_inq(inq_run_t *r, const double *phase1, const double *phase2, uint64_t n_rows, int out_fd, char *errbuf, size_t errcap) {
     if (!r || n_rows != r->P.targets.size() || (n_rows && (!phase1 || !phase2))) {

@@ -476,7 +476,9 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
             res.phase1 = b1.data();
             res.phase2 = b2.data();
             double ms_call = 0;
-            int rc2 = inq_call_flush(ctx, &res, pending.size(), &ms_call);
+            // (rows that travel on from device memory stay there: pending[j] is the row's place in the caller's device arrays)
+            int rc2 = hooks.dev_p1 ? inq_call_flush_device(ctx, hooks.dev_p1, hooks.dev_p2, hooks.dev_cap, pending.data(), pending.size(), nullptr, &ms_call)
+                                   : inq_call_flush(ctx, &res, pending.size(), &ms_call);
             *t_dev += secs(f0, clk::now());
             if (timing == 2)
                 std::fprintf(stderr, "[inq call] @%.1f %zu loci, %.1f MB of CIGARs: locus kernels %.3f ms | wall %.2f ms\n", stamp_ms(), pending.size(),
@@ -487,10 +489,11 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
                 set_err(errbuf, errcap, m);
                 return (rc2 == INQ_ERR_HIP || rc2 == INQ_ERR_NOMEM || rc2 == INQ_ERR_NO_DEVICE) ? INQ_EXIT_ERROR : INQ_EXIT_PANIC;
             }
-            for (size_t j = 0; j < pending.size(); ++j) {
-                p1[pending[j]] = b1[j];
-                p2[pending[j]] = b2[j];
-            }
+            if (!hooks.dev_p1)
+                for (size_t j = 0; j < pending.size(); ++j) {
+                    p1[pending[j]] = b1[j];
+                    p2[pending[j]] = b2[j];
+                }
             pending.clear();
             pending_words = 0;
             return INQ_EXIT_OK;

@@ -572,3 +572,32 @@ def test_ctx_create_multi_on_one_gpu():
             c.close()
     with pytest.raises(hipcall.InqError):
         hipcall.Context.create_multi([0, 99])  # all or nothing: the good context is taken back
+
+
+@pytest.mark.parametrize("frontend,unphased", [("device", False), ("device", True), ("host", False)])
+def test_rows_left_in_device_memory_equal_the_host_rows(tmp_path, frontend, unphased):
+    """inq_run_rows_device (what the RCCL gather of inquistr_amd/call_dist.py reads from): the rows of a share of the targets left in
+    a [2][width] device buffer - written by the flushes' scatter (device front end) or copied up once (host sweep) -, NaN behind the
+    share and for loci no span holds, against inq_run_rows on the same share; then call_dist with rows='device' at world size 1
+    against the CLI's text."""
+    import torch
+
+    from inquistr_amd import call_dist
+
+    bam, bed, loci, recs = _make_case(tmp_path, 78, n_loci=90, ultra_long=True)
+    run = call.Run(bam, None, bed, 5, 3, 4, unphased, "S", frontend=frontend)
+    order, cuts = run.partition(3)
+    mine = order[int(cuts[1]):int(cuts[2])]
+    width = len(mine) + 7
+    want1, want2 = run.rows(mine)
+    d1, d2 = run.rows_device(mine, width)
+    assert d2 == d1 + 8 * width
+    t = torch.as_tensor(call_dist._DeviceArray(d1, (2, width)), device="cuda:0").cpu().numpy()
+    assert np.array_equal(np.nan_to_num(t[0, : len(mine)], nan=-7e77), np.nan_to_num(want1, nan=-7e77))
+    assert np.array_equal(np.nan_to_num(t[1, : len(mine)], nan=-7e77), np.nan_to_num(want2, nan=-7e77))
+    assert np.isnan(t[:, len(mine):]).all() and (~np.isnan(want1)).sum() > 3
+    run.close()
+    out = tmp_path / "d.inq"
+    with open(out, "w") as f:
+        call_dist.genotype_repeats_distributed(bam, None, bed, 5, 3, 4, unphased, "S", out=f, frontend=frontend, rows="device")
+    assert out.read_text() == _expected_text(loci, recs, unphased, 5, 3, "S", 4)

@@ -617,6 +617,32 @@ def test_bench_two_ranks_report_every_ranks_clock_and_the_gathers_tail():
     assert line["gather"]["collectives"] == 2 and line["gather"]["bytes_per_rank_per_collective"] == 4 * 2 * 10_000 * 8
 
 
+def test_bench_l2_dist_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 --l2-dist rehearsed on the one GPU (gloo, both ranks on device 0): the END-TO-END multi-rank mode - call_dist
+    over one SEQ-bearing BAM, strong scaling - prints a line whose .inq equals the single-process CLI's and CPU mode B's byte for
+    byte, with every rank's loci, BAM bytes, seconds and reader threads, the one-process `--devices 0,0` run beside it."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29657",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--l2-dist", "--l2-dist-loci", "1500", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["inq_identical_to_single_process"] is True
+    assert line["cpu_baseline"]["inq_identical"] is True and line["cpu_baseline"]["kind"] == "port"
+    assert line["native_devices"]["inq_identical"] is True and line["native_devices"]["devices"] == "0,0"
+    assert [p["rank"] for p in line["per_rank"]] == [0, 1] and sum(p["loci"] for p in line["per_rank"]) == 1500
+    read = [p["bam_bytes_read"] for p in line["per_rank"]]
+    assert min(read) > 0.3 * line["config"]["bam_bytes"] and sum(read) < 1.15 * line["config"]["bam_bytes"]
+    for p in line["per_rank"]:
+        assert p["front"] == "device" and p["span_loop_GBps"] > 1 and p["io_threads"] >= 2 and p["io_threads"] * 2 <= max(p["granted_cpus"], 4)
+
+
 def test_superset_of_candidates_changes_nothing(ctx):
     """The ABI lets the host offer more reads than fetch() would yield (one sweep over the file instead
     of an index query per locus): the device applies htslib's overlap rule.  Offering every locus the
