@@ -748,11 +748,15 @@ def l2_dist(args):
         line["bam_bytes_read_all_ranks"] = int(sum(reads))
         line["bam_bytes_read_over_file"] = sum(reads) / bam_bytes
         if loop:
-            agg = sum(reads) / 1e9 / max(loop)
-            line["pcie"] = {"bound": "pcie", "achieved": agg, "unit": "GB/s", "peak": PCIE_SPEC_GBS * (1 if args.same_device else world),
-                            "frac": agg / (PCIE_SPEC_GBS * (1 if args.same_device else world)),
-                            "what": "compressed bytes all ranks handed to their devices / the longest rank's span loop (median over the timed steps); "
-                                    "peak = one Gen5 x16 link per rank" + (" (ranks share ONE device and link here)" if args.same_device else "")}
+            # conservative: all compressed bytes of a pass / the WHOLE pass (context creation, planning, rows, gather, text included) - the
+            # ranks' span loops are short and need not coincide, so bytes / the longest loop would overstate what the links carried at once
+            agg = sum(reads) / 1e9 / (dt_max / args.steps)
+            links = 1 if args.same_device else world
+            line["pcie"] = {"bound": "pcie", "achieved": agg, "unit": "GB/s", "peak": PCIE_SPEC_GBS * links, "frac": agg / (PCIE_SPEC_GBS * links),
+                            "span_loop_GBps_per_rank": [r.get("span_loop_GBps") for r in allr], "links": links,
+                            "what": "compressed bytes all ranks handed to their devices in one pass / the seconds of the whole pass (max over ranks); "
+                                    "peak = one Gen5 x16 link per rank" + (" (the ranks share ONE device and link here)" if args.same_device else "") +
+                                    "; span_loop_GBps_per_rank = each rank's own bytes / its own span loop"}
         # the host side of N links: what page-cache reads + DMA reads ask of the host's memory per second at the achieved rate
         line["host"] = {"granted_cpus": allr[0].get("granted_cpus"), "reader_threads_per_rank": allr[0].get("io_threads"),
                         "host_memory_traffic_GBps_at_achieved_rate": (3 * line["pcie"]["achieved"]) if loop else None,

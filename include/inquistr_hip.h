@@ -177,10 +177,11 @@ int inq_ctx_timing_enable(inq_ctx_t *ctx, int on);
 int inq_ctx_timing_read(inq_ctx_t *ctx, int which, double *total_ms, uint64_t *launches);
 int inq_ctx_timing_reset(inq_ctx_t *ctx);
 
-/* Tuning knobs.  key: "grid_medium" / "grid_big" = workgroups launched for the 65..256-read and the
- * deeper-locus kernels (defaults 8192 / 1024); "max_reads_hint" = N > 0 promises that no locus of the
- * following batches is offered more than N reads (N <= 64 skips both extra launches; a violated promise
- * is reported as INQ_ERR_ARG), 0 (default) = unknown;
+/* Tuning knobs.  key: "grid_medium" = workgroups of the kernel that takes the 65..256-read loci and walks the deeper ones
+ * (default 8192); "grid_tail" ("grid_big" up to ABI v4) = workgroups of the persistent kernel that reduces the deeper ones (default
+ * 256, never more than the device's compute units: they meet at grid barriers); "max_reads_hint" = N > 0 promises that no locus of
+ * the following batches is offered more than N reads (N <= 64 skips the two launches behind the first kernel - which cost a few
+ * microseconds when nothing deep is there; a violated promise is reported as INQ_ERR_ARG), 0 (default) = unknown;
  * "verify_crc" = 0 skips the CRC32 check of the device front end (default 1);
  * "inflate_algo" = 0 inflates with one workgroup per BGZF block (no latency floor, 0.54-0.82 ms per 1000 blocks), 1 with one
  * lane per block (36-56 ms for up to ~65 000 blocks), 2 (default) = the quicker one, which is 0 at every size measured;

@@ -74,6 +74,7 @@ int status_to_code(uint32_t st) {
     if (st & ST_RANGE) return INQ_ERR_RANGE;
     if (st & ST_PHASE) return INQ_ERR_PHASE;
     if (st & ST_AUX) return INQ_ERR_AUX;
+    if (st & ST_INTERNAL) return INQ_ERR_HIP;  // a grid barrier gave up waiting (the grid drained; the rows of very deep loci are not there)
     return INQ_OK;
 }
 
@@ -132,6 +133,8 @@ int inq_ctx_create_early(int device_id, inq_ctx_t **out, volatile int *stage_rea
     inq_ctx *c = new (std::nothrow) inq_ctx();
     if (!c) return INQ_ERR_NOMEM;
     c->device = device_id;
+    c->n_cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
+    c->grid_tail = std::min<uint32_t>(c->grid_tail, c->n_cus);  // a partitioned device (CPX: 32 CUs) takes a smaller grid
     c->backend = std::string("hip:") + prop.gcnArchName + ":" + prop.name;
     bool published = false;
     auto fail = [&](int code) {
@@ -263,7 +266,7 @@ static int enqueue_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, vo
     if ((rc = ensure(c, c->worklist, (size_t)shard_cap * kListShards * 2 * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->sval, (size_t)b->n_pairs * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->smeta, (size_t)b->n_pairs)) != INQ_OK) return rc;
-    // loci of more than kGridSelectMin reads are reduced over the whole grid (deep_select.hip): a state of ~45 KB each, and there
+    // loci of more than kGridSelectMin reads are reduced over the whole grid (deep_select.hip): a state of 74 KB each, and there
     // cannot be more of them than n_pairs / kGridSelectMin; nothing is allocated or launched when the depth hint rules them out
     const uint32_t hint0 = c->call_hint ? c->call_hint : c->max_reads_hint;
     const bool deep_possible = b->n_pairs > kGridSelectMin && !(hint0 && hint0 <= kGridSelectMin);
@@ -311,7 +314,7 @@ static int enqueue_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, vo
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->e0, s));
     }
-    launch_locus_call(a, b->unphased != 0, nt, grid_small, c->grid_medium, c->grid_big, s, ev ? ev->e1 : nullptr, deep_possible ? c->deep.p : nullptr);
+    launch_locus_call(a, b->unphased != 0, nt, grid_small, c->grid_medium, c->grid_tail, s, ev ? ev->e1 : nullptr, deep_possible ? c->deep.p : nullptr);
     HIP_TRY(c, hipGetLastError());
     if (ev) HIP_TRY(c, hipEventRecord(ev->e2, s));
     return INQ_OK;
@@ -526,9 +529,9 @@ int inq_ctx_timing_read(inq_ctx_t *c, int which, double *total_ms, uint64_t *lau
 
 int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     if (!c || !key) return INQ_ERR_ARG;
-    if (std::strcmp(key, "grid_big") == 0) {
+    if (std::strcmp(key, "grid_tail") == 0 || std::strcmp(key, "grid_big") == 0) {  // ("grid_big": the name up to ABI v4)
         if (value < 1 || value > 65535) return INQ_ERR_ARG;
-        c->grid_big = (uint32_t)value;
+        c->grid_tail = std::min<uint32_t>((uint32_t)value, c->n_cus ? c->n_cus : 1u);  // all of them must be resident at once
         return INQ_OK;
     }
     if (std::strcmp(key, "grid_medium") == 0) {

@@ -26,7 +26,8 @@ namespace inq {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // device status word bits (mapped to INQ_ERR_* by the host, same precedence as the oracle)
-constexpr uint32_t ST_INDEX = 1u, ST_CIGAR_OP = 2u, ST_RANGE = 4u, ST_PHASE = 8u, ST_LOCUS = 16u, ST_HINT = 32u, ST_AUX = 64u;
+constexpr uint32_t ST_INDEX = 1u, ST_CIGAR_OP = 2u, ST_RANGE = 4u, ST_PHASE = 8u, ST_LOCUS = 16u, ST_HINT = 32u, ST_AUX = 64u,
+                   ST_INTERNAL = 128u;  // a grid barrier of locus_call_tail gave up waiting (never seen; the grid drains all the same)
 
 // per-pair meta byte: low 3 bits are the public INQ_PAIR_* bits
 constexpr uint32_t PM_CLIP = 1u, PM_FETCHED = 2u, PM_KEPT = 4u;

@@ -18,6 +18,12 @@ struct DevStatus {
         unsigned int n;
     } list_count[2][kListShards];
     unsigned long long ties;    // unphased loci whose split cuts mixed Span/Clip ties
+    // locus_call_tail (deep_select.hip), each word on a line of its own: the grid barrier's arrival counter (monotonic inside a launch),
+    // its abort word (a barrier that waited too long: every workgroup leaves), the exit ticket (the last workgroup out empties the
+    // work lists).  locus_call_small puts all three back to zero in front of every sequence.
+    struct alignas(128) Word {
+        unsigned int v;
+    } bar_count, bar_abort, exit_ticket;
 };
 
 struct KArgs {
@@ -45,13 +51,14 @@ struct KArgs {
 };
 
 // deep_scratch: deep_select_scratch_bytes(n_pairs) of ctx scratch for the loci the grid-wide select takes (may be null when the
-// depth hint rules them out)
+// depth hint rules them out, or no locus can be that deep); grid_tail: workgroups of the persistent locus_call_tail - they wait
+// for one another at grid barriers, so all of them must be resident at once: at most one per compute unit of the device
 void launch_locus_call(const KArgs &a, bool unphased, bool nt_loads, uint32_t grid_small, uint32_t grid_medium,
-                       uint32_t grid_big, hipStream_t s, hipEvent_t ev_mid, void *deep_scratch);
+                       uint32_t grid_tail, hipStream_t s, hipEvent_t ev_mid, void *deep_scratch);
 
-// deep_select.hip: loci with more offered reads than this are reduced by launches over the whole grid instead of one workgroup
+// deep_select.hip: loci with more offered reads than this are reduced by the whole grid instead of one workgroup
 constexpr uint32_t kGridSelectMin = 65536;
 size_t deep_select_scratch_bytes(uint64_t n_pairs);
-void launch_deep_select(const KArgs &k, bool unphased, void *scratch, uint64_t n_pairs, hipStream_t s);
+void launch_locus_tail(const KArgs &k, bool unphased, void *scratch, uint64_t n_pairs, uint32_t grid, hipStream_t s);
 
 }  // namespace inq
