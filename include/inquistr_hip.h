@@ -197,9 +197,18 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * device allocations cost microseconds, tools/alloc_probe.hip); 0 = the span is inflated when it is called;
  * "gather_nt" = 1 (default) / 0: the device front end's CIGAR gather stores with the non-temporal policy (the batch it builds is
  * read by a later launch); "batch_loci_hint" = N: inq_call_span_deferred sizes the batch's buffers for N loci from its first span;
+ * "retired_limit_mb" / "test_fail_allocs": see inq_ctx_alloc_retries;
  * "nt_loads" = 1 / 0 forces the non-temporal cache policy for the CIGAR stream on / off; -1 (default)
  * picks it when no read is shared between loci (n_pairs <= n_reads). */
 int inq_ctx_set_option(inq_ctx_t *ctx, const char *key, int64_t value);
+/* How often a device allocation of this context met "out of memory", gave the buffers it had outgrown and parked back (options
+ * "retired_limit_mb": how many MB may be parked, default 16384) and tried again - and, for the deferred batch's speculative
+ * reserve, fell back to the bytes really needed.  ("test_fail_allocs" = N makes the next N first attempts fail: the test seam.) */
+uint64_t inq_ctx_alloc_retries(const inq_ctx_t *ctx);
+/* The same for every context made FROM NOW ON in this process (any thread): key and value are checked at once, the option is applied
+ * inside inq_ctx_create / _early / _multi before the context is handed out.  For a host that does not make the contexts itself
+ * (libinquistr_host.so does: `inquistr call --ctx-option key=value`).  The library reads NO option from the environment. */
+int inq_default_option(const char *key, int64_t value);
 
 /* Page-locks caller-owned host memory in place (hipHostRegister: 0.5 ms for 268 MB of huge-page-backed memory, against 50 - 60 ms
  * for inq_alloc_pinned of the same size), so that copies from it are plain DMA.  The runtime must be up (a ctx exists). */

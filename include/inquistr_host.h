@@ -95,6 +95,10 @@ void inq_host_set_local_share(int sharers, int index);
 /* what the last call that ended in this process did (spans, BAM bytes, span loop / loader / device seconds, front end, reader
  * threads; device, status, loci and rows_s are not filled): a rank of the one-process-per-GPU run reports it next to its rows */
 void inq_host_last_call_stats(inq_part_stats_t *out);
+/* An option (include/inquistr_hip.h: inq_ctx_set_option's keys) for every device context this library makes from now on: the host
+ * library creates its contexts itself, so this is how a caller of inq_genotype_repeats & co sets "inflate_ahead", "verify_crc",
+ * "grid_tail", ... (`inquistr call --ctx-option key=value`).  0, or 1 for an unknown key / a value out of range. */
+int inq_host_ctx_option(const char *key, int64_t value);
 int inq_host_granted_cpus(void); /* CPUs of the affinity mask, cut by the cgroup's CPU quota */
 int inq_host_span_io_threads(uint64_t threads, int sharers); /* the reader pool size a call with -t threads would take */
 /* tests (no GPU involved): the control flow of inq_genotype_repeats_devices with rows that name their target and their part; a device

@@ -26,6 +26,7 @@ HOST_ABI_SYMBOLS = (
     "inq_genotype_repeats_devices",
     "inq_host_set_local_share",
     "inq_host_granted_cpus",
+    "inq_host_ctx_option",
     "inq_host_last_call_stats",
     "inq_host_span_io_threads",
     "inq_host_devices_selftest",
@@ -151,6 +152,8 @@ def load():
         L.inq_host_set_local_share.argtypes = [C.c_int, C.c_int]
         L.inq_host_last_call_stats.restype = None
         L.inq_host_last_call_stats.argtypes = [C.POINTER(PartStatsC)]
+        L.inq_host_ctx_option.restype = C.c_int
+        L.inq_host_ctx_option.argtypes = [C.c_char_p, C.c_int64]
         L.inq_host_granted_cpus.restype = C.c_int
         L.inq_host_granted_cpus.argtypes = []
         L.inq_host_span_io_threads.restype = C.c_int

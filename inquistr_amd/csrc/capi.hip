@@ -42,6 +42,39 @@ void purge_retired(inq_ctx *c) {
     for (auto &e : gone) (void)hipFree(e.first);  // hipFree waits for the device: work that still reads the buffer ends first
 }
 
+// hipMalloc that gives the parked buffers back before it gives up: retired buffers (ctx.h) are memory the context could free at any
+// moment, so "out of memory" with some of them waiting is not yet out of memory.  `exact` (< want, or 0): what the caller really
+// needs, tried last without the headroom.  ("test_fail_allocs" = N makes the next N first attempts fail: the retry's test seam.)
+int device_alloc(inq_ctx *c, void **out, size_t want, size_t exact, size_t *got) {
+    *out = nullptr;
+    *got = want;
+    hipError_t e = hipSuccess;
+    if (c->test_fail_allocs > 0) {
+        --c->test_fail_allocs;
+        ++c->alloc_retries;
+        e = hipErrorOutOfMemory;
+    } else {
+        e = hipMalloc(out, want);
+    }
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();  // clear the sticky error
+        purge_retired(c);         // waits for the device: whatever still read those buffers is through
+        ++c->alloc_retries;
+        e = hipMalloc(out, want);
+        if (e == hipErrorOutOfMemory && exact && exact < want) {
+            (void)hipGetLastError();
+            e = hipMalloc(out, exact);
+            *got = exact;
+        }
+    }
+    if (e != hipSuccess) {
+        *out = nullptr;
+        c->last_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? INQ_ERR_NOMEM : INQ_ERR_HIP;
+    }
+    return INQ_OK;
+}
+
 int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return INQ_OK;
     if (b.p) {
@@ -52,7 +85,7 @@ int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
         bool too_much;
         {
             std::lock_guard<std::mutex> g(c->retired_mu);
-            too_much = c->retired_bytes > (16ull << 30);
+            too_much = c->retired_bytes > c->retired_limit;
         }
         if (too_much) purge_retired(c);
     }
@@ -60,9 +93,12 @@ int ensure(inq_ctx *c, DevBuf &b, size_t bytes) {
     // calls.  Large buffers get little of it: device memory a process holds is wiped by the driver when the process leaves, at
     // ~20 GB/s, and while that goes on the NEXT process's hipInit and hipMalloc wait (0.1 -> 0.3 s of start-up, 50 ms per GB
     // allocated: profiles/r04_results/back_to_back_vs_paused_processes.txt) - spans of a file are the same size to a percent
+    const size_t floor_bytes = bytes < 256 ? 256 : bytes;
     size_t want = bytes < 256 ? 256 : bytes < (32u << 20) ? bytes + bytes / 2 + (1u << 16) : bytes + bytes / 16 + (1u << 20);
-    HIP_TRY(c, hipMalloc(&b.p, want));
-    b.cap = want;
+    size_t got = 0;
+    const int rc = device_alloc(c, &b.p, want, floor_bytes, &got);
+    if (rc != INQ_OK) return rc;
+    b.cap = got;
     return INQ_OK;
 }
 
@@ -103,6 +139,8 @@ const char *inq_strerror(int code) {
     default: return "unknown error";
     }
 }
+
+static void apply_default_options(inq_ctx *c);
 
 // The context in two steps for a caller that is in a hurry: *out is set and *stage_ready raised as soon as the staging entry points
 // (inq_span_stage_begin / _wait / inq_span_stage) may be used - the runtime is up, the copy and inflate streams and the staging
@@ -146,6 +184,7 @@ int inq_ctx_create_early(int device_id, inq_ctx_t **out, volatile int *stage_rea
     // the streams of the staging path first (the process's first stream costs 18 - 170 ms, every further one 8): uploads and the
     // inflates behind them start while the rest of the context is still being made
     if (span_state_init(c) != INQ_OK) return fail(INQ_ERR_HIP);
+    apply_default_options(c);
     lap("hipSetDevice + copy / inflate streams, slots");
     *out = c;
     if (stage_ready) {
@@ -527,6 +566,40 @@ int inq_ctx_timing_read(inq_ctx_t *c, int which, double *total_ms, uint64_t *lau
     return INQ_OK;
 }
 
+// options every context made from now on starts with (inq_default_option): applied inside inq_ctx_create_early BEFORE the context is
+// published for staging, so that an uploader thread never sees the built-in value of e.g. "inflate_ahead"
+static std::mutex g_defaults_mu;
+static std::vector<std::pair<std::string, int64_t>> g_defaults;
+
+int inq_default_option(const char *key, int64_t value) {
+    if (!key) return INQ_ERR_ARG;
+    try {
+        inq_ctx probe;  // the key and the value are checked on a context that is never opened
+        probe.n_cus = 256;
+        const int rc = inq_ctx_set_option(&probe, key, value);
+        if (rc != INQ_OK) return rc;
+        std::lock_guard<std::mutex> g(g_defaults_mu);
+        for (auto &kv : g_defaults)
+            if (kv.first == key) {
+                kv.second = value;
+                return INQ_OK;
+            }
+        g_defaults.emplace_back(key, value);
+        return INQ_OK;
+    } catch (...) {
+        return INQ_ERR_NOMEM;
+    }
+}
+
+static void apply_default_options(inq_ctx *c) {
+    std::vector<std::pair<std::string, int64_t>> d;
+    {
+        std::lock_guard<std::mutex> g(g_defaults_mu);
+        d = g_defaults;
+    }
+    for (auto &kv : d) (void)inq_ctx_set_option(c, kv.first.c_str(), kv.second);
+}
+
 int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     if (!c || !key) return INQ_ERR_ARG;
     if (std::strcmp(key, "grid_tail") == 0 || std::strcmp(key, "grid_big") == 0) {  // ("grid_big": the name up to ABI v4)
@@ -573,12 +646,24 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
         c->inflate_tokens = value < 0 ? -1 : (value != 0);
         return INQ_OK;
     }
+    if (std::strcmp(key, "retired_limit_mb") == 0) {  // outgrown buffers parked before they are given back (default 16384)
+        if (value < 0 || value > (1ll << 20)) return INQ_ERR_ARG;
+        c->retired_limit = (size_t)value << 20;
+        return INQ_OK;
+    }
+    if (std::strcmp(key, "test_fail_allocs") == 0) {  // test seam: the next N device allocations see "out of memory" at their first attempt
+        if (value < 0 || value > 1000000) return INQ_ERR_ARG;
+        c->test_fail_allocs = (uint32_t)value;
+        return INQ_OK;
+    }
     if (std::strcmp(key, "nt_loads") == 0) {
         c->nt_loads = value < 0 ? -1 : (value != 0);
         return INQ_OK;
     }
     return INQ_ERR_ARG;
 }
+
+uint64_t inq_ctx_alloc_retries(const inq_ctx_t *c) { return c ? c->alloc_retries : 0; }
 
 int inq_pin_host(void *p, size_t bytes) {
     if (!p || !bytes) return INQ_ERR_ARG;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -68,6 +69,10 @@ struct inq_ctx {
     std::mutex retired_mu;  // the uploader thread (inq_span_stage) grows its slots while the caller grows the scan buffers
     std::vector<std::pair<void *, size_t>> retired;
     size_t retired_bytes = 0;
+    size_t retired_limit = 16ull << 30;  // option "retired_limit_mb"
+    // an allocation that fails for lack of memory gives the parked buffers back and tries again (capi.hip device_alloc)
+    uint32_t test_fail_allocs = 0;  // option "test_fail_allocs": the next N allocations fail at their first attempt
+    uint64_t alloc_retries = 0;     // how often that second attempt was needed (inq_ctx_alloc_retries)
     std::vector<inq::EvTriple> ev_pool;
     size_t ev_used = 0;
     inq::SpanState *span = nullptr;  // created on first use by the device front end
@@ -83,8 +88,17 @@ struct inq_ctx {
     } while (0)
 
 namespace inq {
+// The one place the library could read an experiment's switch from the environment - and it does only when built with
+// -DINQ_DEBUG_ENV (make DEBUG_ENV=1).  What a host can set is inq_ctx_set_option / inq_default_option, nothing else; INQ_TIMING
+// (stage clocks on stderr) is the only variable the shipped library looks at.
+#ifdef INQ_DEBUG_ENV
+inline const char *debug_env(const char *name) { return std::getenv(name); }
+#else
+inline const char *debug_env(const char *) { return nullptr; }
+#endif
 // grows b to at least `bytes` (with headroom); the old buffer is retired, not freed: no synchronisation, contents NOT kept
 int ensure(inq_ctx *c, DevBuf &b, size_t bytes);
+int device_alloc(inq_ctx *c, void **out, size_t want, size_t exact, size_t *got);
 void retire(inq_ctx *c, void *p, size_t bytes);
 void purge_retired(inq_ctx *c);  // hipFree of everything retired (waits for the device: call where it is idle)
 // enqueue-only launch sequence of the locus kernels over a device-resident batch

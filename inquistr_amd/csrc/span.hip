@@ -59,8 +59,7 @@ struct SpanState {
     } stage[INQ_SPAN_SLOTS];  // two sets of four: the spans of the NEXT file of a cohort are staged while this file's are still being called
     hipStream_t copy_stream = nullptr;
     hipStream_t ahead_stream = nullptr;  // the inflates launched at staging time
-    hipEvent_t ev_warm = nullptr;  // behind the one warm-up copy below (it goes on the ahead stream: a stream of its own cost 8 ms of start-up)
-    bool warm_pending = false;
+    uint8_t *h_warm = nullptr;  // page-locked target of the one warm-up copy (call_span_impl)
     // the batch the last inq_call_span built
     uint64_t n_reads = 0, n_cigar_words = 0, n_pairs = 0, n_loci = 0;
     bool last_from_acc = false;
@@ -97,7 +96,7 @@ void span_state_destroy(SpanState *S) {
     for (DevBuf *b : {&S->acc.cigar, &S->acc.reads, &S->acc.pair_read, &S->acc.off, &S->acc.lstart, &S->acc.lend})
         if (b->p) (void)hipFree(b->p);
     if (S->copy_stream) (void)hipStreamDestroy(S->copy_stream);
-    if (S->ev_warm) (void)hipEventDestroy(S->ev_warm);
+    if (S->h_warm) (void)hipHostFree(S->h_warm);
     if (S->d_st) (void)hipFree(S->d_st);
     if (S->h) (void)hipHostFree(S->h);
     if (S->h_rows) (void)hipHostFree(S->h_rows);
@@ -117,8 +116,7 @@ int inq::span_state_init(inq_ctx *c) {
     // what STAGING needs, and nothing else: inq_ctx_create_early publishes the context right behind this function
     HIP_TRY(c, hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&S->ahead_stream, hipStreamNonBlocking));
-    if (const char *e = std::getenv("INQ_INFLATE_AHEAD")) c->inflate_ahead = std::atoi(e) != 0;  // A/B and tests; the option is "inflate_ahead"
-    if (const char *e = std::getenv("INQ_GATHER_NT")) c->gather_nt = std::atoi(e) != 0;            // A/B; the option is "gather_nt"
+    // ("inflate_ahead", "gather_nt": options, inq_ctx_set_option / inq_default_option - the environment is not read)
     for (auto &g : S->stage) {
         HIP_TRY(c, hipMalloc((void **)&g.d_err, sizeof(unsigned int)));
         HIP_TRY(c, hipEventCreate(&g.ev_up));
@@ -135,7 +133,6 @@ int inq::span_state_init_rest(inq_ctx *c) {
     HIP_TRY(c, hipHostMalloc((void **)&S->h, sizeof(SpanState::Host), hipHostMallocDefault));
     for (auto &e : S->ev) HIP_TRY(c, hipEventCreate(&e));
     S->have_ev = true;
-    HIP_TRY(c, hipEventCreateWithFlags(&S->ev_warm, hipEventDisableTiming));
     return INQ_OK;
 }
 
@@ -153,7 +150,11 @@ int ensure_keep(inq_ctx *c, DevBuf &b, size_t bytes, size_t used, hipStream_t s,
     if (bytes <= b.cap && b.p) return INQ_OK;
     void *np = nullptr;
     const size_t want = std::max(bytes < (32u << 20) ? bytes + bytes / 2 + (1u << 20) : bytes + bytes / 8 + (1u << 20), reserve);
-    HIP_TRY(c, hipMalloc(&np, want));
+    // (the speculative reserve - the whole batch's size guessed from its first span - and the headroom are given up before the call is:
+    // device_alloc frees the parked buffers, then falls back to the bytes really needed)
+    size_t got = 0;
+    const int rc = device_alloc(c, &np, want, bytes, &got);
+    if (rc != INQ_OK) return rc;
     if (b.p) {
         if (used) {
             const hipError_t e = hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, s);
@@ -166,7 +167,7 @@ int ensure_keep(inq_ctx *c, DevBuf &b, size_t bytes, size_t used, hipStream_t s,
         retire(c, b.p, b.cap);
     }
     b.p = np;
-    b.cap = want;
+    b.cap = got;
     return INQ_OK;
 }
 
@@ -228,9 +229,8 @@ int upload_and_inflate(inq_ctx *c, SpanState *S, const uint8_t *comp, uint64_t c
     ia.err = &S->d_st->inflate;
     ia.verify_crc = c->verify_crc ? 1u : 0u;
     ia.debug_flags = 0u;
-#ifdef INQ_INFLATE_DEBUG_ENV  // timing experiments only (drops stores: wrong bytes), never in the shipped library
-    if (const char *dbg = std::getenv("INQ_INFLATE_DEBUG")) ia.debug_flags = (uint32_t)std::atoi(dbg);
-#endif
+    // timing experiments only (drops stores: wrong bytes); reads nothing unless built with -DINQ_DEBUG_ENV
+    if (const char *dbg = debug_env("INQ_INFLATE_DEBUG")) ia.debug_flags = (uint32_t)std::atoi(dbg);
     ia.algo = c->inflate_algo;
     // literal-heavy or match-heavy?  (the host still has the compressed bytes: a few block headers are read; option
     // "inflate_lit_pairs" = 0 / 1 forces a form, -1 = look)
@@ -362,11 +362,12 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
         S->h_rows_cap = want;
     }
     if (!S->copy_path_warm && u_bytes >= (512u << 10)) {
-        // the first device-to-host copy of this size costs the host ~8 ms inside the runtime; spent here, on another stream,
-        // it hides behind the inflate that was just enqueued instead of sitting behind the last kernel of the span
-        HIP_TRY(c, hipMemcpyAsync(S->h_rows, ahead ? staged->u.p : S->u.p, 512u << 10, hipMemcpyDeviceToHost, S->ahead_stream));
-        HIP_TRY(c, hipEventRecord(S->ev_warm, S->ahead_stream));
-        S->warm_pending = true;
+        // the first device-to-host copy of this size costs the host ~8 ms inside the runtime; spent here, on the copy stream (the
+        // other direction of the uploads), it hides behind the inflate that was just enqueued instead of sitting behind the last
+        // kernel of the span.  It lands in a page-locked scratch of its own: nothing waits for it, no row can be overwritten by it
+        // (round 4 put it on the ahead stream into the row staging: the first flush then waited for inflates queued behind it)
+        if (!S->h_warm) HIP_TRY(c, hipHostMalloc((void **)&S->h_warm, 512u << 10, hipHostMallocDefault));
+        HIP_TRY(c, hipMemcpyAsync(S->h_warm, ahead ? staged->u.p : S->u.p, 512u << 10, hipMemcpyDeviceToHost, S->copy_stream));
         S->copy_path_warm = true;
     }
     HIP_TRY(c, hipMemcpyAsync(&S->h->val[0], a.anchor_base + na, 8, hipMemcpyDeviceToHost, s));
@@ -546,10 +547,6 @@ int call_span_impl(inq_ctx *c, const inq_span_t *sp, inq_result_t *r, inq_span_s
     c->call_hint = std::max<uint32_t>(S->h->st.max_reads, 1u);
     if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(S->ev[5], s));
-    if (S->warm_pending) {  // the warm-up copy (long done) must not land in the rows
-        HIP_TRY(c, hipEventSynchronize(S->ev_warm));
-        S->warm_pending = false;
-    }
     HIP_TRY(c, hipMemcpyAsync(S->h_rows, dr.phase1, nl * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(S->h_rows + nl, dr.phase2, nl * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&S->h->ks, c->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, s));
@@ -641,7 +638,8 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
     HIP_TRY(c, hipEventRecord(S->ev[4], s));
     if ((rc = call_batch_device_impl(c, &db, &dr, s)) != INQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(S->ev[5], s));
-    if (const char *again = std::getenv("INQ_CALL_AGAIN"); again && again[0] == '1') {
+    // measurement builds only (make DEBUG_ENV=1; tools/profile_cli_locus.sh): the shipped library reads nothing here
+    if (const char *again = debug_env("INQ_CALL_AGAIN"); again && again[0] == '1') {
         // measurement only: the same launch sequence once more on the same batch (same rows), to tell what a launch that comes
         // cold behind the gather pays (caches, translations, write-back) from what the batch's layout costs
         HIP_TRY(c, hipEventRecord(S->ev[0], s));
@@ -651,10 +649,6 @@ int call_flush_impl(inq_ctx *c, inq_result_t *r, uint64_t n_loci, double *ms_cal
         float ms2 = 0.f;
         (void)hipEventElapsedTime(&ms2, S->ev[0], S->ev[1]);
         std::fprintf(stderr, "[inq call] the same %llu loci again: locus kernels %.3f ms\n", (unsigned long long)nl, (double)ms2);
-    }
-    if (S->warm_pending) {
-        HIP_TRY(c, hipEventSynchronize(S->ev_warm));
-        S->warm_pending = false;
     }
     if (dev) {  // the rows' places go up (4 B per locus, through the page-locked row staging), the rows stay where they are
         if ((rc = ensure(c, S->tmp, std::max<size_t>(nl * 4, 64))) != INQ_OK) return rc;
@@ -739,6 +733,15 @@ int span_stage_begin_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
     g.blocks.p = (uint8_t *)g.tab.p + off_blocks, g.blocks.cap = 0;
     g.anchors.p = (uint8_t *)g.tab.p + off_anch, g.anchors.cap = 0;
     g.anchor_stop.p = (uint8_t *)g.tab.p + off_stop, g.anchor_stop.cap = 0;
+    // From here on the copy engine may be reading the caller's span buffer and this slot's table: an error exit must not hand them back
+    // while it does (the slot stays invalid, `pending` is not raised, so nobody will wait for this upload later).
+    struct DrainOnError {
+        hipStream_t s;
+        bool armed = true;
+        ~DrainOnError() {
+            if (armed) (void)hipStreamSynchronize(s);
+        }
+    } drain{s};
     if (sp->comp_bytes) HIP_TRY(c, hipMemcpyAsync(g.comp.p, sp->comp, sp->comp_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync((uint8_t *)g.comp.p + sp->comp_bytes, 0, kPad, s));
     if (tab_bytes) HIP_TRY(c, hipMemcpyAsync(g.tab.p, g.h_tab, tab_bytes, hipMemcpyHostToDevice, s));
@@ -782,6 +785,7 @@ int span_stage_begin_impl(inq_ctx *c, const inq_span_t *sp, int slot) {
     g.n_blocks = nb;
     g.n_anchors = na;
     g.pending = true;
+    drain.armed = false;
     return INQ_OK;
 }
 

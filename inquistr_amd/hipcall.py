@@ -53,6 +53,8 @@ ABI_SYMBOLS = (
     "inq_span_stage",
     "inq_ctx_create_early",
     "inq_ctx_create_multi",
+    "inq_default_option",
+    "inq_ctx_alloc_retries",
     "inq_span_stage_begin",
     "inq_span_stage_wait",
     "inq_call_span_staged",
@@ -186,6 +188,10 @@ def load(path: Optional[str] = None):
     vp = C.c_void_p
     L.inq_ctx_create.restype = C.c_int
     L.inq_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.inq_ctx_alloc_retries.restype = C.c_uint64
+    L.inq_ctx_alloc_retries.argtypes = [vp]
+    L.inq_default_option.restype = C.c_int
+    L.inq_default_option.argtypes = [C.c_char_p, C.c_int64]
     L.inq_ctx_create_multi.restype = C.c_int
     L.inq_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.inq_ctx_destroy.restype = None
@@ -297,6 +303,10 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    @property
+    def alloc_retries(self) -> int:
+        return int(self._L.inq_ctx_alloc_retries(self._h))
 
     @property
     def backend(self) -> str:

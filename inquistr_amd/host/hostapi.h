@@ -17,6 +17,7 @@ namespace inq {
 struct HostApi {
     decltype(&::inq_genotype_repeats) genotype_repeats;
     decltype(&::inq_genotype_repeats_devices) genotype_repeats_devices;
+    decltype(&::inq_host_ctx_option) ctx_option;
     decltype(&::inq_combine) combine;
     decltype(&::inq_outlier) outlier;
     decltype(&::inq_host_sample_name) host_sample_name;
@@ -55,6 +56,7 @@ inline const HostApi &host_api() {
         };
         a.genotype_repeats = reinterpret_cast<decltype(a.genotype_repeats)>(sym("inq_genotype_repeats"));
         a.genotype_repeats_devices = reinterpret_cast<decltype(a.genotype_repeats_devices)>(sym("inq_genotype_repeats_devices"));
+        a.ctx_option = reinterpret_cast<decltype(a.ctx_option)>(sym("inq_host_ctx_option"));
         a.combine = reinterpret_cast<decltype(a.combine)>(sym("inq_combine"));
         a.outlier = reinterpret_cast<decltype(a.outlier)>(sym("inq_outlier"));
         a.host_sample_name = reinterpret_cast<decltype(a.host_sample_name)>(sym("inq_host_sample_name"));

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/inquistr_host.h"
@@ -27,6 +28,7 @@ static void usage(FILE *f) {
         "      --reference <REFERENCE>      reference fasta for cram decoding\n"
         "      --device <N>                 HIP device ordinal [default: 0]\n"
         "      --devices <N,N,...>          several HIP devices: the loci are split among them by BAM bytes, same output\n"
+        "      --ctx-option <KEY=VALUE>     a device-context option (include/inquistr_hip.h, inq_ctx_set_option), repeatable\n"
         "  -h, --help                       Print help\n",
         f);
 }
@@ -225,6 +227,7 @@ int main(int argc, char **argv) {
     a.threads = 1;
     std::string bam;
     std::vector<int32_t> devices;  // --devices: one part of the targets per entry (an ordinal may repeat: N parts on one GPU)
+    std::vector<std::pair<std::string, long long>> ctx_options;  // --ctx-option key=value
     auto need = [&](int &i) -> const char * {
         if (i + 1 >= argc) {
             std::fprintf(stderr, "error: a value is required for '%s' but none was supplied\n", argv[i]);
@@ -268,6 +271,17 @@ int main(int argc, char **argv) {
                 b = e + 1;
             }
         }
+        else if (s == "--ctx-option" || s.rfind("--ctx-option=", 0) == 0) {
+            const std::string kv = s == "--ctx-option" ? std::string(need(i)) : s.substr(13);
+            const size_t e2 = kv.find('=');
+            char *endp = nullptr;
+            const long long v = e2 == std::string::npos ? 0 : std::strtoll(kv.c_str() + e2 + 1, &endp, 10);
+            if (e2 == std::string::npos || e2 == 0 || e2 + 1 == kv.size() || (endp && *endp)) {
+                std::fprintf(stderr, "error: invalid value '%s' for '--ctx-option <KEY=VALUE>'\n", kv.c_str());
+                return 2;
+            }
+            ctx_options.emplace_back(kv.substr(0, e2), v);
+        }
         else if (key == "-h" || key == "--help") { usage(stdout); return 0; }
         else if (!s.empty() && s[0] == '-' && s.size() > 1) {
             std::fprintf(stderr, "error: unexpected argument '%s' found\n", s.c_str());
@@ -283,6 +297,11 @@ int main(int argc, char **argv) {
         return 2;
     }
     a.bam = bam.c_str();
+    for (const auto &kv : ctx_options)  // (a call handed to a server runs on the server's context: its options are the server's)
+        if (inq::host_api().ctx_option(kv.first.c_str(), kv.second) != 0) {
+            std::fprintf(stderr, "error: invalid value '%s=%lld' for '--ctx-option <KEY=VALUE>': no such option, or value out of range\n", kv.first.c_str(), kv.second);
+            return 2;
+        }
     if (devices.size() == 1) a.device = devices[0], devices.clear();
     if (!devices.empty()) {
         // one process, one thread + one device context per listed device (host/multi_device.cc); a server holds ONE device

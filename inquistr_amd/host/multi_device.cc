@@ -182,6 +182,7 @@ void inq_host_last_call_stats(inq_part_stats_t *out) {
     out->front = s.front, out->io_threads = s.io_threads;
 }
 void inq_host_set_local_share(int sharers, int index) { set_local_share(sharers, index); }
+int inq_host_ctx_option(const char *key, int64_t value) { return inq_default_option(key, value) == INQ_OK ? INQ_EXIT_OK : INQ_EXIT_ERROR; }
 int inq_host_granted_cpus(void) { return granted_cpus(); }
 int inq_host_span_io_threads(uint64_t threads, int sharers) {
     inq_call_args_t a;

@@ -148,7 +148,7 @@ void SpanPipeline::run() {
     std::string e;
     if (!loader.open(path_, &e)) return fail(e);
     // the reader threads of this file (span_planner.h: spread over the L3 domains of the GPU's NUMA node)
-    const char *pin_env = std::getenv("INQ_IO_PIN");
+    const char *pin_env = debug_env("INQ_IO_PIN");
     IoPool pool(n_threads_, guess_gpu_numa_node(device_), !(pin_env && pin_env[0] == '0'), io_group_offset_);
     if (verbose_) std::fprintf(stderr, "[inq loader] @%.1f %s\n", stamp_ms(), pool.layout().c_str());
     // span k + 1 is planned (index searches for some 25 000 loci: ~4 ms) on a helper thread while span k is being read
@@ -409,10 +409,9 @@ SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamFile &ba
     if (sharers <= 0) local_share(&sharers, &share_index);
     bool pinned = false;
     std::function<void()> gate;
-#ifdef INQ_DEBUG_ENV  // A/B switches of rounds 2 - 3, kept for experiments only: not in the shipped library
-    if (const char *pin_env = std::getenv("INQ_SPAN_PINNED")) pinned = pin_env[0] == '1';
-    if (std::getenv("INQ_GATE_READS")) gate = [&actx] { (void)actx.wait(); };
-#endif
+    // A/B switches of rounds 2 - 3, read only by a build with -DINQ_DEBUG_ENV
+    if (const char *pin_env = debug_env("INQ_SPAN_PINNED")) pinned = pin_env[0] == '1';
+    if (debug_env("INQ_GATE_READS")) gate = [&actx] { (void)actx.wait(); };
     // the loader uploads every span it has read (waiting for the context the first time), so that the upload of span k+1
     // overlaps the inflate of span k
     return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args, sharers), pinned,
@@ -575,7 +574,7 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
                          (unsigned long long)loop_spans, loop_comp_bytes / 1e6, loop_s, loop_comp_bytes / 1e9 / std::max(loop_s, 1e-9));
         }
         leak_all = fast_exit;  // only after a clean run: error paths tear down normally
-        if (const char *probe = std::getenv("INQ_EXIT_PROBE")) {
+        if (const char *probe = debug_env("INQ_EXIT_PROBE")) {
             // experiment: what does the process's exit pay for?  1 = unmap the span buffers here (the pipeline's destructor) and
             // time it, 2 = also destroy the device context (every hipFree) and time that; then the fast exit as usual
             const auto e0 = clk::now();

@@ -90,7 +90,9 @@ public:
           numa_query_(std::move(numa_query)), device_(device), io_group_offset_(io_group_offset) {
         for (int i = 0; i < kSlotsPerSet; ++i) slots_[i].slot = slot_base + i;
         int use = kSlotsPerSet;
+#ifdef INQ_DEBUG_ENV
         if (const char *e = std::getenv("INQ_SPAN_BUFFERS")) use = std::min(kSlotsPerSet, std::max(2, std::atoi(e)));  // A/B only
+#endif
         for (int i = 0; i < use; ++i) free_.push_back(&slots_[i]);
         th_ = std::thread([this] { run(); });
         if (stage_) up_ = std::thread([this] { run_uploads(); });  // span k uploads while span k + 1 is being read
@@ -164,7 +166,11 @@ private:
     WaitFn stage_wait_;
     HostBufPool *pool_ = nullptr;
     std::function<void()> gate_;
+#ifdef INQ_DEBUG_ENV
     bool register_ = std::getenv("INQ_SPAN_REGISTER") && std::getenv("INQ_SPAN_REGISTER")[0] == '1';
+#else
+    bool register_ = false;  // (page-locking the span buffers in place: an experiment of round 3)
+#endif
     std::function<void()> gate_registered_;  // waits for the runtime before the first registration
     std::function<int()> numa_query_;  // the GPU's NUMA node, kNumaUnknown while the context is not there yet, -1 = do not place
     int device_ = 0;

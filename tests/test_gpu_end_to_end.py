@@ -500,11 +500,16 @@ def test_file_scale_rows_equal_the_cpu_program_whatever_the_span_size(tmp_path, 
                           capture_output=True)
     assert want.returncode == 0, want.stderr[-500:]
     assert want.stdout.count(b"\n") == n_loci + 1
-    for env in ({"INQ_FRONTEND": "device"}, {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "16", "INQ_FLUSH_LOCI": "3000"},
-                {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "3", "INQ_INFLATE_AHEAD": "0"}, {"INQ_FRONTEND": "host"}):
-        r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, **env))
+    for env, extra in (({"INQ_FRONTEND": "device"}, []), ({"INQ_FRONTEND": "device", "INQ_SPAN_MB": "16", "INQ_FLUSH_LOCI": "3000"}, []),
+                       ({"INQ_FRONTEND": "device", "INQ_SPAN_MB": "3"}, ["--ctx-option", "inflate_ahead=0", "--ctx-option=gather_nt=0"]),
+                       ({"INQ_FRONTEND": "host"}, [])):
+        r = subprocess.run(cmd + extra, capture_output=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-500:]
-        assert r.stdout == want.stdout, f"rows differ with {env}"
+        assert r.stdout == want.stdout, f"rows differ with {env} {extra}"
+    bad = subprocess.run(cmd + ["--ctx-option", "inflate_ahead"], capture_output=True)
+    assert bad.returncode == 2 and b"--ctx-option" in bad.stderr
+    bad = subprocess.run(cmd + ["--ctx-option", "no_such=1"], capture_output=True)
+    assert bad.returncode == 2 and b"no such option" in bad.stderr
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])

@@ -750,17 +750,25 @@ def test_many_spans_with_staged_uploads_equal_the_host_front_end(tmp_path, monke
     prefix = str(tmp_path / "w")
     make_synth_bam.write("unphased100k", 20_000, prefix)
     texts = {}
-    for name, env in (("host", {"INQ_FRONTEND": "host"}), ("device64", {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "64"}),
-                      ("device64_inflated_when_staged", {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "64", "INQ_INFLATE_AHEAD": "1"}),
-                      ("device", {"INQ_FRONTEND": "device"}), ("auto", {})):
-        for k in ("INQ_FRONTEND", "INQ_SPAN_MB", "INQ_INFLATE_AHEAD"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        out = tmp_path / f"{name}.inq"
-        with open(out, "w") as f:
-            call.genotype_repeats(prefix + ".bam", None, prefix + ".bed", 5, 3, 8, True, "S", None, out=f)
-        texts[name] = out.read_text()
+    L = call.load()
+    try:
+        # (the span is inflated when it is staged - option "inflate_ahead", the default - or when it is called: set for the contexts
+        # the host library makes through inq_host_ctx_option, the library reads no such switch from the environment)
+        for name, env, ahead in (("host", {"INQ_FRONTEND": "host"}, 1), ("device64", {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "64"}, 0),
+                                 ("device64_inflated_when_staged", {"INQ_FRONTEND": "device", "INQ_SPAN_MB": "64"}, 1),
+                                 ("device", {"INQ_FRONTEND": "device"}, 1), ("auto", {}, 1)):
+            for k in ("INQ_FRONTEND", "INQ_SPAN_MB"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            assert L.inq_host_ctx_option(b"inflate_ahead", ahead) == 0
+            out = tmp_path / f"{name}.inq"
+            with open(out, "w") as f:
+                call.genotype_repeats(prefix + ".bam", None, prefix + ".bed", 5, 3, 8, True, "S", None, out=f)
+            texts[name] = out.read_text()
+    finally:
+        L.inq_host_ctx_option(b"inflate_ahead", 1)
+    assert L.inq_host_ctx_option(b"no_such_option", 1) == 1 and L.inq_host_ctx_option(b"inflate_algo", 7) == 1
     assert texts["host"] == texts["device64"] == texts["device64_inflated_when_staged"] == texts["device"] == texts["auto"]
     rows = texts["host"].splitlines()
     assert len(rows) == 20_001 and not any(r.endswith("NaN\tNaN") for r in rows[1:])

@@ -373,6 +373,82 @@ def test_very_deep_loci_at_the_edges_of_the_clip_rule(ctx, orc, seed, unphased):
     assert ng > 10_000
 
 
+@pytest.mark.parametrize("unphased", [False, True])
+@pytest.mark.parametrize("spread", ["one_value", "two_bytes", "five_bytes", "negative_and_huge"])
+def test_very_deep_locus_with_calls_of_every_spread(ctx, orc, unphased, spread):
+    """The grid-wide select (csrc/deep_select.hip) works on keys rebased to the locus' smallest Call and starts at the most
+    significant byte their spread reaches: a 70 000-read locus whose Calls are all EQUAL (one pass over a single bin), spread over
+    two bytes, over five (several 28-bit insertions per read: Calls beyond 2^32), and from large negative (deletions) to huge
+    positive - next to a second very deep locus of ordinary spread, so that loci of different pass counts share the passes.
+    Exact against the oracle, per-pair outputs included, for support 3 and for a support that makes the clip rule bite."""
+    import random
+
+    rng = random.Random({"one_value": 1, "two_bytes": 2, "five_bytes": 3, "negative_and_huge": 4}[spread])
+    big = (1 << 28) - 1
+    start, end = 800_000, 800_100
+
+    def cigar():
+        if spread == "one_value":
+            return [("M", 150), ("I", 17), ("M", 200)]
+        if spread == "two_bytes":
+            return [("M", 150), ("I", rng.randint(6, 40_000)), ("M", 200)]
+        if spread == "five_bytes":
+            return [("M", 150)] + [x for _ in range(rng.choice([0, 1, 3, 9])) for x in (("I", rng.choice([big, 1 << 24, 77])), ("M", 1))] + [("M", 200)]
+        if rng.random() < 0.5:  # a deletion inside the window, nothing else
+            return [("M", 140), ("D", rng.choice([6, 2000, 60_000])), ("M", 300)]
+        return [("M", 150)] + [x for _ in range(rng.choice([1, 5])) for x in (("I", big), ("M", 1))] + [("M", 200)]
+
+    for support in (3, 20_000):
+        bb = B.BatchBuilder(minlen=5, support=support, unphased=unphased)
+        ids = []
+        for k in range(70_000):
+            cig = cigar()
+            if k % 9 == 0:
+                cig = [("S", 30)] + cig  # a soft clip that counts: the read starts inside the window (phased mode keeps it)
+            pos = start - 10 - 100 if cig[0][0] != "S" else start + 5
+            ids.append(bb.add_read(pos, B.encode_cigar(cig), mapq=60, phase=rng.choice([1, 2, 2]), is_2d=False))
+        ordinary = gen.random_locus_reads(rng, start + 3000, end + 3000, 200, long_every=11)
+        ids2 = [bb.add_read(r.pos, B.encode_cigar(r.cigar), mapq=60, phase=rng.choice([1, 2]), reverse=bool(r.flag & 0x10))
+                for r in (ordinary[rng.randrange(len(ordinary))] for _ in range(66_500))]
+        order = sorted(range(len(ids)), key=lambda i: (bb._reads[ids[i]][2], i))
+        order2 = sorted(range(len(ids2)), key=lambda i: (bb._reads[ids2[i]][2], i))
+        bb.add_locus(start, end, [ids[i] for i in order])
+        bb.add_locus(start + 3000, end + 3000, [ids2[i] for i in order2])
+        bb.add_locus(start + 9000, start + 9050, ids[100:130])
+        batch = bb.build()
+        rc, got = ctx.call_batch(batch, debug=True)
+        oc, want = orc.call_batch(batch, debug=True, threads=8)
+        assert rc == oc == 0
+        _assert_same(got, want, f"spread={spread} unphased={unphased} support={support}")
+        if spread == "five_bytes":
+            assert np.abs(want.pair_call).max() > (1 << 31)
+        if support == 3:
+            assert not np.isnan(got.phase2[0]) and not np.isnan(got.phase2[1])
+
+
+def test_allocation_that_meets_out_of_memory_frees_the_parked_buffers_and_tries_again(orc):
+    """ensure() parks a buffer it has outgrown instead of freeing it (no wait for the device); an allocation that then fails for lack
+    of memory must give those back and try again rather than fail the call.  The failure is injected ("test_fail_allocs":
+    the next N allocations see out-of-memory at their first attempt); growing batches make the context outgrow and park its buffers;
+    every call must still return the oracle's rows, the retries must have happened, and with "retired_limit_mb" = 0 nothing stays parked."""
+    from inquistr_amd import hipcall
+
+    with hipcall.Context(0) as c:
+        wl = synth.WORKLOADS["phased10k"]
+        for round_, (n_loci, fail) in enumerate(((64, 0), (700, 5), (3000, 50), (3001, 0))):
+            batch = synth.generate_numpy(wl, 0, n_loci)
+            if round_ == 2:
+                c.set_option("retired_limit_mb", 0)
+            c.set_option("test_fail_allocs", fail)
+            before = c.alloc_retries
+            rc, got = c.call_batch(batch, debug=True)
+            oc, want = orc.call_batch(batch, debug=True)
+            assert rc == oc == 0
+            _assert_same(got, want, f"round {round_}")
+            assert c.alloc_retries - before >= min(fail, 1) * 2  # the injected failure and the second attempt
+        c.set_option("test_fail_allocs", 0)
+
+
 def test_domain_errors(ctx, orc):
     def one(**kw):
         bb = B.BatchBuilder(**{k: v for k, v in kw.items() if k in ("minlen", "support", "unphased")})

@@ -7,8 +7,9 @@ OUT=$ROOT/gpurun_out/prof_cli_locus
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/tools/make_synth_bam.py unphased100k 100000 /tmp/cli_prof native 6 > $OUT/gen.log 2>&1 || { tail $OUT/gen.log; exit 1; }
-export INQ_FRONTEND=device INQ_FAST_EXIT=0 INQ_INFLATE_AHEAD=0 INQ_CALL_AGAIN=1
-CLI="$ROOT/inquistr_amd/lib/inquistr call /tmp/cli_prof.bam -R /tmp/cli_prof.bed -t 16 -u --sample-name S"
+# INQ_CALL_AGAIN is read by a measurement build only: make -C inquistr_amd/csrc -B DEBUG_ENV=1 (and rebuild without it afterwards)
+export INQ_FRONTEND=device INQ_FAST_EXIT=0 INQ_CALL_AGAIN=1
+CLI="$ROOT/inquistr_amd/lib/inquistr call /tmp/cli_prof.bam -R /tmp/cli_prof.bed -t 16 -u --sample-name S --ctx-option inflate_ahead=0"
 i=0
 # (one set only: the TCP_UTCL1_* / TCC_EA0_* sets made rocprofv3 abort and the run hang on this pool - round 4 lost eight GPU-minutes to it)
 for set in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
