@@ -93,6 +93,86 @@ PCIE_SPEC_GBS = 64.0  # PCIe Gen5 x16, one direction, before protocol overhead (
 GPU_REST_S = float(os.environ.get("INQ_BENCH_REST_S", "1.2"))
 
 
+class BackgroundGen:
+    """The large SEQ-bearing BAM of the l2_seq_large block, written by a child process (tools/make_synth_bam.py, niced) from the first
+    second of the run - 31 GB at zlib level 6 are ~2 core-hours/60 - and STOPPED (SIGSTOP to its process group) during every timed
+    region of this script: it makes progress while this process generates inputs, runs the profiler's child passes, and above all
+    during the rests in front of every timed GPU process (1.2 s each, some fifty of them).  r4 wrote the file in 114 s of a 303 s run
+    with everything else waiting."""
+
+    def __init__(self, workload: str, loci: int, level: int, directory: str):
+        import signal
+
+        self._sig = signal
+        self.loci, self.level = loci, level
+        self.prefix = os.path.join(directory, f"{workload}_{loci}")
+        self.t0 = time.perf_counter()
+        self.paused_s, self._t_pause = 0.0, None
+        self.log = open(self.prefix + ".gen.log", "w")
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "make_synth_bam.py"), workload, str(loci), self.prefix, "native-seq", str(level)]
+        self.p = subprocess.Popen(cmd, stdout=self.log, stderr=subprocess.STDOUT, start_new_session=True, preexec_fn=lambda: os.nice(19), cwd=ROOT)
+        self.seconds = None
+
+    def _kill(self, sig):
+        try:
+            os.killpg(self.p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def pause(self):
+        if self.p.poll() is None and self._t_pause is None:
+            self._kill(self._sig.SIGSTOP)
+            self._t_pause = time.perf_counter()
+
+    def resume(self):
+        if self._t_pause is not None:
+            self.paused_s += time.perf_counter() - self._t_pause
+            self._t_pause = None
+            self._kill(self._sig.SIGCONT)
+
+    def wait(self, timeout: float):
+        """True when the file is there; the child gets the machine to itself for what is left."""
+        self.resume()
+        try:
+            rc = self.p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            self.abort()
+            return False
+        if self.seconds is None:
+            self.seconds = time.perf_counter() - self.t0
+        self.log.close()
+        return rc == 0 and os.path.exists(self.prefix + ".bam")
+
+    def abort(self):
+        self._kill(self._sig.SIGCONT)
+        self._kill(self._sig.SIGKILL)
+        try:
+            self.p.wait(timeout=30)
+        except Exception:  # noqa: BLE001
+            pass
+
+
+BG = None  # the running BackgroundGen, if any
+
+
+def bg_pause():
+    if BG is not None:
+        BG.pause()
+
+
+def bg_resume():
+    if BG is not None:
+        BG.resume()
+
+
+def rest_then_quiet(seconds: float):
+    """The rest in front of a timed GPU process: the background generator works through it and is stopped when it ends."""
+    bg_resume()
+    if seconds > 0:
+        time.sleep(seconds)
+    bg_pause()
+
+
 def h2d_copy_peak(dev, mb: int = 256, reps: int = 6):
     """What the host-to-device link delivers on this box, measured in this run: one pinned buffer of a span's size (256 MB) copied
     to the device `reps` times on a stream of its own, HIP events around each copy, best and median.  The `pcie` roofline objects
@@ -121,7 +201,7 @@ def h2d_copy_peak(dev, mb: int = 256, reps: int = 6):
             "what": f"pinned host -> device copy of {mb} MB, best of {reps} (HIP events), measured in this run"}
 
 
-def startup_floor(reps: int = 5):
+def startup_floor(reps: int = 3):
     """What ANY process that launches one kernel on this box pays: tools/hip_startup_probe.hip (hipInit, a stream, one empty kernel,
     three allocations, one small copy - nothing of this repo), whole process from start to exit, measured in this run.  Printed
     beside every whole-process time of the L2 blocks: the difference is what the product adds."""
@@ -132,7 +212,7 @@ def startup_floor(reps: int = 5):
         return None
     ts, stages = [], None
     for _ in range(reps):
-        time.sleep(GPU_REST_S)
+        rest_then_quiet(GPU_REST_S)
         t = time.perf_counter()
         r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
         ts.append(time.perf_counter() - t)
@@ -199,7 +279,8 @@ def l1_block(wl, dev_index: int, loci: int = 50_000, reps: int = 5):
 
 
 def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_loci: int = 10_000, c_loci: int = 2_000, seq: bool = False,
-             level: int = 6, lean: bool = False, served_callers: int = 0, cohort: bool = True, floor=None, h2d=None, trace_runs: int = 1):
+             level: int = 6, lean: bool = False, served_callers: int = 0, cohort: bool = True, floor=None, h2d=None, trace_runs: int = 1,
+             ready_prefix: str = "", ready_gen_s: float = 0.0, b2b_runs: int = 3):
     """End to end (BAM + BED -> .inq) next to the reference-shaped CPU programs, small enough for the default run.
     Product CLI with the device front end: median of `reps` whole-process wall times (HIP start-up included; the CLI
     leaves through _Exit once the rows are written).  CPU side = oracle/ref_shaped_call, the reference's control flow
@@ -223,13 +304,18 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
     from tools import make_synth_bam
 
     wl = synth.WORKLOADS[workload]
-    tmp = tempfile.mkdtemp(prefix="inq_l2_")
-    prefix = os.path.join(tmp, f"{workload}_{loci}")
+    tmp = os.path.dirname(ready_prefix) if ready_prefix else tempfile.mkdtemp(prefix="inq_l2_")
+    prefix = ready_prefix or os.path.join(tmp, f"{workload}_{loci}")
     try:
         t0 = time.perf_counter()
         info = {}
-        make_synth_bam.write_native(workload, loci, prefix, threads=host_cores_available(), device=device, seq=seq, level=level, info=info)
-        gen_s = time.perf_counter() - t0
+        if ready_prefix:  # written beside the earlier blocks (BackgroundGen)
+            gen_s = ready_gen_s
+        else:
+            bg_resume()  # (writing this block's own file is no measurement: the large file's writer shares the cores)
+            make_synth_bam.write_native(workload, loci, prefix, threads=host_cores_available(), device=device, seq=seq, level=level, info=info)
+            gen_s = time.perf_counter() - t0
+        bg_pause()
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
         cli = os.path.join(ROOT, "inquistr_amd", "lib", "inquistr")
         ref = os.path.join(ROOT, "oracle", "ref_shaped_call")
@@ -243,7 +329,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
 
         def run(cmd, env=None, timeout=None, rest=0.0):
             if rest:
-                time.sleep(rest)
+                rest_then_quiet(rest)
             t = time.perf_counter()
             r = subprocess.run(cmd, capture_output=True, env=env, timeout=timeout)
             dt = time.perf_counter() - t
@@ -262,7 +348,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         dev = [run(cmd, dict(os.environ, INQ_FRONTEND="device"), rest=GPU_REST_S) for _ in range(reps)]
         t_dev = statistics.median(t for t, _ in dev)
         out_dev = dev[0][1]
-        b2b = [run(cmd, dict(os.environ, INQ_FRONTEND="device")) for _ in range(3)]  # ... and without the rest, each behind the last one's exit
+        b2b = [run(cmd, dict(os.environ, INQ_FRONTEND="device")) for _ in range(b2b_runs)]  # ... and without the rest, each behind the last one's exit
         t_host, out_host = (None, None) if lean else run(cmd, dict(os.environ, INQ_FRONTEND="host"), rest=GPU_REST_S)
         rows = out_dev.splitlines(keepends=True)
         bam_bytes = os.path.getsize(prefix + ".bam")
@@ -287,12 +373,12 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
             tb2, out_b2 = run([ref, prefix + ".bam", prefix + ".bed", "B", str(all_cores)] + args_tail)
             res["cpu_B_all_cores"] = {"seconds": tb2, "loci": loci, "loci_per_s": loci / tb2, "cores": all_cores, "inq_identical": out_b2 == out_dev}
         # the device front end's own stage times for this file (HIP events / host clocks inside the CLI, one extra run)
-        time.sleep(GPU_REST_S)
+        rest_then_quiet(GPU_REST_S)
         r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="2"))
         res["device_front_stages"] = stage_summary(r.stderr.decode(), bam_bytes)
         loops = [res["device_front_stages"].get("span_loop_s")]
         for _ in range(max(0, trace_runs - 1)):  # more samples of the span loop's own time (INQ_TIMING=1: one line per run)
-            time.sleep(GPU_REST_S)
+            rest_then_quiet(GPU_REST_S)
             r2 = subprocess.run(cmd, capture_output=True, env=dict(os.environ, INQ_FRONTEND="device", INQ_TIMING="1"))
             loops.append(stage_summary(r2.stderr.decode(), bam_bytes).get("span_loop_s"))
         loops = [x for x in loops if x]
@@ -437,6 +523,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         import shutil
 
         shutil.rmtree(tmp, ignore_errors=True)
+        bg_resume()  # behind the block's timed regions the large file's writer goes on
 
 
 def stage_summary(stderr_text: str, bam_bytes: int):
@@ -550,6 +637,50 @@ def l2_end_to_end(workload: str, loci: int, threads: int, reps: int, keep: str =
             "note": "CPU modes = oracle/ref_shaped_call: CPU restatement of the reference's control flow, not the Rust binary"}
 
 
+def l0_config(ctx, dev, stream, workload: str, n_loci: int, what: str, reps: int = 10):
+    """L0 of one more BASELINE workload in the running process: the batch generated on the device, 3 + `reps` launches with the
+    generator's depth as the hint, HIP events around the first kernel and the whole sequence, wall clock around the `reps`."""
+    import torch
+
+    from inquistr_amd import synth
+
+    w = synth.WORKLOADS[workload]
+    n = n_loci or w.n_loci
+    bg_resume()
+    shard = synth.DeviceBatch(w, dev, 0, n)
+    bg_pause()
+    try:
+        ctx.set_option("max_reads_hint", w.reads_per_locus)
+        for _ in range(3):
+            ctx.call_batch_device(shard.c_batch, shard.c_result, stream.cuda_stream)
+        torch.cuda.synchronize()
+        rc, _ = ctx.status()
+        if rc != 0:
+            raise RuntimeError(f"device status {rc}")
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.call_batch_device(shard.c_batch, shard.c_result, stream.cuda_stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        k_ms, nl = ctx.timing_read(1)
+        s_ms, _ = ctx.timing_read(0)
+        ctx.timing_enable(False)
+        rc, ties = ctx.status()
+        if rc != 0:
+            raise RuntimeError(f"device status {rc}")
+        alg = shard.algorithmic_bytes()
+        return {"what": what, "loci": n, "pairs": shard.n_pairs, "cigar_ops": shard.n_ops_total, "unphased": bool(w.unphased),
+                "value": n * reps / dt, "unit": "loci/s", "ms_per_step": dt * 1e3 / reps, "avg_kernel_ms": k_ms / nl,
+                "avg_launch_sequence_ms": s_ms / nl, "algorithmic_bytes": alg, "achieved_GBps": alg / (k_ms / nl * 1e-3) / 1e9,
+                "frac": alg / (k_ms / nl * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": nl, "n_tie_loci": ties}
+    finally:
+        del shard
+        torch.cuda.empty_cache()
+        bg_resume()
+
+
 def live_traffic(workload: str, per_gpu: int):
     """HBM bytes per launch of the hot kernel from the PMC counters, collected IN THIS RUN: two child processes under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no trace domains, as /opt/skills/guides/MI355X_MICROARCH.md
@@ -568,7 +699,7 @@ def live_traffic(workload: str, per_gpu: int):
         d = tempfile.mkdtemp(prefix="inq_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2",
-                   "--workload", workload, "--loci-per-gpu", str(per_gpu), "--no-cpu-baseline", "--no-l2", "--no-read-peak", "--no-live-pmc"]
+                   "--workload", workload, "--loci-per-gpu", str(per_gpu), "--no-cpu-baseline", "--no-l2", "--no-read-peak", "--no-live-pmc", "--no-l0-configs"]
             # (its own process group, so that a profiler that hangs is ended together with the program it started)
             pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), start_new_session=True)
             try:
@@ -831,7 +962,10 @@ def main():
     ap.add_argument("--l2-seq-large-loci", type=int, default=-1,
                     help="loci of the large SEQ / QUAL-bearing BAM of the default line's l2_seq_large block (0.32 GB per 1 000 loci; north_star's "
                          "configuration is 100 000 = 32 GB); -1 = the largest size up to 100 000 that disk, page cache and --l2-seq-large-gen-budget admit; 0 skips it")
-    ap.add_argument("--l2-seq-large-gen-budget", type=float, default=130.0, help="seconds the default line may spend WRITING the large file")
+    ap.add_argument("--l2-seq-large-gen-budget", type=float, default=130.0,
+                    help="seconds of all granted cores the large file may cost to write (it is written by a child process beside the earlier blocks, stopped during every timed region)")
+    ap.add_argument("--no-l2-phased", action="store_true", help="skip the l2_phased block (config #2's shape as a SEQ-bearing file, phased: the reference's default mode)")
+    ap.add_argument("--no-l0-configs", action="store_true", help="skip the per-config L0 figures (phased10k, expansion50k, shard500k / 8)")
     ap.add_argument("--l2-level", type=int, default=6, help="zlib level of the BAMs the l2 blocks are timed on (6 = htslib's default)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: the workload's n_loci are split over the ranks (config #4: --workload shard500k --scaling strong)")
@@ -886,6 +1020,40 @@ def main():
             dist.init_process_group("gloo")
 
     wl = synth.WORKLOADS[args.workload]
+    global BG
+    large_plan = None
+    if world == 1 and not args.no_l2 and not args.no_l2_seq and args.l2_seq_large_loci != 0:
+        # The large SEQ-bearing file (north_star's configuration: 100 000 loci x 30 reads of long-read records = 31 GB at level 6) is
+        # written by a child process from now on, beside everything up to its own block.  Its size: the largest up to 100 000 loci
+        # that (a) disk and page cache admit and (b) the granted cores deflate within --l2-seq-large-gen-budget seconds at
+        # ~55 loci per second and core (measured: 880 loci/s on 16 cores at level 6; level 1 is ~3 x that).
+        import shutil
+        import tempfile
+
+        want = args.l2_seq_large_loci if args.l2_seq_large_loci > 0 else 100_000
+        chosen_by = "--l2-seq-large-loci" if args.l2_seq_large_loci > 0 else "north_star's 100 000 loci"
+        if args.l2_seq_large_loci < 0:
+            rate = (55.0 if args.l2_level >= 4 else 160.0) * host_cores_available()
+            if want > rate * args.l2_seq_large_gen_budget:
+                want = int(rate * args.l2_seq_large_gen_budget) // 1000 * 1000
+                chosen_by = (f"generation budget: {args.l2_seq_large_gen_budget:.0f} s at ~{rate:.0f} loci/s written "
+                             f"(level {args.l2_level}, {host_cores_available()} cores)")
+        free = shutil.disk_usage(tempfile.gettempdir()).free
+        try:
+            avail = int(next(ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")).split()[1]) * 1024
+        except Exception:  # noqa: BLE001
+            avail = 0
+        per_locus = 0.33e6 * 1.3
+        cap = int(min(free / per_locus, avail / (2 * per_locus))) // 1000 * 1000
+        if cap < want:
+            want, chosen_by = cap, f"disk / page cache: {free / 1e9:.0f} GB free in {tempfile.gettempdir()}, {avail / 1e9:.0f} GB of memory available"
+        want = min(want, wl.n_loci)
+        large_plan = {"loci": want, "chosen_by": chosen_by}
+        if want >= 5_000:
+            try:
+                BG = BackgroundGen(wl.name, want, args.l2_level, tempfile.mkdtemp(prefix="inq_l2_large_"))
+            except Exception as e:  # noqa: BLE001
+                large_plan["error"] = f"{type(e).__name__}: {e}"
     if args.scaling == "strong":
         # total work fixed: the workload's loci are cut into `world` contiguous shards (config #4: 500 000 / N per rank);
         # every rank allocates the largest shard size so the gather buffers are rectangular
@@ -975,6 +1143,7 @@ def main():
                 pending.pop(0).wait()
         torch.cuda.synchronize()
 
+    bg_pause()  # the timed loop has the host to itself
     for i in range(args.warmup):
         step(i)
     drain()
@@ -1004,6 +1173,30 @@ def main():
     rc, ties = ctx.status()
     if rc != 0:
         raise SystemExit(f"device status {rc}: {hipcall.strerror(rc)}")
+    # The same launch WITHOUT the caller's depth hint: an external caller of inq_call_batch_device that does not know its deepest
+    # locus gets two more launches behind the first kernel (locus_call_mid_walk and the persistent locus_call_tail, which find
+    # empty work lists and leave; round 4: ~38 launches, 0.15 ms).  Same batch, same stream, HIP events around the whole sequence.
+    no_hint = None
+    if world == 1:
+        ctx.set_option("max_reads_hint", 0)
+        for i in range(3):
+            ctx.call_batch_device(shard.c_batch, results[0][0], main_stream.cuda_stream)
+        torch.cuda.synchronize()
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        n_nh = max(5, min(args.steps, 20))
+        for i in range(n_nh):
+            ctx.call_batch_device(shard.c_batch, results[0][0], main_stream.cuda_stream)
+        torch.cuda.synchronize()
+        nh_seq, nh_n = ctx.timing_read(0)
+        nh_k, _ = ctx.timing_read(1)
+        ctx.timing_enable(False)
+        rc2, _t = ctx.status()
+        if rc2 != 0:
+            raise SystemExit(f"device status {rc2} without the depth hint: {hipcall.strerror(rc2)}")
+        ctx.set_option("max_reads_hint", wl.reads_per_locus)
+        no_hint = {"avg_launch_sequence_ms": nh_seq / nh_n, "avg_kernel_ms": nh_k / nh_n, "launches_timed": nh_n}
+    bg_resume()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -1099,14 +1292,35 @@ def main():
             line["gather"] = {"collective": f"dist.gather ({args.backend})", "bytes_per_rank_per_collective": int(G * 2 * per_gpu * 8),
                               "collectives": (args.steps + G - 1) // G,
                               "exposed_ms_total_max_over_ranks": max(p["gather_exposed_ms_total"] for p in per_rank)}
+        if no_hint:
+            # what an external caller of inq_call_batch_device pays when it cannot promise a depth
+            line["roofline"]["avg_launch_sequence_ms_no_hint"] = no_hint["avg_launch_sequence_ms"]
+            line["roofline"]["frac_no_hint"] = alg_bytes / (no_hint["avg_launch_sequence_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            line["roofline"]["no_hint"] = dict(no_hint, launches_per_sequence=3, over_hinted_sequence=no_hint["avg_launch_sequence_ms"] / (seq_ms / max(1, launches)),
+                                               what="the same launches without max_reads_hint: locus_call_small + locus_call_mid_walk + the persistent locus_call_tail "
+                                                    "(both find empty work lists and leave); frac_no_hint = algorithmic bytes / that whole sequence / 8 TB/s")
         if world == 1 and not args.no_read_peak:
             pk = measured_read_peak()
             if pk:
                 line["roofline"]["peak_measured"] = pk
                 line["roofline"]["frac_of_measured"] = achieved / pk["value"]
+        if world == 1 and not args.no_l0_configs:
+            # loci/s and roofline fraction per workload, a few timed launches each in this same process (the headline
+            # workload is the line itself); config #4 as ONE of its eight shards (62 500 loci: what one GPU of the node holds)
+            line["l0_configs"] = {}
+            for name, n_cfg, what in (("phased10k", 0, "config #2"), ("expansion50k", 0, "config #5"), ("shard500k", 500_000 // 8, "config #4, one of 8 shards")):
+                if name == wl.name:
+                    continue
+                try:
+                    line["l0_configs"][name] = l0_config(ctx, dev, main_stream, name, n_cfg, what)
+                except Exception as e:  # noqa: BLE001
+                    line["l0_configs"][name] = {"error": f"{type(e).__name__}: {e}"}
+            ctx.set_option("max_reads_hint", wl.reads_per_locus)
         if world == 1 and not args.no_cpu_baseline:
+            bg_pause()
             n_s = min(args.cpu_sample_loci, n_mine)
             want, line["cpu_baseline"] = cpu_baseline(wl, n_s)
+            bg_resume()
             # the rows the timed steps left on the device for those loci against the oracle's, bit for bit
             lb, lg = state["last"]
             got = outs[lb][lg][:, :n_s].cpu().numpy()
@@ -1118,14 +1332,20 @@ def main():
                     raise SystemExit(f"parity: H{k + 1} of locus {int(np.argmin(same))} differs from the CPU oracle")
             line["parity_checked_loci"] = n_s
             line["parity"] = "rows of the cpu_baseline sample produced by the timed steps == CPU oracle rows (bit-exact, NaN == NaN)"
+        more_to_come = world == 1 and not args.no_l2
+        if more_to_come:
+            # The line as far as it exists - metric, roofline, cpu_baseline, the per-config L0 figures - goes out NOW: the end-to-end blocks
+            # below write and read tens of GB, and a box with a slow disk must not lose the headline with them.  The full line (a
+            # superset of this one) is printed last.
+            print(json.dumps(dict(line, partial="L0 + roofline + cpu_baseline; the full line with the end-to-end blocks follows")), flush=True)
         if world == 1 and not args.no_l2:
-            # The end-to-end blocks.  Files are written at zlib level 6 (htslib's default for BAM output); `l2_seq_level1` is the
-            # level-1 twin of `l2_seq` (rounds 1 - 3 wrote level 1), so that what the level does is visible in one line.
+            # The end-to-end blocks.  Files are written at zlib level 6 (htslib's default for BAM output).
             # At most three GPU processes at any time: this one, and either a CLI run or a server with its one caller.
             floor = None
             h2d = None
             try:
                 floor = startup_floor()
+                bg_pause()
                 h2d = h2d_copy_peak(dev)
             except Exception as e:  # noqa: BLE001
                 line["l2_probe_error"] = f"{type(e).__name__}: {e}"
@@ -1134,12 +1354,14 @@ def main():
             if h2d:
                 line["h2d_copy_peak"] = h2d
             try:
+                bg_pause()
                 line["l1"] = l1_block(wl, local_rank)
             except Exception as e:  # noqa: BLE001
                 line["l1"] = {"error": f"{type(e).__name__}: {e}"}
+            bg_resume()
             lvl = args.l2_level
             try:
-                line["l2"] = l2_block(wl.name, min(args.l2_default_loci, wl.n_loci), host_threads(), dev, level=lvl, floor=floor, h2d=h2d)
+                line["l2"] = l2_block(wl.name, min(args.l2_default_loci, wl.n_loci), host_threads(), dev, level=lvl, floor=floor, h2d=h2d, cohort=False)
             except Exception as e:  # noqa: BLE001  the L0 line above stays valid without it
                 line["l2"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_l2 and not args.no_l2_seq:
@@ -1148,50 +1370,43 @@ def main():
                                           level=lvl, cohort=False, floor=floor, h2d=h2d)
             except Exception as e:  # noqa: BLE001
                 line["l2_seq"] = {"error": f"{type(e).__name__}: {e}"}
-            if lvl != 1:
-                try:
-                    line["l2_seq_level1"] = l2_block(wl.name, min(args.l2_seq_default_loci, wl.n_loci), host_threads(), dev, reps=3, seq=True, level=1,
-                                                     lean=True, cohort=False, floor=floor, h2d=h2d)
-                except Exception as e:  # noqa: BLE001
-                    line["l2_seq_level1"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_l2 and not args.no_l2_seq and args.l2_seq_large_loci != 0:
-            # ... and on a file large enough for the process's fixed costs (the HIP runtime's start-up, 0.2 - 0.5 s) not to be the
-            # measurement: north_star's own configuration is 100 000 loci x 30 reads of long-read records = 32 GB of BAM.  The default
-            # line takes the largest size up to that which (a) disk and page cache admit and (b) can be WRITTEN within
-            # --l2-seq-large-gen-budget seconds at this level on the cores this box grants, estimated from the l2_seq file written a
-            # moment ago (zlib level 6 costs ~55 core-milliseconds per MB of records; 100 000 loci are ~3 core-hours/60);
-            # --l2-seq-large-loci 100000 forces the full configuration (profiles/r04_results/ holds such a run).
-            import shutil
-            import tempfile
-
-            want = args.l2_seq_large_loci if args.l2_seq_large_loci > 0 else 100_000
-            chosen_by = "--l2-seq-large-loci" if args.l2_seq_large_loci > 0 else "north_star's 100 000 loci"
-            if args.l2_seq_large_loci < 0:
-                small = line.get("l2_seq", {})
-                rate = small.get("loci", 0) / small["bam_gen_s"] if small.get("bam_gen_s") else 0.0  # loci written per second
-                if rate > 0 and want > rate * args.l2_seq_large_gen_budget:
-                    want = int(rate * args.l2_seq_large_gen_budget) // 1000 * 1000
-                    chosen_by = (f"generation budget: {args.l2_seq_large_gen_budget:.0f} s at {rate:.0f} loci/s written "
-                                 f"(level {lvl}, {host_cores_available()} cores)")
-            free = shutil.disk_usage(tempfile.gettempdir()).free
-            try:
-                avail = int(next(ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")).split()[1]) * 1024
-            except Exception:  # noqa: BLE001
-                avail = 0
-            per_locus = 0.33e6 * 1.3
-            cap = int(min(free / per_locus, avail / (2 * per_locus))) // 1000 * 1000
-            if cap < want:
-                want, chosen_by = cap, f"disk / page cache: {free / 1e9:.0f} GB free in {tempfile.gettempdir()}, {avail / 1e9:.0f} GB of memory available"
-            if want < 5_000:
-                line["l2_seq_large"] = {"skipped": f"no room or time for a large file ({chosen_by})"}
+        if world == 1 and not args.no_l2 and not args.no_l2_seq and not args.no_l2_phased:
+            try:  # PHASED - the reference's default mode (-u is opt-in, src/main.rs:55) - on config #2's shape as a SEQ-bearing file
+                wp = synth.WORKLOADS["phased10k"]
+                line["l2_phased"] = l2_block(wp.name, wp.n_loci, host_threads(), dev, reps=5, seq=True, level=lvl, lean=True, cohort=False,
+                                             floor=floor, h2d=h2d, trace_runs=3, b2b_runs=2)
+            except Exception as e:  # noqa: BLE001
+                line["l2_phased"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and large_plan is not None:
+            # ... and on a file large enough for the process's fixed costs (the HIP runtime's start-up, 0.15 - 0.2 s) not to be the
+            # measurement: north_star's own configuration is 100 000 loci x 30 reads of long-read records = 31 GB of BAM.  The file
+            # has been in the making since the first second of this run (BackgroundGen); what is left of it is written now.
+            if BG is None:
+                line["l2_seq_large"] = {"skipped": f"no room or time for a large file ({large_plan['chosen_by']})", **({"error": large_plan["error"]} if "error" in large_plan else {})}
             else:
                 try:
-                    line["l2_seq_large"] = l2_block(wl.name, min(want, wl.n_loci), host_threads(), dev, reps=5, seq=True, lean=True, level=lvl,
-                                                    cohort=False, floor=floor, h2d=h2d, trace_runs=5)
-                    line["l2_seq_large"]["size_chosen_by"] = chosen_by
+                    t_w = time.perf_counter()
+                    ok = BG.wait(timeout=max(60.0, 3.0 * args.l2_seq_large_gen_budget))
+                    waited = time.perf_counter() - t_w
+                    if not ok:
+                        raise RuntimeError("the large file's writer failed: " + open(BG.prefix + ".gen.log").read()[-300:])
+                    gen = BG
+                    BG = None  # (its process is gone: nothing to stop any more)
+                    line["l2_seq_large"] = l2_block(wl.name, large_plan["loci"], host_threads(), dev, reps=5, seq=True, lean=True, level=lvl,
+                                                    cohort=False, floor=floor, h2d=h2d, trace_runs=4, ready_prefix=gen.prefix, ready_gen_s=gen.seconds,
+                                                    b2b_runs=2)
+                    line["l2_seq_large"]["size_chosen_by"] = large_plan["chosen_by"]
+                    line["l2_seq_large"]["written"] = {"wall_s_start_to_done": gen.seconds, "of_which_stopped_s": gen.paused_s,
+                                                       "waited_for_it_at_the_end_s": waited,
+                                                       "how": "a niced child process from the first second of this run, stopped during every timed region"}
                 except Exception as e:  # noqa: BLE001
                     line["l2_seq_large"] = {"error": f"{type(e).__name__}: {e}"}
+                    if BG is not None:
+                        BG.abort()
+                        BG = None
         print(json.dumps(line), flush=True)
+    if BG is not None:
+        BG.abort()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
