@@ -109,7 +109,10 @@ class BackgroundGen:
         self.t0 = time.perf_counter()
         self.paused_s, self._t_pause = 0.0, None
         self.log = open(self.prefix + ".gen.log", "w")
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "make_synth_bam.py"), workload, str(loci), self.prefix, "native-seq", str(level)]
+        # two threads fewer than the cores the cgroup grants: a process group that uses its whole CPU quota is throttled for the rest of
+        # the scheduler's 100 ms period, and the timed process that starts right behind a rest would begin inside that hole
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "make_synth_bam.py"), workload, str(loci), self.prefix, "native-seq", str(level),
+               str(max(1, host_cores_available() - 2))]
         self.p = subprocess.Popen(cmd, stdout=self.log, stderr=subprocess.STDOUT, start_new_session=True, preexec_fn=lambda: os.nice(19), cwd=ROOT)
         self.seconds = None
 
@@ -168,9 +171,10 @@ def bg_resume():
 def rest_then_quiet(seconds: float):
     """The rest in front of a timed GPU process: the background generator works through it and is stopped when it ends."""
     bg_resume()
-    if seconds > 0:
-        time.sleep(seconds)
+    if seconds > 0.2:
+        time.sleep(seconds - 0.15)
     bg_pause()
+    time.sleep(min(0.15, max(seconds, 0.0)))  # a scheduler period without the generator in front of the timed process
 
 
 def h2d_copy_peak(dev, mb: int = 256, reps: int = 6):
@@ -312,7 +316,7 @@ def l2_block(workload: str, loci: int, threads: int, device, reps: int = 5, a_lo
         if ready_prefix:  # written beside the earlier blocks (BackgroundGen)
             gen_s = ready_gen_s
         else:
-            bg_resume()  # (writing this block's own file is no measurement: the large file's writer shares the cores)
+            bg_pause()  # (the cgroup grants a fixed number of cores: two writers at once only halve each other)
             make_synth_bam.write_native(workload, loci, prefix, threads=host_cores_available(), device=device, seq=seq, level=level, info=info)
             gen_s = time.perf_counter() - t0
         bg_pause()
@@ -1361,13 +1365,14 @@ def main():
             bg_resume()
             lvl = args.l2_level
             try:
-                line["l2"] = l2_block(wl.name, min(args.l2_default_loci, wl.n_loci), host_threads(), dev, level=lvl, floor=floor, h2d=h2d, cohort=False)
+                line["l2"] = l2_block(wl.name, min(args.l2_default_loci, wl.n_loci), host_threads(), dev, level=lvl, floor=floor, h2d=h2d, cohort=False,
+                                      a_loci=4_000, b2b_runs=2)
             except Exception as e:  # noqa: BLE001  the L0 line above stays valid without it
                 line["l2"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_l2 and not args.no_l2_seq:
             try:  # the same comparison on records shaped like a real long-read BAM (SEQ, QUAL, ML / MM, HP last)
                 line["l2_seq"] = l2_block(wl.name, min(args.l2_seq_default_loci, wl.n_loci), host_threads(), dev, a_loci=2_000, c_loci=300, seq=True,
-                                          level=lvl, cohort=False, floor=floor, h2d=h2d)
+                                          level=lvl, cohort=False, floor=floor, h2d=h2d, b2b_runs=2)
             except Exception as e:  # noqa: BLE001
                 line["l2_seq"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_l2 and not args.no_l2_seq and not args.no_l2_phased:

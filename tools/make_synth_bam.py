@@ -227,7 +227,7 @@ if __name__ == "__main__":
 
         n = write_native(sys.argv[1], int(sys.argv[2]), sys.argv[3], device=torch.device("cuda:0") if torch.cuda.is_available() else None,
                          seq=sys.argv[4] != "native", qual_mode=0 if sys.argv[4].endswith("random") else 1,
-                         level=int(sys.argv[5]) if len(sys.argv) > 5 else 1)
+                         level=int(sys.argv[5]) if len(sys.argv) > 5 else 1, threads=int(sys.argv[6]) if len(sys.argv) > 6 else 0)
     else:
         n = write(sys.argv[1], int(sys.argv[2]), sys.argv[3], seq=len(sys.argv) > 4 and sys.argv[4] == "seq")
     print(f"wrote {sys.argv[3]}.bam/.bai/.bed: {n} reads, {os.path.getsize(sys.argv[3] + '.bam') / 1e6:.1f} MB")
