@@ -518,6 +518,8 @@ __device__ __forceinline__ bool grid_barrier(DevStatus *st, uint32_t &epoch) {
     return ok != 0u;
 }
 
+}  // namespace
+
 // ---------------------------------------------------------------- the kernel
 template <bool UNPHASED>
 __global__ __launch_bounds__(256) void locus_call_tail(DeepArgs a) {
@@ -655,8 +657,6 @@ __global__ __launch_bounds__(256) void locus_call_tail(DeepArgs a) {
 #undef INQ_BARRIER
     leave();
 }
-
-}  // namespace
 
 size_t deep_select_scratch_bytes(uint64_t n_pairs) {
     const uint64_t cap = n_pairs / kGridSelectMin + 1u;

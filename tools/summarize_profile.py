@@ -92,4 +92,23 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
     for (k, c), v in sorted(pmc.items()):
         if k == small:
             f.write(f"| {c} | {statistics.mean(v):.0f} |\n")
+    # the other BASELINE configs, each traced on its own (tools/profile_round.sh): kernel stats next to the bench line of the traced run
+    for wl2 in ("phased10k", "expansion50k", "shard500k"):
+        ks, bl2 = os.path.join(src, f"kernel_stats_{wl2}.csv"), os.path.join(src, f"bench_line_{wl2}.json")
+        if not (os.path.exists(ks) and os.path.exists(bl2)):
+            continue
+        import shutil
+
+        shutil.copy(ks, os.path.join(dst, f"{tag}_kernel_stats_{wl2}.csv"))
+        try:
+            d2 = json.loads(open(bl2).read())
+        except Exception:  # noqa: BLE001
+            continue
+        rows2 = [r for r in csv.DictReader(open(ks)) if "locus_call_small" in r["Name"]]
+        f.write(f"\n## `--workload {wl2}` ({d2['config']['loci_per_gpu']} loci), `{tag}_kernel_stats_{wl2}.csv`\n\n")
+        for r in rows2:
+            f.write(f"`{r['Name'].split('(')[0]}`: {r['Calls']} dispatches, avg {float(r['AverageNs'])/1e3:.1f} us\n\n")
+        f.write(f"bench.py line of the traced run: value {d2['value']:.4g} loci/s, avg_kernel_ms {d2['roofline']['avg_kernel_ms']:.4f}, "
+                f"algorithmic bytes {d2['roofline']['algorithmic_bytes_per_launch']}, frac {d2['roofline']['frac']:.3f}"
+                + (f", no-hint sequence {d2['roofline'].get('avg_launch_sequence_ms_no_hint', 0):.4f} ms" if d2['roofline'].get('avg_launch_sequence_ms_no_hint') else "") + ".\n")
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())
