@@ -301,10 +301,7 @@ static int enqueue_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, vo
     const uint64_t blocks = (b->n_loci + 3) / 4;
     const uint32_t per_xcd = (uint32_t)((blocks + 7) / 8);
     const uint32_t grid_small = per_xcd * 8u;
-    // small launches: one locus per workgroup (option "small_split": -1 = by the batch's size, 0 / 1 = never / always)
-    const bool split = b->n_loci > 0 && (c->small_split < 0 ? b->n_loci <= kSplitMaxLoci : c->small_split != 0) && b->n_loci < 0x7fffff00ull;
-    const uint32_t per_xcd_split = split ? (uint32_t)((b->n_loci + 7) / 8) : 0u;
-    const uint32_t shard_cap = std::max((grid_small / kListShards + 1u) * 4u, per_xcd_split * 8u / kListShards + 1u);
+    const uint32_t shard_cap = (grid_small / kListShards + 1u) * 4u;
     if ((rc = ensure(c, c->worklist, (size_t)shard_cap * kListShards * 2 * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->sval, (size_t)b->n_pairs * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->smeta, (size_t)b->n_pairs)) != INQ_OK) return rc;
@@ -336,7 +333,6 @@ static int enqueue_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, vo
     a.sval = (int64_t *)c->sval.p;
     a.smeta = (uint8_t *)c->smeta.p;
     a.blocks_per_xcd = per_xcd;
-    a.blocks_per_xcd_split = per_xcd_split;
     a.shard_cap = shard_cap;
     const uint32_t hint = c->call_hint ? c->call_hint : c->max_reads_hint;
     c->call_hint = 0;
@@ -648,10 +644,6 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     }
     if (std::strcmp(key, "inflate_tokens") == 0) {
         c->inflate_tokens = value < 0 ? -1 : (value != 0);
-        return INQ_OK;
-    }
-    if (std::strcmp(key, "small_split") == 0) {
-        c->small_split = value < 0 ? -1 : (value != 0);
         return INQ_OK;
     }
     if (std::strcmp(key, "retired_limit_mb") == 0) {  // outgrown buffers parked before they are given back (default 16384)

@@ -42,7 +42,6 @@ struct inq_ctx {
     uint32_t max_reads_hint = 0;  // 0 = unknown; else the caller's bound on reads per locus
     uint32_t call_hint = 0;       // set by the host-buffer entry, which sees the offsets, for its own launch
     int nt_loads = -1;  // -1 auto: non-temporal when no read is shared between loci
-    int small_split = -1;  // -1 auto: batches of up to kSplitMaxLoci loci take one locus per workgroup (locus_call_small_split)
     bool timing = false;
     bool verify_crc = true;  // device front end: check inflated blocks against their CRC32
     // workgroup inflate: the counting passes leave the symbols behind for the commit (option "inflate_tokens").  Round 3 switched it on

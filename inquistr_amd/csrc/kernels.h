@@ -7,8 +7,6 @@ namespace inq {
 
 // Device-resident status block (one per ctx).
 constexpr int kListShards = 32;
-// batches of up to this many loci go through locus_call_small_split (kernels.hip): four waves per locus
-constexpr uint64_t kSplitMaxLoci = 24576;
 
 struct DevStatus {
     unsigned int err;           // ST_* bits OR-ed by the kernels
@@ -48,7 +46,6 @@ struct KArgs {
     int64_t *sval;       // [n_pairs]
     uint8_t *smeta;      // [n_pairs]
     uint32_t blocks_per_xcd;  // grid_small / 8
-    uint32_t blocks_per_xcd_split;  // > 0: the launch uses locus_call_small_split (one locus per workgroup), its grid / 8
     uint32_t shard_cap;       // loci one shard can list: every locus whose block has blockIdx % kListShards == shard
     uint32_t max_reads_hint;  // caller's promise (0 = none): no locus is offered more reads than this
 };

@@ -304,92 +304,6 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
     wave_locus<UNPHASED, AUX, 1>(a, j, p0, (int)n64, start, end, lane, lds[wave]);
 }
 
-// The same for SMALL launches: one locus per WORKGROUP, its reads dealt to the four waves in contiguous quarters (file order is kept:
-// slot = pair number inside the locus).  A launch of 10 000 loci is 10 000 waves on a chip that holds 8 192: one full round and a
-// tail round at a fifth of the occupancy, ~0.60 of the HBM peak (BASELINE config #2).  With four waves per locus the same launch is
-// 40 000 quarter-length waves - the tail is a twentieth, four times the loads are in flight during the ramp-up.  Each wave walks its
-// quarter exactly as above; the per-read Calls meet in LDS and wave 0 does the register reduce.  Chosen by the launcher for batches
-// of up to kSplitMaxLoci loci (measured crossover); large launches keep one wave per locus (no LDS hand-over, no
-// workgroup barrier, a longer stream per wave).
-struct SplitLds {
-    long long val[64];
-    unsigned int meta[64];
-};
-template <bool UNPHASED, int AUX>
-__global__ __launch_bounds__(256) void locus_call_small_split(KArgs a) {
-    __shared__ WaveLds lds[4];
-    __shared__ SplitLds sp;
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t j = xcd_remap(blockIdx.x, a.blocks_per_xcd_split);
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.status->bar_count.v = 0u, a.status->bar_abort.v = 0u, a.status->exit_ticket.v = 0u;
-    if (j >= a.n_loci) return;
-    const uint64_t p0 = a.locus_pair_off[j], p1 = a.locus_pair_off[j + 1];
-    const uint32_t start = a.locus_start[j], end = a.locus_end[j];
-    uint32_t status = 0;
-    if (p1 < p0 || p1 > a.n_pairs) status |= ST_INDEX;
-    if (start < 10u || end < start) status |= ST_LOCUS;
-    const uint64_t n64 = p1 - p0;
-    if (!status && a.max_reads_hint && n64 > a.max_reads_hint) status |= ST_HINT;
-    if (status) {  // block-uniform
-        if (threadIdx.x == 0) {
-            atomicOr(&a.status->err, status);
-            a.phase1[j] = qnan();
-            a.phase2[j] = qnan();
-        }
-        return;
-    }
-    if (n64 > 64ull) {
-        if (threadIdx.x == 0) {
-            const uint32_t kind = n64 > 64ull * kMediumSlots ? 1u : 0u;
-            const uint32_t shard = blockIdx.x % kListShards;
-            const uint32_t slot = atomicAdd(&a.status->list_count[kind][shard].n, 1u);
-            a.worklist[((uint64_t)kind * kListShards + shard) * a.shard_cap + slot] = (uint32_t)j;
-        }
-        return;
-    }
-    const int n = (int)n64;
-    const int q = (n + 3) / 4, first = (int)wave * q, cnt = max(0, min(q, n - first));
-    Window W;
-    W.se = start - 10u;
-    W.ee = end + 10u;
-    W.se1 = W.se + 1u;
-    W.width = W.ee - W.se1;
-    W.minlen = a.minlen;
-    BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
-    if (cnt > 0) {  // wave-uniform
-        bool valid;
-        int64_t v;
-        uint32_t me;
-        const PairMeta m = load_pair_meta(b, p0 + (uint64_t)first, cnt, lane, status, valid);
-        walk_pairs<UNPHASED, AUX>(b, m, valid, cnt, W, lane, status, lds[wave], v, me);
-        if (lane < cnt) {
-            sp.val[first + lane] = v;
-            sp.meta[first + lane] = me;
-            if (a.pair_call) a.pair_call[p0 + first + lane] = v;
-            if (a.pair_bits) a.pair_bits[p0 + first + lane] = (uint8_t)(me & 7u);
-        }
-    }
-    if (status) atomicOr(&a.status->err, status);  // per lane: index / phase errors belong to the lane's read
-    __syncthreads();
-    if (wave != 0u) return;
-    int64_t val[1] = {lane < n ? (int64_t)sp.val[lane] : 0};
-    uint32_t meta[1] = {lane < n ? sp.meta[lane] : 0u};
-    bool tie;
-    double out1, out2;
-    constexpr int64_t kFit = 1ll << (31 - LaneOrder<true, 1>::IDX_BITS);
-    const bool big_value = (meta[0] & PM_KEPT) && (val[0] < -kFit || val[0] >= kFit);
-    if (ballot64(big_value) == 0ull)
-        reduce_locus_in_lanes<UNPHASED, true, 1>(val, meta, lane, a.support, out1, out2, tie);
-    else
-        reduce_locus_in_lanes<UNPHASED, false, 1>(val, meta, lane, a.support, out1, out2, tie);
-    if (lane == 0) {
-        a.phase1[j] = out1;
-        a.phase2[j] = out2;
-        if (tie) atomicAdd((unsigned long long *)&a.status->ties, 1ull);
-    }
-}
-
 // Loci with 65..256 offered reads: still one wave per locus, four reads per lane.  Persistent waves
 // stride over the work list that locus_call_small filled.
 template <bool UNPHASED, int AUX>
@@ -498,8 +412,7 @@ __global__ __launch_bounds__(256) void locus_call_mid_walk(KArgs a) {
 template <bool UNPHASED, int AUX>
 static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, uint32_t grid_tail, hipStream_t s,
                      hipEvent_t ev_mid, void *deep_scratch) {
-    if (a.blocks_per_xcd_split) hipLaunchKernelGGL((locus_call_small_split<UNPHASED, AUX>), dim3(a.blocks_per_xcd_split * 8u), dim3(256), 0, s, a);
-    else if (grid_small) hipLaunchKernelGGL((locus_call_small<UNPHASED, AUX>), dim3(grid_small), dim3(256), 0, s, a);
+    if (grid_small) hipLaunchKernelGGL((locus_call_small<UNPHASED, AUX>), dim3(grid_small), dim3(256), 0, s, a);
     if (ev_mid) (void)hipEventRecord(ev_mid, s);
     // launches a promised depth makes pointless are skipped (a broken promise is flagged by locus_call_small)
     const uint32_t h = a.max_reads_hint;
