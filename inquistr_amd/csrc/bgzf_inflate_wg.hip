@@ -137,6 +137,9 @@ struct WgLds {
     // block-uniform state
     uint32_t P, out, status, last, type, eob, hlit, hdist, flag;
     uint32_t red[T / 64], red2[T / 64];
+#ifdef INQ_WG_PAD  // experiments only (tools/inflate_occupancy.sh): bytes of LDS nobody uses, so that fewer workgroups share a CU
+    uint32_t pad[INQ_WG_PAD / 4];
+#endif
 };
 
 // root values: < 32768 a byte of an earlier stretch (deflate distances are <= 32768), 32768 .. 32768 + kRoundCap a byte of
