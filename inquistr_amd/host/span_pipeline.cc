@@ -24,8 +24,9 @@ double stamp_ms() { return std::chrono::duration<double, std::milli>(std::chrono
 // runtime is up: it is read from sysfs for the device-th render node this process can really open.  INQ_NUMA_NODE=n overrides,
 // -1 switches all of it off; INQ_NUMA_CPUS=0 keeps the memory preference but lets the threads run anywhere.
 int guess_gpu_numa_node(int device) {
-    static std::mutex mu;
-    static std::map<int, int> memo;
+    // (never destroyed: a context thread that was given up on - AsyncCtx - may still come through here while the process exits)
+    static std::mutex &mu = *new std::mutex();
+    static std::map<int, int> &memo = *new std::map<int, int>();
     std::lock_guard<std::mutex> g(mu);
     auto it = memo.find(device);
     if (it != memo.end()) return it->second;

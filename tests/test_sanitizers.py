@@ -31,7 +31,7 @@ def test_host_front_end_under_asan_ubsan():
     env["INQ_FUZZ_TRIALS"] = "12"
     env["INQ_HOST_LIB"] = os.path.join(ROOT, "inquistr_amd", "lib", "libinquistr_host_asan.so")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_host_frontend.py", "tests/test_host_spans.py", "tests/test_outlier_oracle.py", "tests/test_csi_index.py",
-                        "tests/test_error_class.py", "tests/test_corrupt_inputs.py", "-x", "-q", "-k", "not cli",
+                        "tests/test_error_class.py", "tests/test_corrupt_inputs.py", "tests/test_multi_device.py", "-x", "-q", "-k", "not cli",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout
@@ -44,8 +44,9 @@ def _tsan_lib():
 
 @pytest.mark.skipif(_tsan_lib() is None, reason="ThreadSanitizer runtime not installed")
 def test_host_threads_under_tsan():
-    """The sweep front end's worker pool, the span loader's parallel reads and the lazily built index anchors (shared by the
-    span planner's helper thread and the loader) under ThreadSanitizer.  The CLI test is left out: it starts another program."""
+    """The sweep front end's worker pool, the span loader's parallel reads, the lazily built index anchors (shared by the
+    span planner's helper thread and the loader), the device parts of the multi-device entry and the bounded waits for a context
+    thread that never finishes under ThreadSanitizer.  The CLI test is left out: it starts another program."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "inquistr_amd", "host"), "../lib/libinquistr_host_tsan.so"],
                           stdout=subprocess.DEVNULL)
     env = dict(os.environ)
@@ -53,6 +54,7 @@ def test_host_threads_under_tsan():
     env["TSAN_OPTIONS"] = "halt_on_error=1:report_signal_unsafe=0"
     env["INQ_HOST_LIB"] = os.path.join(ROOT, "inquistr_amd", "lib", "libinquistr_host_tsan.so")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_host_frontend.py", "tests/test_host_spans.py", "tests/test_csi_index.py",
+                        "tests/test_multi_device.py",  # one thread per device part; waiters that give a dead context thread up
                         "-x", "-q", "-k", "not cli", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stdout + r.stderr, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout
