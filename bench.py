@@ -796,6 +796,27 @@ def l2_dist(args):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    line = l2_dist_core(args, rank, world, local_rank, dev, backend, args.l2_dist_loci, args.steps, args.warmup)
+    if rank == 0 and line is not None:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def l2_dist_core(args, rank, world, local_rank, dev, backend, loci, steps, warmup, native=True, cpu_b=True):
+    """The measurement of l2_dist() on a process group that exists already (the default `--gpus N` line carries it as its `l2_dist`
+    block, N > 1).  Returns the line (rank 0) or None."""
+    import statistics
+    import tempfile
+
+    import torch
+    import torch.distributed as dist
+
+    from inquistr_amd import call as hostcall  # noqa: F401
+    from inquistr_amd import call_dist, synth
+    from tools import make_synth_bam
+
+    result = None
     wl = synth.WORKLOADS[args.workload]
     threads = args.l2_threads or host_threads()
     # ---- the file: written once by rank 0 (all its cores), kept when --l2-keep names a directory
@@ -804,21 +825,27 @@ def l2_dist(args):
     if world > 1:
         dist.broadcast_object_list(box, src=0)
     tmp = box[0]
-    loci = min(args.l2_dist_loci, wl.n_loci)
+    loci = min(loci, wl.n_loci)
     prefix = os.path.join(tmp, f"{wl.name}_{loci}_seq{args.l2_level}")
     gen_s = 0.0
+    gen_err = [None]
     if rank == 0:
-        os.makedirs(tmp, exist_ok=True)
-        if not os.path.exists(prefix + ".bam"):
-            t0 = time.perf_counter()
-            make_synth_bam.write_native(wl.name, loci, prefix, threads=host_cores_available(), device=dev, seq=True, level=args.l2_level)
-            gen_s = time.perf_counter() - t0
-        for _ in range(2):  # page cache warm = read TWICE (the second read of a fresh file is the slow one: DESIGN.md 4)
-            with open(prefix + ".bam", "rb", buffering=0) as f:
-                while f.read(64 << 20):
-                    pass
+        try:
+            os.makedirs(tmp, exist_ok=True)
+            if not os.path.exists(prefix + ".bam"):
+                t0 = time.perf_counter()
+                make_synth_bam.write_native(wl.name, loci, prefix, threads=host_cores_available(), device=dev, seq=True, level=args.l2_level)
+                gen_s = time.perf_counter() - t0
+            for _ in range(2):  # page cache warm = read TWICE (the second read of a fresh file is the slow one: DESIGN.md 4)
+                with open(prefix + ".bam", "rb", buffering=0) as f:
+                    while f.read(64 << 20):
+                        pass
+        except Exception as e:  # noqa: BLE001  (disk full, ...): every rank must learn it, none may wait at the barrier
+            gen_err = [f"{type(e).__name__}: {e}"]
     if world > 1:
-        dist.barrier()
+        dist.broadcast_object_list(gen_err, src=0)
+    if gen_err[0]:
+        raise RuntimeError("writing the BAM failed on rank 0: " + gen_err[0])
     bam_bytes = os.path.getsize(prefix + ".bam")
     un = wl.unphased
     out_path = os.path.join(tmp, f"dist_rank0_{world}.inq")
@@ -828,14 +855,14 @@ def l2_dist(args):
             call_dist.genotype_repeats_distributed(prefix + ".bam", None, prefix + ".bed", wl.minlen, wl.support, threads, un, "S", out=f,
                                                    rank=rank, world=world, device=local_rank, frontend="device", stats=stats)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_pass({})
     per_step = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         st = {}
         one_pass(st)
         per_step.append(st)
@@ -867,15 +894,15 @@ def l2_dist(args):
         text = open(out_path, "rb").read()
         line = {
             "metric": "loci/sec genotyped (inquiSTR call, BAM + BED -> .inq end to end = L2, one process per GPU)",
-            "value": loci * args.steps / dt_max, "unit": "loci/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/i64",
+            "value": loci * steps / dt_max, "unit": "loci/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt_max * 1e3 / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/i64",
             "data": "synthetic",
             "config": {"workload": f"{wl.name}: {loci} loci x {wl.reads_per_locus} reads of long-read-shaped records (SEQ + QUAL + ML / MM, HP last), "
                                    f"{bam_bytes / 1e9:.1f} GB of BAM at zlib level {args.l2_level}, " + ("--unphased" if un else "phased (HP)") +
                                    f", inquistr_amd.call_dist at {world} rank(s), {backend} gather of 16 B per locus to rank 0",
                        "loci": loci, "bam_bytes": bam_bytes, "threads_per_rank": threads, "same_device": bool(args.same_device),
                        "bam_gen_s": gen_s},
-            "seconds_per_file": dt_max / args.steps,
+            "seconds_per_file": dt_max / steps,
             "per_rank": allr,
         }
         reads = [r["bam_bytes_read"] or 0 for r in allr]
@@ -885,7 +912,7 @@ def l2_dist(args):
         if loop:
             # conservative: all compressed bytes of a pass / the WHOLE pass (context creation, planning, rows, gather, text included) - the
             # ranks' span loops are short and need not coincide, so bytes / the longest loop would overstate what the links carried at once
-            agg = sum(reads) / 1e9 / (dt_max / args.steps)
+            agg = sum(reads) / 1e9 / (dt_max / steps)
             links = 1 if args.same_device else world
             line["pcie"] = {"bound": "pcie", "achieved": agg, "unit": "GB/s", "peak": PCIE_SPEC_GBS * links, "frac": agg / (PCIE_SPEC_GBS * links),
                             "span_loop_GBps_per_rank": [r.get("span_loop_GBps") for r in allr], "links": links,
@@ -909,12 +936,12 @@ def l2_dist(args):
         t_single = time.perf_counter() - t
         line["single_process_cli"] = {"seconds": t_single, "rc": r1.returncode}
         line["inq_identical_to_single_process"] = bool(r1.returncode == 0 and r1.stdout == text)
-        line["speedup_vs_single_process_cli"] = t_single / (dt_max / args.steps)
-        if not args.no_l2_dist_native:
+        line["speedup_vs_single_process_cli"] = t_single / (dt_max / steps)
+        if native and not args.no_l2_dist_native:
             devs = ",".join(str(0 if args.same_device else d) for d in range(world)) if world > 1 else (args.native_devices or "0")
             if "," in devs:
                 ts, ok = [], True
-                for _ in range(max(1, args.steps)):
+                for _ in range(max(1, steps)):
                     time.sleep(GPU_REST_S)
                     t = time.perf_counter()
                     rn = subprocess.run(base + ["--devices", devs], capture_output=True, env=dict(env, INQ_TIMING="1"), timeout=900)
@@ -925,7 +952,7 @@ def l2_dist(args):
                                           "inq_identical": bool(ok), "parts": parts,
                                           "what": "`inquistr call --devices " + devs + "`: ONE process, one thread + one device context per device, rows scattered in host "
                                                   "memory (no torch, no collective); whole process start to exit"}
-        if not args.no_cpu_baseline:
+        if cpu_b and not args.no_cpu_baseline:
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_shaped_call"], stdout=subprocess.DEVNULL)
             cores = host_cores_available()
             t = time.perf_counter()
@@ -937,14 +964,14 @@ def l2_dist(args):
                                     "sample": f"the whole file once: oracle/ref_shaped_call mode B (one reader per worker, own BGZF / BAM / BAI reader on zlib) on "
                                               f"{cores} threads - a CPU restatement of the reference's control flow, not the Rust binary"}
             line["speedup_vs_B"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
         if not args.l2_keep:
             import shutil
 
             shutil.rmtree(tmp, ignore_errors=True)
+        result = line
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    return result
 
 
 def main():
@@ -988,6 +1015,8 @@ def main():
                     help="END-TO-END at N ranks: inquistr_amd.call_dist over one SEQ-bearing BAM, strong scaling (see l2_dist()); --steps = passes over the file")
     ap.add_argument("--l2-dist-loci", type=int, default=20_000, help="loci of that BAM (0.32 GB per 1 000; north_star's configuration: 100000)")
     ap.add_argument("--no-l2-dist-native", action="store_true", help="skip the one-process `inquistr call --devices` run of --l2-dist")
+    ap.add_argument("--l2-dist-default-loci", type=int, default=24_000,
+                    help="N > 1, default line: loci of the SEQ-bearing BAM of its `l2_dist` block (the end-to-end multi-rank measurement beside the L0 one; 0 skips it)")
     ap.add_argument("--native-devices", default="", help="--l2-dist at one rank: the device list of the one-process run (e.g. 0,0,0,0 on a one-GPU box)")
     args = ap.parse_args()
     if args.l2_dist:
@@ -1017,11 +1046,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
 
     wl = synth.WORKLOADS[args.workload]
     global BG
@@ -1074,6 +1105,8 @@ def main():
         lo, hi = rank * per_gpu, (rank + 1) * per_gpu
         total = per_gpu * world
     n_mine = hi - lo
+    want_l2_dist = world > 1 and not args.no_l2 and args.l2_dist_default_loci > 0 and args.scaling == "weak" and args.workload == "unphased100k"
+    final_line = None
 
     ctx = hipcall.Context(local_rank)
     ctx.set_option("max_reads_hint", wl.reads_per_locus)  # the generator's fixed depth: no deep-locus launches needed
@@ -1409,9 +1442,25 @@ def main():
                     if BG is not None:
                         BG.abort()
                         BG = None
-        print(json.dumps(line), flush=True)
+        final_line = line
+        if not (world > 1 and want_l2_dist):
+            print(json.dumps(line), flush=True)
     if BG is not None:
         BG.abort()
+    if world > 1 and want_l2_dist:
+        # N > 1: the END-TO-END measurement beside the L0 one, in the same run - call_dist over one SEQ-bearing BAM, strong scaling
+        # (l2_dist_core) - so that the first run on a node of several GPUs shows what their links ask of ONE host and not
+        # only that device-resident kernels scale.  The L0 line goes out first; the full line, a superset, last.
+        if rank == 0:
+            print(json.dumps(dict(final_line, partial="L0 weak scaling; the full line with the end-to-end `l2_dist` block follows")), flush=True)
+        block = None
+        try:
+            block = l2_dist_core(args, rank, world, local_rank, dev, args.backend, args.l2_dist_default_loci, 2, 1)
+        except Exception as e:  # noqa: BLE001
+            block = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            final_line["l2_dist"] = block
+            print(json.dumps(final_line), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

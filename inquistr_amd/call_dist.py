@@ -158,8 +158,9 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
         if run is not None and rank != 0:
             run.close()
         raise hostcall.CallError(st, f"rank {bad_rank}: {msg}" if world > 1 else msg)
-    # ---- the one exchange of the path: 2 x f64 per locus to rank 0
-    if world > 1:
+    # ---- the one exchange of the path: 2 x f64 per locus to rank 0 (at world size 1 inside an initialised nccl group the same
+    # collective runs over the device buffer: the path a one-GPU box can exercise)
+    if world > 1 or (on_device and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"):
         if on_device:
             buf = dev_buf  # [2][width] in this rank's device memory, written by its flushes
         else:

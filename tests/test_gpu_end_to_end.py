@@ -606,3 +606,34 @@ def test_rows_left_in_device_memory_equal_the_host_rows(tmp_path, frontend, unph
     with open(out, "w") as f:
         call_dist.genotype_repeats_distributed(bam, None, bed, 5, 3, 4, unphased, "S", out=f, frontend=frontend, rows="device")
     assert out.read_text() == _expected_text(loci, recs, unphased, 5, 3, "S", 4)
+
+
+def test_rows_gathered_over_rccl_from_device_memory(tmp_path):
+    """The collective of the one-process-per-GPU form on what a one-GPU box offers: a `nccl` (= RCCL) process group of world size 1,
+    rows left in device memory by the flushes (rows='device'), `dist.gather` reading them there, rank 0 copying the gathered block
+    down and writing the text - against the CLI-equivalent text of the plain-Python restatement."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from inquistr_amd import call_dist
+
+    bam, bed, loci, recs = _make_case(tmp_path, 79, n_loci=70, ultra_long=True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        for unphased in (False, True):
+            out = tmp_path / f"g{int(unphased)}.inq"
+            st = {}
+            with open(out, "w") as f:
+                call_dist.genotype_repeats_distributed(bam, None, bed, 5, 3, 4, unphased, "S", out=f, frontend="device", rows="device", stats=st)
+            assert out.read_text() == _expected_text(loci, recs, unphased, 5, 3, "S", 4)
+            assert st["rows_in"] == "device memory" and st["gather_s"] >= 0
+    finally:
+        dist.destroy_process_group()
