@@ -8,7 +8,7 @@
 #   cig [runs]            the same on the 0.8 GB CIGAR-only file, back to back and with rests between the processes
 #   soak                  damaged deflate streams, random BAMs through both front ends (new seeds)
 #   probes                what allocations, streams, synchronisations cost; hipMalloc back to back
-# Results go to gpurun_out/<what>/ (scratch); what is quoted in DESIGN.md is copied to profiles/r04_results/.
+# Results go to gpurun_out/<what>/ (scratch); what is quoted in DESIGN.md is copied to profiles/r05_results/.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 WHAT=${1:-tests}; shift
@@ -36,8 +36,8 @@ state)
   done; done; done
   run_tests; run_bench ;;
 profiles)
-  bash tools/profile_round.sh r04 2>&1 | tail -25
-  bash tools/profile_front.sh r04_front 50000 2>&1 | tail -30 ;;
+  bash tools/profile_round.sh r05 2>&1 | tail -25
+  bash tools/profile_front.sh r05_front 50000 2>&1 | tail -30 ;;
 loop)
   [ -x inquistr_amd/lib/pagecache_nodes ] || gcc -O2 -o inquistr_amd/lib/pagecache_nodes tools/pagecache_nodes.c
   ( time timeout -k 10 600 python3 tools/make_synth_bam.py unphased100k ${1:-40000} $D/seq native-seq ${2:-6} ) 2>&1 | grep -E "wrote|real"
