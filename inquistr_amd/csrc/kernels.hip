@@ -405,10 +405,16 @@ __global__ __launch_bounds__(256) void locus_call_mid_walk(KArgs a) {
     walk_part<UNPHASED, AUX>(a, lds, cnt, lane, wave);
 }
 
+// Empties the work lists behind a sequence that cannot have filled the deep one (launch_t).
+__global__ void clear_lists(KArgs a) {
+    if (threadIdx.x < 2 * kListShards) a.status->list_count[threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
+}
+
 // ---- launchers (called from capi.hip) ----
 // The sequence: locus_call_small, and - unless the caller's depth hint rules deeper loci out - locus_call_mid_walk and the persistent
-// locus_call_tail (deep_select.hip), which also empties the work lists for the next sequence.  Three launches whatever the batch
-// holds; with nothing deep the last two find empty lists and leave at once.
+// locus_call_tail (deep_select.hip), which also empties the work lists for the next sequence (a hint of at most 256 reads: a
+// one-wave clear_lists in its place).  Three launches whatever the batch holds; with nothing deep the last two find empty lists
+// and leave at once.
 template <bool UNPHASED, int AUX>
 static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, uint32_t grid_tail, hipStream_t s,
                      hipEvent_t ev_mid, void *deep_scratch) {
@@ -418,6 +424,13 @@ static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, 
     const uint32_t h = a.max_reads_hint;
     if (h && h <= 64u) return;  // no locus can be on a work list
     hipLaunchKernelGGL((locus_call_mid_walk<UNPHASED, AUX>), dim3(grid_medium), dim3(256), 0, s, a);
+    if (h && h <= 64u * kMediumSlots) {
+        // nothing can be on the deep list: the medium list is emptied by a one-wave kernel instead of the persistent tail, whose
+        // workgroups need a whole CU's LDS each and would wait for a CU to drain while a span's inflate (eight 20 KB workgroups
+        // per CU, on the ahead stream) is in flight - the CLI's case for data of 65 - 256-fold depth
+        hipLaunchKernelGGL(clear_lists, dim3(1), dim3(64), 0, s, a);
+        return;
+    }
     launch_locus_tail(a, UNPHASED, deep_scratch, a.n_pairs, grid_tail, s);
 }
 
