@@ -302,7 +302,7 @@ static int enqueue_batch(inq_ctx_t *c, const inq_batch_t *b, inq_result_t *r, vo
     const uint32_t per_xcd = (uint32_t)((blocks + 7) / 8);
     const uint32_t grid_small = per_xcd * 8u;
     const uint32_t shard_cap = (grid_small / kListShards + 1u) * 4u;
-    if ((rc = ensure(c, c->worklist, (size_t)shard_cap * kListShards * 2 * 4)) != INQ_OK) return rc;
+    if ((rc = ensure(c, c->worklist, (size_t)shard_cap * kListShards * kListKinds * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->sval, (size_t)b->n_pairs * 8)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->smeta, (size_t)b->n_pairs)) != INQ_OK) return rc;
     // loci of more than kGridSelectMin reads are reduced over the whole grid (deep_select.hip): a state of 74 KB each, and there

@@ -239,8 +239,12 @@ __device__ __forceinline__ double median_of_sorted_range(SortLds<CAP> &L, uint32
     return out;
 }
 
-template <bool UNPHASED, int CAP>
-__device__ __forceinline__ void sort_reduce_locus(const KArgs &a, uint64_t j, uint64_t p0, uint32_t n, SortLds<CAP> &L, SelectLds &sh) {
+// DEFER: a Call beyond the key's 47 bits is not reduced here - the rows are set to kDeferredRow and locus_call_tail, which looks for
+// that pattern at the loci the walk kernel reduces in place, runs the radix select (sh may be null then).  Keeps the select's
+// registers out of locus_call_mid_walk, whose medium-depth path wants the occupancy.
+constexpr unsigned long long kDeferredRow = 0x7ff8dead00000000ull;  // a quiet NaN no row ever holds (rows are finite or __builtin_nan(""))
+template <bool UNPHASED, int CAP, bool DEFER = false>
+__device__ __forceinline__ void sort_reduce_locus(const KArgs &a, uint64_t j, uint64_t p0, uint32_t n, SortLds<CAP> &L, SelectLds *shp) {
     if (threadIdx.x == 0) L.m = L.c1 = L.tie_span = L.tie_clip = L.overflow = 0u;
     __syncthreads();
     // keys of the elements that belong to a haplotype group (slot order is fixed by the sort that follows)
@@ -259,7 +263,12 @@ __device__ __forceinline__ void sort_reduce_locus(const KArgs &a, uint64_t j, ui
     }
     __syncthreads();
     if (L.overflow) {  // a Call beyond 47 bits: not representable in the key
-        reduce_deep_select<UNPHASED>(a, j, p0, n, sh);
+        if (DEFER) {
+            if (threadIdx.x == 0) a.phase1[j] = __longlong_as_double((long long)kDeferredRow), a.phase2[j] = __longlong_as_double((long long)kDeferredRow);
+            __syncthreads();
+        } else {
+            reduce_deep_select<UNPHASED>(a, j, p0, n, *shp);
+        }
         return;
     }
     const uint32_t m = L.m;

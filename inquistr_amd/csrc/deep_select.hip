@@ -525,33 +525,38 @@ template <bool UNPHASED>
 __global__ __launch_bounds__(256) void locus_call_tail(DeepArgs a) {
     __shared__ SortLds<16384> sortL;
     __shared__ SelectLds selL;
-    __shared__ uint32_t cnt[kListShards], cnt_med[kListShards];
+    __shared__ uint32_t cnt[kListShards], cnt2[kListShards], cnt_med[kListShards];
     __shared__ uint32_t n_deep_sh;
     DevStatus *const st = a.k.status;
     if (threadIdx.x < kListShards) {
         cnt[threadIdx.x] = st->list_count[1][threadIdx.x].n;
+        cnt2[threadIdx.x] = st->list_count[2][threadIdx.x].n;
         cnt_med[threadIdx.x] = st->list_count[0][threadIdx.x].n;
     }
     if (threadIdx.x == 0) n_deep_sh = 0u;
     __syncthreads();
-    uint32_t total = 0, total_med = 0;
-    for (int k = 0; k < kListShards; ++k) total += cnt[k], total_med += cnt_med[k];
+    uint32_t total1 = 0, total2 = 0, total_med = 0;
+    for (int k = 0; k < kListShards; ++k) total1 += cnt[k], total2 += cnt2[k], total_med += cnt_med[k];
+    const uint32_t total = total1 + total2;
     // the last workgroup out empties the work lists (every other one has read the counters by then) and tidies the barrier words
     auto leave = [&]() {
         __syncthreads();
         if (threadIdx.x == 0 && (total | total_med)) {
             if (atomicAdd(&st->exit_ticket.v, 1u) == gridDim.x - 1u) {
-                for (int k = 0; k < 2 * kListShards; ++k) st->list_count[k / kListShards][k % kListShards].n = 0u;
+                for (int k = 0; k < kListKinds * kListShards; ++k) st->list_count[k / kListShards][k % kListShards].n = 0u;
                 st->bar_count.v = 0u, st->exit_ticket.v = 0u;
             }
         }
     };
     if (total == 0u) return leave();  // nothing deeper than 256 reads: this is all the launch costs
 
+    // item < total1: list 1 (257 .. kWalkSplit reads; up to kReduceInPlace the walk has reduced them already); the rest: list 2
     auto item_locus = [&](uint32_t item, uint64_t &j, uint64_t &p0, uint64_t &n) {
-        uint32_t shard = 0, idx = item;
-        while (idx >= cnt[shard]) idx -= cnt[shard++];
-        j = a.k.worklist[((uint64_t)kListShards + shard) * a.k.shard_cap + idx];
+        const bool second = item >= total1;
+        const uint32_t *const c = second ? cnt2 : cnt;
+        uint32_t shard = 0, idx = second ? item - total1 : item;
+        while (idx >= c[shard]) idx -= c[shard++];
+        j = a.k.worklist[((uint64_t)(second ? 2 : 1) * kListShards + shard) * a.k.shard_cap + idx];
         p0 = a.k.locus_pair_off[j];
         n = a.k.locus_pair_off[j + 1] - p0;
     };
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(256) void locus_call_tail(DeepArgs a) {
     // and which state is whose without a word being exchanged; workgroup 0 writes the geometry down for the passes
     {
         uint32_t seen = 0;  // very deep loci in front of this chunk (uniform)
-        for (uint32_t base = 0; base < total; base += 256u) {
+        for (uint32_t base = total1; base < total; base += 256u) {  // (they are all on list 2: kGridSelectMin > kWalkSplit)
             const uint32_t item = base + threadIdx.x;
             uint64_t j = 0, p0 = 0, n = 0;
             bool deep = false;
@@ -599,8 +604,12 @@ __global__ __launch_bounds__(256) void locus_call_tail(DeepArgs a) {
     for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
         uint64_t j, p0, n;
         item_locus(item, j, p0, n);
-        if (for_grid(n)) continue;
-        if (n <= 16384u) sort_reduce_locus<UNPHASED, 16384>(a.k, j, p0, (uint32_t)n, sortL, selL);
+        if (for_grid(n)) continue;  // the grid's (phase B)
+        if (n <= kReduceInPlace) {  // reduced by the workgroup that walked it - unless a Call did not fit its sort key
+            if ((unsigned long long)__double_as_longlong(a.k.phase1[j]) == kDeferredRow) reduce_deep_select<UNPHASED>(a.k, j, p0, (uint32_t)n, selL);
+            continue;
+        }
+        if (n <= 16384u) sort_reduce_locus<UNPHASED, 16384>(a.k, j, p0, (uint32_t)n, sortL, &selL);
         else if (n <= 0xffffffffull) reduce_deep_select<UNPHASED>(a.k, j, p0, (uint32_t)n, selL);
         else if (threadIdx.x == 0) {  // 2^32 reads at one locus: outside what the scratch indexing covers
             atomicOr(&st->err, ST_RANGE);

@@ -7,16 +7,20 @@ namespace inq {
 
 // Device-resident status block (one per ctx).
 constexpr int kListShards = 32;
+// work lists: 0 = 65 .. 256 offered reads, 1 = 257 .. kWalkSplit, 2 = deeper (walked by the whole grid)
+constexpr int kListKinds = 3;
+constexpr uint32_t kWalkSplit = 16384;
+constexpr uint32_t kReduceInPlace = 2048;  // a listed locus of up to this many reads is reduced by the workgroup that walked it (locus_call_mid_walk)
 
 struct DevStatus {
     unsigned int err;           // ST_* bits OR-ed by the kernels
     unsigned int pad;
-    // work-list lengths [kind: 0 = medium (65..256 reads), 1 = big][shard], zero between launch sequences
+    // work-list lengths [kind: 0 = medium (65..256 reads), 1 = deep, 2 = deeper than kWalkSplit][shard], zero between launch sequences
     // (the last kernel of a sequence that may have filled them clears them).  Every counter
     // sits on its own 128-byte line: returning atomics on one line serialise at ~11 ns each.
     struct alignas(128) Counter {
         unsigned int n;
-    } list_count[2][kListShards];
+    } list_count[kListKinds][kListShards];
     unsigned long long ties;    // unphased loci whose split cuts mixed Span/Clip ties
     // locus_call_tail (deep_select.hip), each word on a line of its own: the grid barrier's arrival counter (monotonic inside a launch),
     // its abort word (a barrier that waited too long: every workgroup leaves), the exit ticket (the last workgroup out empties the

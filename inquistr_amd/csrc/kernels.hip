@@ -292,9 +292,9 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
         }
         return;
     }
-    if (n64 > 64ull) {  // deeper locus: list it for locus_call_medium (<= 256 reads) or locus_call_big
+    if (n64 > 64ull) {  // deeper locus: listed for locus_call_mid_walk - medium (<= 256 reads), deep, or deeper than kWalkSplit
         if (lane == 0) {
-            const uint32_t kind = n64 > 64ull * kMediumSlots ? 1u : 0u;
+            const uint32_t kind = n64 > kWalkSplit ? 2u : n64 > 64ull * kMediumSlots ? 1u : 0u;
             const uint32_t shard = blockIdx.x % kListShards;
             const uint32_t slot = atomicAdd(&a.status->list_count[kind][shard].n, 1u);
             a.worklist[((uint64_t)kind * kListShards + shard) * a.shard_cap + slot] = (uint32_t)j;
@@ -326,88 +326,122 @@ __device__ __forceinline__ void medium_part(const KArgs &a, WaveLds (&lds)[4], u
 // ---------------------------------------------------------------------------------------------
 // Deep loci.  Scratch layout: sval[p] (i64) and smeta[p] (u8) indexed by global pair number.
 
-constexpr int kBigBlock = 64;           // reads one wave walks per block in locus_call_big_walk
-constexpr uint32_t kWalkSplit = 16384;  // loci deeper than this are walked by the whole grid
+constexpr int kBigBlock = 64;  // reads one wave walks per block
+// (kWalkSplit, kernels.h: loci deeper than this are walked by the whole grid - they are on a work list of their own)
 
-// ---- loci with more than 256 reads, stage 1: walk -----------------------------------------------
-// One workgroup per listed locus; its four waves take 64-read blocks in turn through the same walker
-// and leave (Call, meta) per read in the ctx's global scratch.  The kernel boundary in front of the
-// reduce kernel makes the scratch visible: no fences.  The descriptors of a wave's next block are
-// fetched while it walks the current one.
+// ---- loci with more than 256 reads: walk (and, up to kReduceInPlace reads, reduce) ------------------------------
+// The four waves of a workgroup take the locus' 64-read blocks in turn through the same walker and leave (Call, meta) per read in the
+// ctx's global scratch; the descriptors of a wave's next block are fetched while it walks the current one.  `spread`: the blocks
+// are dealt over every wave of the GRID (a locus of more than kWalkSplit reads: it streams at the chip's rate, not one workgroup's).
 template <bool UNPHASED, int AUX>
-__device__ __forceinline__ void walk_part(const KArgs &a, WaveLds (&lds)[4], uint32_t (&cnt)[kListShards], int lane, uint32_t wave) {
+__device__ __forceinline__ void walk_locus(const KArgs &a, const BatchView &b, uint64_t j, uint64_t p0, uint32_t n, bool spread, int lane, uint32_t wave,
+                                           WaveLds &L) {
+    const uint32_t bstep = spread ? 4u * gridDim.x : 4u;  // blocks between two of this wave's
+    const uint32_t start = a.locus_start[j], end = a.locus_end[j];
+    Window W;
+    W.se = start - 10u;
+    W.ee = end + 10u;
+    W.se1 = W.se + 1u;
+    W.width = W.ee - W.se1;
+    W.minlen = a.minlen;
+    uint32_t status = 0;
+    const uint32_t nblk = (n + kBigBlock - 1) / kBigBlock;
+    auto blk_cnt = [&](uint32_t blk) { return blk < nblk ? (int)min((uint32_t)kBigBlock, n - blk * kBigBlock) : 0; };
+    // software pipeline over this wave's blocks: A = pair index (2 ahead), B = descriptor (1 ahead)
+    uint32_t blk = spread ? blockIdx.x * 4u + wave : wave;
+    uint32_t ri_b = meta_stage_a(b, p0 + (uint64_t)blk * kBigBlock, blk_cnt(blk), lane);
+    uint4 rd = meta_stage_b(b, ri_b);
+    uint32_t ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + bstep) * kBigBlock, blk_cnt(blk + bstep), lane);
+    for (; blk < nblk; blk += bstep) {
+        const int c = blk_cnt(blk);
+        const uint64_t first = p0 + (uint64_t)blk * kBigBlock;
+        bool valid;
+        if (lane < c && (uint64_t)ri_b >= b.n_reads) status |= ST_INDEX;
+        const PairMeta m = meta_stage_c(b, rd, (lane < c && (uint64_t)ri_b < b.n_reads) ? c : 0, lane, status, valid);
+        // next block: descriptor load now (its index arrived during the previous walk), index load for the one after
+        ri_b = ri_next;
+        rd = meta_stage_b(b, ri_b);
+        ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + 2u * bstep) * kBigBlock, blk_cnt(blk + 2u * bstep), lane);
+        int64_t val;
+        uint32_t meta;
+        walk_pairs<UNPHASED, AUX>(b, m, valid, c, W, lane, status, L, val, meta);
+        if (lane < c) {
+            a.sval[first + lane] = val;
+            a.smeta[first + lane] = (uint8_t)meta;
+            if (a.pair_call) a.pair_call[first + lane] = val;
+            if (a.pair_bits) a.pair_bits[first + lane] = (uint8_t)(meta & 7u);
+        }
+    }
+    if (status) atomicOr(&a.status->err, status);
+}
+
+// What the walk and the in-place reduce need of LDS, one after the other: the four waves' walk state, then the sort's keys.
+union MidLds {
+    WaveLds wave[4];
+    SortLds<(int)kReduceInPlace> sort;
+};
+
+template <bool UNPHASED, int AUX>
+__device__ __forceinline__ void walk_part(const KArgs &a, MidLds &lds, uint32_t (&cnt)[kListShards], int lane, uint32_t wave) {
+    BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
+    // ---- list 1 (257 .. kWalkSplit reads): each locus is ONE workgroup's, the list is dealt over the grid - a workgroup looks at its
+    // own items only (round 4 and the first form of this kernel had every workgroup read through the whole list: 10 000 loci of 270
+    // reads took 71 ms)
     if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[1][threadIdx.x].n;
     __syncthreads();
     uint32_t total = 0;
     for (int k = 0; k < kListShards; ++k) total += cnt[k];
-    BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
-    // Every workgroup goes through the whole list.  A locus of up to kWalkSplit reads is walked by ONE workgroup (item modulo
-    // grid); a deeper one (amplicon-depth pile-ups) by ALL of them, 64-read blocks dealt round-robin over every wave of the grid,
-    // so that a single 100 000-read locus streams at the chip's rate instead of one workgroup's.
-    for (uint32_t item = 0; item < total; ++item) {
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
         uint32_t shard = 0, idx = item;
         while (idx >= cnt[shard]) idx -= cnt[shard++];
         const uint64_t j = a.worklist[((uint64_t)kListShards + shard) * a.shard_cap + idx];
         const uint64_t p0 = a.locus_pair_off[j];
         const uint32_t n = (uint32_t)(a.locus_pair_off[j + 1] - p0);
-        const bool shared = n > kWalkSplit;
-        if (!shared && item % gridDim.x != blockIdx.x) continue;
-        const uint32_t bstep = shared ? 4u * gridDim.x : 4u;  // blocks between two of this wave's
-        const uint32_t start = a.locus_start[j], end = a.locus_end[j];
-        Window W;
-        W.se = start - 10u;
-        W.ee = end + 10u;
-        W.se1 = W.se + 1u;
-        W.width = W.ee - W.se1;
-        W.minlen = a.minlen;
-        uint32_t status = 0;
-        const uint32_t nblk = (n + kBigBlock - 1) / kBigBlock;
-        auto blk_cnt = [&](uint32_t blk) { return blk < nblk ? (int)min((uint32_t)kBigBlock, n - blk * kBigBlock) : 0; };
-        // software pipeline over this wave's blocks: A = pair index (2 ahead), B = descriptor (1 ahead)
-        uint32_t blk = shared ? blockIdx.x * 4u + wave : wave;
-        uint32_t ri_b = meta_stage_a(b, p0 + (uint64_t)blk * kBigBlock, blk_cnt(blk), lane);
-        uint4 rd = meta_stage_b(b, ri_b);
-        uint32_t ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + bstep) * kBigBlock, blk_cnt(blk + bstep), lane);
-        for (; blk < nblk; blk += bstep) {
-            const int c = blk_cnt(blk);
-            const uint64_t first = p0 + (uint64_t)blk * kBigBlock;
-            bool valid;
-            if (lane < c && (uint64_t)ri_b >= b.n_reads) status |= ST_INDEX;
-            const PairMeta m = meta_stage_c(b, rd, (lane < c && (uint64_t)ri_b < b.n_reads) ? c : 0, lane, status, valid);
-            // next block: descriptor load now (its index arrived during the previous walk), index load for the one after
-            ri_b = ri_next;
-            rd = meta_stage_b(b, ri_b);
-            ri_next = meta_stage_a(b, p0 + (uint64_t)(blk + 2u * bstep) * kBigBlock, blk_cnt(blk + 2u * bstep), lane);
-            int64_t val;
-            uint32_t meta;
-            walk_pairs<UNPHASED, AUX>(b, m, valid, c, W, lane, status, lds[wave], val, meta);
-            if (lane < c) {
-                a.sval[first + lane] = val;
-                a.smeta[first + lane] = (uint8_t)meta;
-                if (a.pair_call) a.pair_call[first + lane] = val;
-                if (a.pair_bits) a.pair_bits[first + lane] = (uint8_t)(meta & 7u);
-            }
+        walk_locus<UNPHASED, AUX>(a, b, j, p0, n, false, lane, wave, lds.wave[wave]);
+        if (n <= kReduceInPlace) {
+            // reduced on the spot by the workgroup that walked it: its Calls are this CU's own stores (drained, then a barrier), the
+            // sort takes the LDS the walk no longer needs, and thousands of such loci (a targeted panel at 300-fold depth) are
+            // reduced by as many workgroups as walked them instead of by the tail kernel's one per CU
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            sort_reduce_locus<UNPHASED, (int)kReduceInPlace, true>(a, j, p0, n, lds.sort, nullptr);  // (a Call beyond 47 bits: left to the tail)
         }
-        if (status) atomicOr(&a.status->err, status);
+        __syncthreads();  // the LDS goes back to the walk
+    }
+    // ---- list 2 (more than kWalkSplit reads: amplicon pile-ups; few): every workgroup takes part in every one of them
+    __syncthreads();
+    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[2][threadIdx.x].n;
+    __syncthreads();
+    total = 0;
+    for (int k = 0; k < kListShards; ++k) total += cnt[k];
+    for (uint32_t item = 0; item < total; ++item) {
+        uint32_t shard = 0, idx = item;
+        while (idx >= cnt[shard]) idx -= cnt[shard++];
+        const uint64_t j = a.worklist[((uint64_t)2 * kListShards + shard) * a.shard_cap + idx];
+        const uint64_t p0 = a.locus_pair_off[j];
+        const uint64_t n64 = a.locus_pair_off[j + 1] - p0;
+        if (n64 > 0xffffffffull) continue;  // (flagged by the tail kernel: outside what the scratch indexing covers)
+        walk_locus<UNPHASED, AUX>(a, b, j, p0, (uint32_t)n64, true, lane, wave, lds.wave[wave]);
     }
 }
 
 // ONE kernel behind locus_call_small for everything deeper than 64 reads that needs the CIGARs: the medium loci are called outright,
-// the deeper ones walked into the scratch (the reduce of those is locus_call_tail, deep_select.hip).  Both lists are mostly empty:
-// a launch that finds them so costs its launch and nothing else - round 4 had two launches here (and ~36 more behind them).
+// the deeper ones walked into the scratch - and reduced there and then up to kReduceInPlace reads; the reduce of the rest is
+// locus_call_tail (deep_select.hip).  The lists are mostly empty: a launch that finds them so costs its launch and nothing else -
+// round 4 had two launches here (and ~36 more behind them).
 template <bool UNPHASED, int AUX>
 __global__ __launch_bounds__(256) void locus_call_mid_walk(KArgs a) {
-    __shared__ WaveLds lds[4];
+    __shared__ MidLds lds;
     __shared__ uint32_t cnt[kListShards];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    medium_part<UNPHASED, AUX>(a, lds, cnt, lane, wave);
+    medium_part<UNPHASED, AUX>(a, lds.wave, cnt, lane, wave);
     walk_part<UNPHASED, AUX>(a, lds, cnt, lane, wave);
 }
 
-// Empties the work lists behind a sequence that cannot have filled the deep one (launch_t).
+// Empties the work lists behind a sequence that cannot have filled the deep ones (launch_t).
 __global__ void clear_lists(KArgs a) {
-    if (threadIdx.x < 2 * kListShards) a.status->list_count[threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
+    if (threadIdx.x < kListKinds * kListShards) a.status->list_count[threadIdx.x / kListShards][threadIdx.x % kListShards].n = 0u;
 }
 
 // ---- launchers (called from capi.hip) ----
@@ -428,7 +462,7 @@ static void launch_t(const KArgs &a, uint32_t grid_small, uint32_t grid_medium, 
         // nothing can be on the deep list: the medium list is emptied by a one-wave kernel instead of the persistent tail, whose
         // workgroups need a whole CU's LDS each and would wait for a CU to drain while a span's inflate (eight 20 KB workgroups
         // per CU, on the ahead stream) is in flight - the CLI's case for data of 65 - 256-fold depth
-        hipLaunchKernelGGL(clear_lists, dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(clear_lists, dim3(1), dim3(128), 0, s, a);
         return;
     }
     launch_locus_tail(a, UNPHASED, deep_scratch, a.n_pairs, grid_tail, s);

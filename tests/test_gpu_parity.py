@@ -719,6 +719,39 @@ def test_bench_l2_dist_two_ranks_on_one_gpu():
         assert p["front"] == "device" and p["span_loop_GBps"] > 1 and p["io_threads"] >= 2 and p["io_threads"] * 2 <= max(p["granted_cpus"], 4)
 
 
+def test_thousands_of_deep_loci_are_not_a_scan_of_the_work_list_per_workgroup(ctx):
+    """3 000 loci of 270 and of 510 offered reads each (a targeted panel at several-hundred-fold depth: every locus on the deep work
+    list).  Round 4 - and the first form of round 5's merged walk kernel - let every workgroup read through the whole list: 12 ms
+    and 71 ms for 10 000 such loci.  A workgroup now takes its own items only and reduces a locus of up to 2 048 reads where it
+    walked it: the rows must equal the plain batch's (every locus sees a superset of its reads) and the sequence must take well
+    under a millisecond per thousand loci."""
+    import torch
+
+    wl = synth.WORKLOADS["phased10k"]
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(device=dev)
+    base = synth.DeviceBatch(wl, dev, 0, 3000)
+    ctx.set_option("max_reads_hint", 0)
+    ctx.call_batch_device(base.c_batch, base.c_result, stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.status()[0] == 0
+    p1, p2 = base.phase1.cpu().numpy(), base.phase2.cpu().numpy()
+    for k in (4, 8):
+        sup = synth.DeviceBatch(wl, dev, 0, 3000, neighbors=k)
+        for _ in range(2):
+            ctx.call_batch_device(sup.c_batch, sup.c_result, stream.cuda_stream)
+        torch.cuda.synchronize()
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        ctx.call_batch_device(sup.c_batch, sup.c_result, stream.cuda_stream)
+        torch.cuda.synchronize()
+        seq_ms, _ = ctx.timing_read(0)
+        ctx.timing_enable(False)
+        assert ctx.status()[0] == 0
+        assert gen.same_f64(sup.phase1.cpu().numpy(), p1) and gen.same_f64(sup.phase2.cpu().numpy(), p2), k
+        assert seq_ms < 1.5, f"{seq_ms:.2f} ms for 3 000 loci of {(2 * k + 1) * 30} reads"
+
+
 def test_superset_of_candidates_changes_nothing(ctx):
     """The ABI lets the host offer more reads than fetch() would yield (one sweep over the file instead
     of an index query per locus): the device applies htslib's overlap rule.  Offering every locus the

@@ -4,13 +4,17 @@ device-resident batch, HIP events around the whole sequence (inq_ctx_timing_read
 with the caller's depth hint (one launch) and without it (three: small, mid_walk, the persistent tail).  Round 4 launched ~38
 without the hint.
 
-    python3 tools/seq_timing.py [workload] [loci] [reps]
+    python3 tools/seq_timing.py [workload] [loci] [reps] [neighbors]
+
+neighbors = k > 0: every locus is offered the reads of its k neighbours on both sides too ((2k + 1) x 30 reads per locus, every read
+shared by 2k + 1 loci): k = 1 / 2 / 3 / 4 = 90 / 150 / 210 / 270 reads = the 65 - 256-read path of locus_call_mid_walk (and, at 270,
+the walk + tail path).
 """
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get("INQ_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # INQ_ROOT: another checkout (A/B against an earlier round)
 sys.path.insert(0, ROOT)
 
 
@@ -43,12 +47,15 @@ def main():
     wl = synth.WORKLOADS[name]
     loci = int(sys.argv[2]) if len(sys.argv) > 2 else wl.n_loci
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    nb = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     dev = torch.device("cuda:0")
-    ctx = hipcall.Context(0)
-    shard = synth.DeviceBatch(wl, dev, 0, loci)
+    alt = os.environ.get("INQ_LIB")  # another build of libinquistr_hip.so (A/B against an earlier commit)
+    ctx = hipcall.Context(0, lib=hipcall.load(alt)) if alt else hipcall.Context(0)
+    shard = synth.DeviceBatch(wl, dev, 0, loci, neighbors=nb)
     stream = torch.cuda.Stream(device=dev)
-    out = {"workload": name, "loci": loci, "reps": reps, "algorithmic_bytes": shard.algorithmic_bytes()}
-    for label, hint in (("hint", wl.reads_per_locus), ("no_hint", 0), ("hint_again", wl.reads_per_locus), ("no_hint_again", 0)):
+    depth = wl.reads_per_locus * (2 * nb + 1)
+    out = {"workload": name, "loci": loci, "reps": reps, "neighbors": nb, "reads_per_locus": depth, "algorithmic_bytes": shard.algorithmic_bytes()}
+    for label, hint in (("hint", depth), ("no_hint", 0), ("hint_again", depth), ("no_hint_again", 0)):
         seq, k = measure(ctx, shard, stream, hint, reps)
         out[label] = {"sequence_ms": seq, "first_kernel_ms": k, "behind_first_kernel_us": (seq - k) * 1e3,
                       "frac_of_8TBps_sequence": shard.algorithmic_bytes() / (seq * 1e-3) / 8e12,
