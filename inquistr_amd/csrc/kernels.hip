@@ -307,9 +307,7 @@ __global__ __launch_bounds__(256) void locus_call_small(KArgs a) {
 // Loci with 65..256 offered reads: still one wave per locus, four reads per lane.  Persistent waves
 // stride over the work list that locus_call_small filled.
 template <bool UNPHASED, int AUX>
-__device__ __forceinline__ void medium_part(const KArgs &a, WaveLds (&lds)[4], uint32_t (&cnt)[kListShards], int lane, uint32_t wave) {
-    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[0][threadIdx.x].n;
-    __syncthreads();
+__device__ __forceinline__ void medium_part(const KArgs &a, WaveLds (&lds)[4], const uint32_t (&cnt)[kListShards], int lane, uint32_t wave) {
     uint32_t total = 0;
     for (int k = 0; k < kListShards; ++k) total += cnt[k];
     for (uint32_t item = blockIdx.x * 4u + wave; item < total; item += gridDim.x * 4u) {
@@ -320,7 +318,7 @@ __device__ __forceinline__ void medium_part(const KArgs &a, WaveLds (&lds)[4], u
         const int n = (int)(a.locus_pair_off[j + 1] - p0);
         wave_locus<UNPHASED, AUX, kMediumSlots>(a, j, p0, n, a.locus_start[j], a.locus_end[j], lane, lds[wave]);
     }
-    __syncthreads();  // cnt is read again by the walk part
+    __syncthreads();  // the LDS goes on to the walk part
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -382,13 +380,12 @@ union MidLds {
 };
 
 template <bool UNPHASED, int AUX>
-__device__ __forceinline__ void walk_part(const KArgs &a, MidLds &lds, uint32_t (&cnt)[kListShards], int lane, uint32_t wave) {
+__device__ __forceinline__ void walk_part(const KArgs &a, MidLds &lds, const uint32_t (&cnt)[kListShards], const uint32_t (&cnt2)[kListShards], int lane,
+                                          uint32_t wave) {
     BatchView b{a.cigar4, a.reads, a.pair_read, a.n_reads, a.n_cigar4};
     // ---- list 1 (257 .. kWalkSplit reads): each locus is ONE workgroup's, the list is dealt over the grid - a workgroup looks at its
     // own items only (round 4 and the first form of this kernel had every workgroup read through the whole list: 10 000 loci of 270
     // reads took 71 ms)
-    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[1][threadIdx.x].n;
-    __syncthreads();
     uint32_t total = 0;
     for (int k = 0; k < kListShards; ++k) total += cnt[k];
     for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
@@ -409,14 +406,11 @@ __device__ __forceinline__ void walk_part(const KArgs &a, MidLds &lds, uint32_t 
         __syncthreads();  // the LDS goes back to the walk
     }
     // ---- list 2 (more than kWalkSplit reads: amplicon pile-ups; few): every workgroup takes part in every one of them
-    __syncthreads();
-    if (threadIdx.x < kListShards) cnt[threadIdx.x] = a.status->list_count[2][threadIdx.x].n;
-    __syncthreads();
     total = 0;
-    for (int k = 0; k < kListShards; ++k) total += cnt[k];
+    for (int k = 0; k < kListShards; ++k) total += cnt2[k];
     for (uint32_t item = 0; item < total; ++item) {
         uint32_t shard = 0, idx = item;
-        while (idx >= cnt[shard]) idx -= cnt[shard++];
+        while (idx >= cnt2[shard]) idx -= cnt2[shard++];
         const uint64_t j = a.worklist[((uint64_t)2 * kListShards + shard) * a.shard_cap + idx];
         const uint64_t p0 = a.locus_pair_off[j];
         const uint64_t n64 = a.locus_pair_off[j + 1] - p0;
@@ -432,11 +426,13 @@ __device__ __forceinline__ void walk_part(const KArgs &a, MidLds &lds, uint32_t 
 template <bool UNPHASED, int AUX>
 __global__ __launch_bounds__(256) void locus_call_mid_walk(KArgs a) {
     __shared__ MidLds lds;
-    __shared__ uint32_t cnt[kListShards];
+    __shared__ uint32_t cnt[kListKinds][kListShards];  // the three lists' lengths, read once (an idle launch is these 96 loads)
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    medium_part<UNPHASED, AUX>(a, lds.wave, cnt, lane, wave);
-    walk_part<UNPHASED, AUX>(a, lds, cnt, lane, wave);
+    if (threadIdx.x < kListKinds * kListShards) cnt[threadIdx.x / kListShards][threadIdx.x % kListShards] = a.status->list_count[threadIdx.x / kListShards][threadIdx.x % kListShards].n;
+    __syncthreads();
+    medium_part<UNPHASED, AUX>(a, lds.wave, cnt[0], lane, wave);
+    walk_part<UNPHASED, AUX>(a, lds, cnt[1], cnt[2], lane, wave);
 }
 
 // Empties the work lists behind a sequence that cannot have filled the deep ones (launch_t).
