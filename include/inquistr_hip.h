@@ -178,7 +178,7 @@ int inq_ctx_timing_read(inq_ctx_t *ctx, int which, double *total_ms, uint64_t *l
 int inq_ctx_timing_reset(inq_ctx_t *ctx);
 
 /* Tuning knobs.  key: "grid_medium" = workgroups of the kernel that takes the 65..256-read loci and walks the deeper ones
- * (default 8192); "grid_tail" ("grid_big" up to ABI v4) = workgroups of the persistent kernel that reduces the deeper ones (default
+ * (default 4096); "grid_tail" ("grid_big" up to ABI v4) = workgroups of the persistent kernel that reduces the deeper ones (default
  * 256, never more than the device's compute units: they meet at grid barriers); "max_reads_hint" = N > 0 promises that no locus of
  * the following batches is offered more than N reads (N <= 64 skips the two launches behind the first kernel - which cost a few
  * microseconds when nothing deep is there; a violated promise is reported as INQ_ERR_ARG), 0 (default) = unknown;

@@ -51,6 +51,8 @@ def main():
     dev = torch.device("cuda:0")
     alt = os.environ.get("INQ_LIB")  # another build of libinquistr_hip.so (A/B against an earlier commit)
     ctx = hipcall.Context(0, lib=hipcall.load(alt)) if alt else hipcall.Context(0)
+    if os.environ.get("GRID_MEDIUM"):  # A/B of the mid_walk kernel's grid
+        ctx.set_option("grid_medium", int(os.environ["GRID_MEDIUM"]))
     shard = synth.DeviceBatch(wl, dev, 0, loci, neighbors=nb)
     stream = torch.cuda.Stream(device=dev)
     depth = wl.reads_per_locus * (2 * nb + 1)
