@@ -880,7 +880,7 @@ def l2_dist_core(args, rank, world, local_rank, dev, backend, loci, steps, warmu
         return statistics.median(v) if v else None
 
     mine = {"rank": rank, "device": local_rank, "loci": per_step[-1].get("loci"), "bam_bytes_read": per_step[-1].get("bam_bytes_this_call"),
-            "rows_s": med("rows_s"), "gather_s": med("gather_s"), "span_loop_s": med("span_loop_s"), "span_loop_GBps": med("span_loop_GBps"),
+            "open_s": med("open_s"), "output_s": med("output_s"), "rows_s": med("rows_s"), "gather_s": med("gather_s"), "span_loop_s": med("span_loop_s"), "span_loop_GBps": med("span_loop_GBps"),
             "wait_loader_s": med("wait_loader_s"), "device_calls_s": med("device_calls_s"), "io_threads": per_step[-1].get("io_threads"),
             "granted_cpus": per_step[-1].get("granted_cpus"), "rows_in": per_step[-1].get("rows_in"), "front": per_step[-1].get("front")}
     allr = [None] * world

@@ -154,6 +154,13 @@ typedef struct inq_staged inq_staged_t;
 int inq_session_stage(inq_session_t *s, const inq_call_args_t *args, inq_staged_t **out);
 int inq_session_run(inq_session_t *s, inq_staged_t *staged, int out_fd, char *errbuf, size_t errcap);
 void inq_session_discard(inq_staged_t *staged);
+/* A prepared run ON a session (inq_run_* above): its inq_run_rows / inq_run_rows_device calls use the session's device context, its
+ * span buffers and its BED cache instead of making their own - what a resident rank of a one-process-per-GPU job
+ * (inquistr_amd/call_dist.py under torch.distributed.run) calls file after file, or pass after pass: the context (streams, device
+ * slots: tens of milliseconds even in a process whose runtime is up) and a GB of touched span buffers are made once per process, not
+ * once per file.  args->device is ignored (the session's device is used).  The session must outlive the run; one call at a time per
+ * session, as for every other inq_session_* entry. */
+int inq_session_run_open(inq_session_t *s, const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap);
 
 /* ---- BAM -> batch front end (no GPU involved) ---- */
 typedef struct inq_frontend inq_frontend_t;

@@ -48,6 +48,7 @@ HOST_ABI_SYMBOLS = (
     "inq_session_stage",
     "inq_session_run",
     "inq_session_discard",
+    "inq_session_run_open",
     "inq_combine",
     "inq_frontend_open",
     "inq_frontend_n_targets",
@@ -190,6 +191,8 @@ def load():
         L.inq_session_call_many.argtypes = [vp, C.POINTER(CallArgsC), C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.inq_session_close.restype = None
         L.inq_session_close.argtypes = [vp]
+        L.inq_session_run_open.restype = C.c_int
+        L.inq_session_run_open.argtypes = [vp, C.POINTER(CallArgsC), C.POINTER(vp), C.c_char_p, C.c_size_t]
         L.inq_combine.restype = C.c_int
         L.inq_combine.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
         L.inq_frontend_open.restype = C.c_int
@@ -359,18 +362,26 @@ def partition(bamp: str, region: Optional[str], region_file: Optional[str], worl
 
 class Run:
     """inq_run_*: the BAM header, its index and the targets opened once (get_targets + get_bam_reader, src/call.rs:146-147,
-    182-202); serves the work split, this process's rows and the ordered `.inq` output of a multi-process run."""
+    182-202); serves the work split, this process's rows and the ordered `.inq` output of a multi-process run.
+    session: a Session whose device context, span buffers and BED cache the run's rows calls use (inq_session_run_open) - what a
+    resident rank passes file after file; the session must stay open while the run is."""
 
     def __init__(self, bamp, region=None, region_file=None, minlen=5, support=3, threads=1, unphased=False, sample_name=None,
-                 device: int = 0, frontend: Optional[str] = None):
+                 device: int = 0, frontend: Optional[str] = None, session: Optional["Session"] = None):
         self._L = load()
         self._h = C.c_void_p()
+        self._session = session  # the session closes the runs still open on it before it goes (Session.close)
         self._args = _args(bamp, region, region_file, minlen, support, threads, unphased, sample_name, None, device, frontend)
         err = C.create_string_buffer(2048)
-        rc = self._L.inq_run_open(C.byref(self._args), C.byref(self._h), err, len(err))
+        if session is not None:
+            rc = self._L.inq_session_run_open(session._h, C.byref(self._args), C.byref(self._h), err, len(err))
+        else:
+            rc = self._L.inq_run_open(C.byref(self._args), C.byref(self._h), err, len(err))
         if rc != 0:
             self._h = C.c_void_p()
             raise CallError(rc, err.value.decode(errors="replace"))
+        if session is not None:
+            session._runs.add(self)
 
     @property
     def n_targets(self) -> int:
@@ -438,8 +449,11 @@ class Session:
     """inq_session_*: many BAMs on one device context (the HIP runtime starts once; file k + 1 is staged while file k is called)."""
 
     def __init__(self, device: int = 0):
+        import weakref
+
         self._L = load()
         self._h = C.c_void_p()
+        self._runs = weakref.WeakSet()  # runs opened on this session (Run(session=...)): closed with it, never after it
         rc = self._L.inq_session_open(device, C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
@@ -476,6 +490,8 @@ class Session:
 
     def close(self):
         if self._h and self._h.value:
+            for r in list(self._runs):  # a run uses the session's context to its end (its device rows are freed on it)
+                r.close()
             self._L.inq_session_close(self._h)
             self._h = C.c_void_p()
 

@@ -36,6 +36,21 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
+_sessions = {}
+
+
+def _process_session(device: int):
+    """One call.Session per device for the life of the process (closed at exit): a rank's device context, its span buffers and
+    its parsed BED outlive the file."""
+    sess = _sessions.get(device)
+    if sess is None:
+        import atexit
+
+        sess = _sessions[device] = hostcall.Session(device)
+        atexit.register(sess.close)
+    return sess
+
+
 def _exchange_status(status: int, message: str, rank: int, world: int, group=None):
     """Every rank learns whether any rank failed (and rank 0 the failing rank's message) BEFORE the row gather, so that a
     data-dependent failure on one rank (a record the reference panics on, a HIP error, out of memory) ends the run on all
@@ -56,47 +71,67 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
                                  support: int = 3, threads: int = 1, unphased: bool = False,
                                  sample_name: Optional[str] = None, out=None, rank: int = 0, world: int = 1,
                                  device: int = 0, compute: Optional[Callable] = None, group=None,
-                                 frontend: Optional[str] = None, stats: Optional[dict] = None, rows: Optional[str] = None) -> None:
+                                 frontend: Optional[str] = None, stats: Optional[dict] = None, rows: Optional[str] = None,
+                                 session=None) -> None:
     """Same arguments as call.genotype_repeats plus (rank, world).  Rank 0 writes header + rows.
     Raises CallError (same status on every rank) if any rank fails.  stats (rank 0): seconds of the output stage.
-    rows: "device" / "host" = where this rank's rows wait for the gather; None = device memory when the backend is nccl."""
+    rows: "device" / "host" = where this rank's rows wait for the gather; None = device memory when the backend is nccl.
+    session: the call.Session this rank's device work runs on; None = one per process and device, opened at the first call and
+    kept (a resident rank calls file after file on one device context)."""
     import torch
     import torch.distributed as dist
 
-    # ---- the work split, computed ONCE (rank 0: BED + .bai through the C++ host library) and broadcast: contiguous slices of
-    # the targets in file order, cut so that every rank has about the same amount of BAM to read (SURVEY.md 8e).  Rank 0 keeps
-    # the opened run (header, index, targets) for its own rows and for the output stage: nothing is opened or parsed twice.
-    plan = [None]
+    # ---- the work split: EVERY rank opens the run (BAM header, index, BED: ~25 ms for 100 000 targets) at the same time and cuts the
+    # targets itself - contiguous slices in file order, about the same amount of BAM per rank (SURVEY.md 8e); the cut is a pure
+    # function of the index and the target list, so all ranks hold the same plan without a broadcast (round 4: rank 0 opened, cut and
+    # broadcast 100 000 indices while the others waited, then they opened - twice the fixed cost in front of every rank's spans).  One
+    # small exchange makes sure of it: status, message and a digest of the plan.  A resident rank (a worker that calls file after
+    # file) runs on ONE session per device: the device context, a GB of touched span buffers and the parsed BED are the process's,
+    # not the file's (inq_session_run_open).
+    import time
+    import zlib
+
+    if rows not in (None, "device", "host"):
+        raise ValueError("rows: 'device', 'host' or None")
+    if rows == "device" and world > 1 and dist.get_backend(group) != "nccl":
+        raise ValueError("rows='device' needs the nccl backend")
+    t_open = time.perf_counter()
     st, msg = 0, ""
     run = None
-    if rank == 0:
-        try:
-            run = hostcall.Run(bamp, region, region_file, minlen, support, threads, unphased, sample_name, device=device, frontend=frontend)
-            plan = [run.partition(world)]
-        except hostcall.CallError as e:
-            st, msg = e.status, e.message
-        except Exception as e:  # noqa: BLE001  (library missing, out of memory, ...): the other ranks must not wait in the broadcast
-            st, msg = 1, f"{type(e).__name__}: {e}"
+    order, cuts, digest = None, None, 0
+    try:
+        sess = _process_session(device) if (compute is None and session is None) else session
+        run = hostcall.Run(bamp, region, region_file, minlen, support, threads, unphased, sample_name, device=device, frontend=frontend,
+                           session=sess if compute is None else None)
+        order, cuts = run.partition(world)
+        digest = zlib.crc32(cuts.tobytes(), zlib.crc32(order.tobytes()))
+    except hostcall.CallError as e:
+        st, msg = e.status, e.message
+    except Exception as e:  # noqa: BLE001  (library missing, out of memory, ...): the other ranks must not wait for this one
+        st, msg = 1, f"{type(e).__name__}: {e}"
     if world > 1:
-        head = [(st, msg, plan[0])]
-        dist.broadcast_object_list(head, src=0, group=group)
-        st, msg, plan[0] = head[0]
+        got = [None] * world
+        dist.all_gather_object(got, (int(st), str(msg), int(digest)), group=group)
+        for r, (s_r, m_r, _d) in enumerate(got):
+            if s_r != 0:
+                st, msg = s_r, m_r
+                break
+        else:
+            if any(d != got[0][2] for _s, _m, d in got):
+                st, msg = 1, "the ranks cut the targets differently (different files, or different versions of the host library?)"
     if st != 0:
+        if run is not None:
+            run.close()
         raise hostcall.CallError(st, msg)
-    order, cuts = plan[0]
+    if stats is not None:
+        stats["open_s"] = time.perf_counter() - t_open  # header + index + BED + the cut (+ the exchange's wait for the slowest rank)
     n = len(order)
     lo, hi = int(cuts[rank]), int(cuts[rank + 1])
     mine = order[lo:hi]
     width = max(max(int(cuts[r + 1] - cuts[r]) for r in range(world)), 1)
-    if rows not in (None, "device", "host"):
-        raise ValueError("rows: 'device', 'host' or None")
     # rows stay in device memory for the RCCL gather (world 1 + rows="device": the same path without a collective, for tests)
     on_device = compute is None and (rows == "device" or (rows is None and world > 1 and dist.get_backend(group) == "nccl"))
-    if on_device and world > 1 and dist.get_backend(group) != "nccl":
-        raise ValueError("rows='device' needs the nccl backend")
     # ---- this rank's rows
-    import time
-
     t_rows = time.perf_counter()
     p1 = np.full(len(mine), np.nan)
     p2 = np.full(len(mine), np.nan)
@@ -104,19 +139,13 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
     st, msg = 0, ""
     try:
         if compute is None and on_device:
-            # every rank keeps an opened run: its device context and the device row buffer live in it until the gather is over
-            if run is None:
-                run = hostcall.Run(bamp, region, region_file, minlen, support, threads, unphased, sample_name, device=device, frontend=frontend)
+            # the device row buffer lives in the run until the gather is over
             d1, _d2 = run.rows_device(mine, width)
             dev_buf = torch.as_tensor(_DeviceArray(d1, (2, width)), device=torch.device("cuda", device))
         elif len(mine) and compute is None:
             # the product path: the C++ driver on this rank's share (inq_genotype_repeats_rows), which picks the device front end
             # (inflate + record scan + join on this rank's GPU) or the host sweep by the amount of BAM; rows come back as f64
-            if run is not None:
-                p1, p2 = run.rows(mine)
-            else:
-                p1, p2 = hostcall.genotype_repeats_rows(bamp, region, region_file, mine, minlen, support, threads, unphased,
-                                                        device=device, frontend=frontend)
+            p1, p2 = run.rows(mine)
         elif len(mine):  # tests: per-batch compute supplied by the caller (the oracle, on CPU-only machines)
             fe_all = hostcall.FrontEnd(bamp, region=region, region_file=region_file)
             targets = fe_all.targets()
@@ -155,8 +184,7 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
             stats["bam_bytes_read"] = None
     st, msg, bad_rank = _exchange_status(st, msg, rank, world, group)
     if st != 0:
-        if run is not None and rank != 0:
-            run.close()
+        run.close()
         raise hostcall.CallError(st, f"rank {bad_rank}: {msg}" if world > 1 else msg)
     # ---- the one exchange of the path: 2 x f64 per locus to rank 0 (at world size 1 inside an initialised nccl group the same
     # collective runs over the device buffer: the path a one-GPU box can exercise)
@@ -175,8 +203,7 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
         if stats is not None:
             stats["gather_s"] = time.perf_counter() - t_g  # exposed: nothing overlaps it in a one-file call (16 B per locus)
         if rank != 0:
-            if run is not None:
-                run.close()
+            run.close()
             return
         full1, full2 = np.full(n, np.nan), np.full(n, np.nan)
         got = torch.stack(bufs).cpu().numpy() if on_device else [b.numpy() for b in bufs]  # rank 0: ONE copy down

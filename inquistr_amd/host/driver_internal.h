@@ -197,6 +197,19 @@ struct AsyncCtx {
     }
 };
 
+}  // namespace inqhost
+
+// a session: many BAMs on ONE device context (session.cc; a prepared run may be opened on one: run.cc inq_session_run_open)
+struct inq_session {
+    inqhost::AsyncCtx actx;
+    inqhost::HostBufPool pool;
+    inqhost::BedCache bed_cache;
+    int32_t device = 0;
+    uint64_t n_staged = 0;  // inq_session_stage: which of the two sets of device slots the next file takes
+};
+
+namespace inqhost {
+
 // How many processes / device parts share this host's cores with the caller, and which of them it is: the reader pool of a span
 // pipeline takes the granted cores (sched_getaffinity, cut by the cgroup's CPU quota) divided by that number, and binds its threads to
 // L3 domains starting at a different one per sharer.  Default: LOCAL_WORLD_SIZE / LOCAL_RANK as torch.distributed.run exports them

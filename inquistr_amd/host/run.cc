@@ -632,20 +632,26 @@ struct inq_run {
     Prepared P;
     // inq_run_rows_device: the context outlives the call (its rows are read from device memory afterwards)
     std::unique_ptr<AsyncCtx> actx;
+    // inq_session_run_open: context, span buffers and BED cache are the session's (which outlives the run)
+    inq_session *sess = nullptr;
     double *d1 = nullptr, *d2 = nullptr;
     uint64_t dcap = 0;
+    AsyncCtx *ctx_of_rows() { return sess ? &sess->actx : actx.get(); }
     ~inq_run() {
-        if (actx && actx->wait()) inq_dev_free_rows(actx->ctx, d1);  // (d2 points into the same allocation)
+        AsyncCtx *c = ctx_of_rows();
+        if (d1 && c && c->wait()) inq_dev_free_rows(c->ctx, d1);  // (d2 points into the same allocation)
     }
 };
 
-static int inq_run_open_impl(const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap) {
+static int inq_run_open_impl(const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap, inq_session *sess = nullptr) {
     if (!out || !args) return INQ_EXIT_ERROR;
     *out = nullptr;
     std::unique_ptr<inq_run> R(new inq_run());
     R->args.reset(new OwnedArgs(*args));
+    R->sess = sess;
+    if (sess) R->args->a.device = sess->device;
     std::string msg;
-    int rc = prepare(&R->args->a, R->P, msg);
+    int rc = prepare(&R->args->a, R->P, msg, sess ? &sess->bed_cache : nullptr);
     if (rc != INQ_EXIT_OK) {
         set_err(errbuf, errcap, msg);
         return rc;
@@ -655,6 +661,13 @@ static int inq_run_open_impl(const inq_call_args_t *args, inq_run_t **out, char 
 }
 int inq_run_open(const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap) {
     INQ_GUARD(inq_run_open_impl(args, out, errbuf, errcap), errbuf, errcap)
+}
+int inq_session_run_open(inq_session_t *s, const inq_call_args_t *args, inq_run_t **out, char *errbuf, size_t errcap) {
+    if (!s) {
+        set_err(errbuf, errcap, "null session");
+        return INQ_EXIT_ERROR;
+    }
+    INQ_GUARD(inq_run_open_impl(args, out, errbuf, errcap, s), errbuf, errcap)
 }
 uint64_t inq_run_n_targets(const inq_run_t *r) { return r ? r->P.targets.size() : 0; }
 const char *inq_run_sample(const inq_run_t *r) { return r ? r->P.sample.c_str() : ""; }
@@ -679,10 +692,18 @@ static int inq_run_rows_impl(inq_run_t *r, const uint32_t *target_index, uint64_
         return INQ_EXIT_ERROR;
     }
     const auto t_start = std::chrono::steady_clock::now();
-    AsyncCtx actx;
-    actx.start(r->args->a.device);
     RowsOut ro;
     ro.idx = target_index, ro.n = n_index, ro.p1 = phase1, ro.p2 = phase2, ro.active = true;
+    if (r->sess) {  // the session's context and span buffers: nothing is made or torn down per call
+        SessionHooks hooks;
+        hooks.pool = &r->sess->pool;
+        const bool keep_leak = r->sess->actx.leak;
+        const int rc = genotype_prepared(&r->args->a, r->sess->actx, r->P, -1, errbuf, errcap, ro, t_start, hooks);
+        r->sess->actx.leak = keep_leak;  // the context belongs to the session
+        return rc;
+    }
+    AsyncCtx actx;
+    actx.start(r->args->a.device);
     return genotype_prepared(&r->args->a, actx, r->P, -1, errbuf, errcap, ro, t_start);
 }
 int inq_run_rows(inq_run_t *r, const uint32_t *target_index, uint64_t n_index, double *phase1, double *phase2, char *errbuf, size_t errcap) {
@@ -696,29 +717,32 @@ static int inq_run_rows_device_impl(inq_run_t *r, const uint32_t *target_index, 
     }
     *d_phase1 = *d_phase2 = nullptr;
     const auto t_start = std::chrono::steady_clock::now();
-    if (!r->actx) {
+    if (!r->sess && !r->actx) {
         r->actx.reset(new AsyncCtx());
         r->actx->start(r->args->a.device);
     }
-    if (!r->actx->wait()) {
-        set_err(errbuf, errcap, ctx_failure_message(*r->actx));
+    AsyncCtx &actx = *r->ctx_of_rows();
+    if (!actx.wait()) {
+        set_err(errbuf, errcap, ctx_failure_message(actx));
         return INQ_EXIT_ERROR;
     }
     // one array of 2 x width: phase1 row, phase2 row (one collective's buffer); made afresh per call - every entry starts as NaN, a
     // device allocation costs microseconds (tools/alloc_probe.hip)
     const uint64_t w = std::max<uint64_t>(width, 1);
-    inq_dev_free_rows(r->actx->ctx, r->d1);
+    inq_dev_free_rows(actx.ctx, r->d1);
     r->d1 = r->d2 = nullptr, r->dcap = 0;
-    if (inq_dev_alloc_rows(r->actx->ctx, 2 * w, &r->d1) != INQ_OK) {
+    if (inq_dev_alloc_rows(actx.ctx, 2 * w, &r->d1) != INQ_OK) {
         set_err(errbuf, errcap, "cannot allocate the device row arrays");
         return INQ_EXIT_ERROR;
     }
     r->d2 = r->d1 + w, r->dcap = w;
     RowsOut ro;
     ro.idx = target_index, ro.n = n_index, ro.active = true, ro.d1 = r->d1, ro.d2 = r->d2, ro.dcap = r->dcap;
-    const bool keep_leak = r->actx->leak;
-    const int rc = genotype_prepared(&r->args->a, *r->actx, r->P, -1, errbuf, errcap, ro, t_start);
-    r->actx->leak = keep_leak;  // the context belongs to the run
+    SessionHooks hooks;
+    if (r->sess) hooks.pool = &r->sess->pool;
+    const bool keep_leak = actx.leak;
+    const int rc = genotype_prepared(&r->args->a, actx, r->P, -1, errbuf, errcap, ro, t_start, hooks);
+    actx.leak = keep_leak;  // the context belongs to the run (or its session)
     if (rc != INQ_EXIT_OK) return rc;
     *d_phase1 = r->d1, *d_phase2 = r->d2;
     return INQ_EXIT_OK;

@@ -7,12 +7,7 @@ using namespace inqhost;
 // src/combine.rs).  The HIP runtime's start-up (0.1 - 0.3 s, the whole cost of a 1 GB file) is paid once; span buffers are
 // reused; and while file k is being called, file k + 1 is opened, its targets parsed, its spans planned, read and uploaded
 // into the other set of device staging slots.  Each file's output is byte for byte that of its own `inquistr call`.
-struct inq_session {
-    AsyncCtx actx;
-    HostBufPool pool;
-    BedCache bed_cache;
-    uint64_t n_staged = 0;  // inq_session_stage: which of the two sets of device slots the next file takes
-};
+// (struct inq_session: driver_internal.h)
 
 namespace {
 struct StagedFile {
@@ -63,6 +58,7 @@ int inq_session_open(int32_t device, inq_session_t **out) {
     *out = nullptr;
     try {
         inq_session *S = new inq_session();
+        S->device = device;
         S->actx.start(device);  // returns at once: the runtime starts on its own thread
         *out = S;
         return INQ_EXIT_OK;

@@ -171,3 +171,17 @@ def test_session_and_run_fail_loudly_without_gpu(tmp_path):
     text = (tmp_path / "rows.inq").read_text().splitlines()
     assert text[0] == "chromosome\tbegin\tend\tS_H1\tS_H2" and len(text) == run.n_targets + 1 and text[1].endswith("\tNaN\tNaN")
     run.close()
+    # a run opened ON a session (inq_session_run_open: what a resident rank of call_dist uses): the same split, the same loud failure
+    with call.Session(0) as S:
+        srun = call.Run(bam, None, bed, threads=2, sample_name="S", session=S)
+        o2, c2 = srun.partition(3)
+        assert np.array_equal(o2, order) and np.array_equal(c2, cuts)
+        for _ in range(2):  # (the session survives the failing call)
+            with pytest.raises(call.CallError) as e:
+                srun.rows(order[:4])
+            assert e.value.status == 1 and "no CPU fallback" in e.value.message
+        with pytest.raises(call.CallError) as e:
+            srun.rows_device(order[:4], 8)
+        assert e.value.status == 1
+        # (left open: the session closes the runs still open on it before it goes)
+    assert not (srun._h and srun._h.value)

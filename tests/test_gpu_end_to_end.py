@@ -608,6 +608,46 @@ def test_rows_left_in_device_memory_equal_the_host_rows(tmp_path, frontend, unph
     assert out.read_text() == _expected_text(loci, recs, unphased, 5, 3, "S", 4)
 
 
+@pytest.mark.parametrize("frontend", ["device", "host"])
+def test_runs_on_one_session_equal_runs_of_their_own(tmp_path, frontend):
+    """inq_session_run_open: runs opened on ONE session (its device context, span buffers and BED cache - what a resident rank of
+    call_dist keeps for the life of the process) give the rows of runs that make their own context, file after file, host rows and
+    device rows alike; and call_dist, which takes the process's session by itself, prints the same text pass after pass."""
+    import torch
+
+    from inquistr_amd import call_dist
+
+    cases = [_make_case(tmp_path / f"c{k}", 90 + k, n_loci=60 + 11 * k, ultra_long=True) for k in range(2) if not (tmp_path / f"c{k}").mkdir()]
+    with call.Session(0) as S:
+        for rep in range(2):
+            for bam, bed, loci, recs in cases:
+                for unphased in (False, True):
+                    own = call.Run(bam, None, bed, 5, 3, 4, unphased, "S", frontend=frontend)
+                    order, cuts = own.partition(2)
+                    mine = order[int(cuts[1]):]
+                    want1, want2 = own.rows(mine)
+                    own.close()
+                    srun = call.Run(bam, None, bed, 5, 3, 4, unphased, "S", frontend=frontend, session=S)
+                    got1, got2 = srun.rows(mine)
+                    assert np.array_equal(np.nan_to_num(got1, nan=-7e77), np.nan_to_num(want1, nan=-7e77))
+                    assert np.array_equal(np.nan_to_num(got2, nan=-7e77), np.nan_to_num(want2, nan=-7e77))
+                    d1, _ = srun.rows_device(mine, len(mine) + 3)
+                    t = torch.as_tensor(call_dist._DeviceArray(d1, (2, len(mine) + 3)), device="cuda:0").cpu().numpy()
+                    assert np.array_equal(np.nan_to_num(t[0, : len(mine)], nan=-7e77), np.nan_to_num(want1, nan=-7e77))
+                    assert np.array_equal(np.nan_to_num(t[1, : len(mine)], nan=-7e77), np.nan_to_num(want2, nan=-7e77))
+                    assert (~np.isnan(want1)).sum() > 1
+                    srun.close()
+    for rep in range(3):
+        bam, bed, loci, recs = cases[rep % 2]
+        out = tmp_path / f"p{rep}.inq"
+        st = {}
+        with open(out, "w") as f:
+            call_dist.genotype_repeats_distributed(bam, None, bed, 5, 3, 4, rep == 1, "S", out=f, frontend=frontend, stats=st)
+        assert out.read_text() == _expected_text(loci, recs, rep == 1, 5, 3, "S", 4)
+        assert st["open_s"] > 0 and st["rows_s"] > 0
+    assert len(call_dist._sessions) == 1  # one context for the three passes
+
+
 def test_rows_gathered_over_rccl_from_device_memory(tmp_path):
     """The collective of the one-process-per-GPU form on what a one-GPU box offers: a `nccl` (= RCCL) process group of world size 1,
     rows left in device memory by the flushes (rows='device'), `dist.gather` reading them there, rank 0 copying the gathered block
