@@ -1015,8 +1015,10 @@ def main():
                     help="END-TO-END at N ranks: inquistr_amd.call_dist over one SEQ-bearing BAM, strong scaling (see l2_dist()); --steps = passes over the file")
     ap.add_argument("--l2-dist-loci", type=int, default=20_000, help="loci of that BAM (0.32 GB per 1 000; north_star's configuration: 100000)")
     ap.add_argument("--no-l2-dist-native", action="store_true", help="skip the one-process `inquistr call --devices` run of --l2-dist")
-    ap.add_argument("--l2-dist-default-loci", type=int, default=24_000,
-                    help="N > 1, default line: loci of the SEQ-bearing BAM of its `l2_dist` block (the end-to-end multi-rank measurement beside the L0 one; 0 skips it)")
+    ap.add_argument("--l2-dist-default-loci", type=int, default=-1,
+                    help="N > 1, default line: loci of the SEQ-bearing BAM of its `l2_dist` block (the end-to-end multi-rank measurement beside the L0 one; 0 skips it; "
+                         "-1 = the largest size up to north_star's 100 000 that rank 0's granted cores write within --l2-dist-gen-budget seconds and disk / page cache admit)")
+    ap.add_argument("--l2-dist-gen-budget", type=float, default=45.0, help="seconds the file of the default N > 1 line's `l2_dist` block may take to write")
     ap.add_argument("--native-devices", default="", help="--l2-dist at one rank: the device list of the one-process run (e.g. 0,0,0,0 on a one-GPU box)")
     args = ap.parse_args()
     if args.l2_dist:
@@ -1105,7 +1107,25 @@ def main():
         lo, hi = rank * per_gpu, (rank + 1) * per_gpu
         total = per_gpu * world
     n_mine = hi - lo
-    want_l2_dist = world > 1 and not args.no_l2 and args.l2_dist_default_loci > 0 and args.scaling == "weak" and args.workload == "unphased100k"
+    want_l2_dist = world > 1 and not args.no_l2 and args.l2_dist_default_loci != 0 and args.scaling == "weak" and args.workload == "unphased100k"
+    l2_dist_loci = args.l2_dist_default_loci
+    if want_l2_dist and l2_dist_loci < 0:
+        # strong scaling over N links wants a file whose per-rank share is still many spans: the largest up to north_star's 100 000 loci
+        # (31 GB) that rank 0's cores deflate within the budget (~55 loci per second and core at level 6) and the box can hold twice
+        import shutil
+        import tempfile
+
+        rate = (55.0 if args.l2_level >= 4 else 160.0) * host_cores_available()
+        l2_dist_loci = min(100_000, max(8_000, int(rate * args.l2_dist_gen_budget) // 1000 * 1000))
+        try:
+            avail = int(next(ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")).split()[1]) * 1024
+            free = shutil.disk_usage(tempfile.gettempdir()).free
+            l2_dist_loci = max(2_000, min(l2_dist_loci, int(min(free / 0.43e6, avail / 0.86e6)) // 1000 * 1000))
+        except Exception:  # noqa: BLE001
+            pass
+        pick = [l2_dist_loci]
+        dist.broadcast_object_list(pick, src=0)  # (every rank must name the same file)
+        l2_dist_loci = pick[0]
     final_line = None
 
     ctx = hipcall.Context(local_rank)
@@ -1455,7 +1475,7 @@ def main():
             print(json.dumps(dict(final_line, partial="L0 weak scaling; the full line with the end-to-end `l2_dist` block follows")), flush=True)
         block = None
         try:
-            block = l2_dist_core(args, rank, world, local_rank, dev, args.backend, args.l2_dist_default_loci, 2, 1)
+            block = l2_dist_core(args, rank, world, local_rank, dev, args.backend, l2_dist_loci, 2, 1)
         except Exception as e:  # noqa: BLE001
             block = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:

@@ -22,7 +22,7 @@ def _san_libs():
 
 @pytest.mark.skipif(_san_libs() is None, reason="sanitizer runtimes not installed")
 def test_host_front_end_under_asan_ubsan():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "inquistr_amd", "host"), "../lib/libinquistr_host_asan.so"],
+    subprocess.check_call(["make", "-j8", "-C", os.path.join(ROOT, "inquistr_amd", "host"), "../lib/libinquistr_host_asan.so"],
                           stdout=subprocess.DEVNULL)
     env = dict(os.environ)
     env["LD_PRELOAD"] = " ".join(_san_libs())
@@ -47,7 +47,7 @@ def test_host_threads_under_tsan():
     """The sweep front end's worker pool, the span loader's parallel reads, the lazily built index anchors (shared by the
     span planner's helper thread and the loader), the device parts of the multi-device entry and the bounded waits for a context
     thread that never finishes under ThreadSanitizer.  The CLI test is left out: it starts another program."""
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "inquistr_amd", "host"), "../lib/libinquistr_host_tsan.so"],
+    subprocess.check_call(["make", "-j8", "-C", os.path.join(ROOT, "inquistr_amd", "host"), "../lib/libinquistr_host_tsan.so"],
                           stdout=subprocess.DEVNULL)
     env = dict(os.environ)
     env["LD_PRELOAD"] = _tsan_lib()
