@@ -127,3 +127,37 @@ def test_decision_on_the_benchmark_kinds(probe, kind, level, want):
     assert probe.inq_probe_wants_pairs(comp, len(comp), blocks.ctypes.data, len(blocks)) == want
     # nothing to look at: the default form
     assert probe.inq_probe_wants_pairs(comp, len(comp), blocks.ctypes.data, 0) == 1
+
+
+def test_probe_reads_libdeflate_headers_too(probe):
+    """htslib built with libdeflate writes other headers (other code-length code shapes, block splitting): the probe's reading equals
+    the plain-Python one on them as well, every stream inflates to its input under zlib and under libdeflate's own decoder, and the
+    decision on base-quality-like bytes is the one taken for zlib's streams (literal-heavy: the pairs form)."""
+    from tools import libdeflate_shim as ld
+
+    if not ld.available():
+        pytest.skip("libdeflate runtime not in the image")
+    rng = random.Random(11)
+    seen = set()
+    for trial in range(60):
+        kind = trial % 4
+        n = rng.randrange(200, 60000)
+        if kind == 0:
+            data = bytes(rng.randrange(0, 51) for _ in range(n))
+        elif kind == 1:
+            data = b"".join(struct.pack("<I", rng.randint(1, 400) << 4 | rng.choice([0, 0, 1, 2])) for _ in range(n // 4))
+        elif kind == 2:
+            data = bytes(rng.choice(b"ACGTN") for _ in range(n))
+        else:
+            data = bytes(rng.getrandbits(8) for _ in range(n))
+        payload = ld.Compressor(rng.choice([1, 3, 6, 9, 12])).compress(data)
+        assert zlib.decompressobj(-15).decompress(payload) == data
+        rc, back = ld.decompress(payload, len(data))
+        assert rc == 0 and back == data
+        want = _py_mass(payload)
+        got = probe.inq_probe_literal_mass(payload, len(payload))
+        assert got == (-1 if want is None else want), (trial, kind)
+        seen.add(want is None)
+        if want is not None and kind == 0 and n > 4000:
+            assert want / 32768.0 > 0.42, (trial, want)  # base qualities: literal-heavy, the pairs form
+    assert False in seen

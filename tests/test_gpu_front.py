@@ -395,6 +395,30 @@ def test_device_front_end_text_equals_host_front_end(tmp_path, seed, unphased, t
     assert texts["host"] == texts["device"] and texts["host"].count("\n") == len(loci) + 1
 
 
+@pytest.mark.skipif(not __import__("tools.libdeflate_shim", fromlist=["x"]).available(), reason="libdeflate runtime not in the image")
+@pytest.mark.parametrize("level,unphased", [(6, False), (12, True), (1, False)])
+def test_bam_written_with_libdeflate_through_both_front_ends(tmp_path, monkeypatch, level, unphased):
+    """A BAM whose BGZF blocks libdeflate compressed (what an htslib built with libdeflate writes; small blocks so that records
+    straddle many of them): the device front end's text equals the host sweep's (zlib inflate) and the Python restatement's."""
+    from inquistr_amd import call
+    from tests.test_gpu_end_to_end import _expected_text
+    from tests.test_host_frontend import _make_case
+    from tools import bamio
+    from tools import libdeflate_shim as ld
+
+    comp = ld.Compressor(level)
+    monkeypatch.setattr(bamio, "bgzf_block", lambda data, lv=1: ld.bgzf_block(data, level, comp))
+    bam, bed, loci, recs = _make_case(tmp_path, 40 + level, n_loci=110, ultra_long=True, block=3000 if level == 12 else bamio.BLOCK)
+    monkeypatch.undo()
+    texts = {}
+    for fe in ("host", "device"):
+        path = tmp_path / f"{fe}.inq"
+        with open(path, "w") as f:
+            call.genotype_repeats(bam, None, bed, 5, 3, 4, unphased, "S", None, out=f, frontend=fe)
+        texts[fe] = path.read_text()
+    assert texts["host"] == texts["device"] == _expected_text(loci, recs, unphased, 5, 3, "S", 4)
+
+
 def test_device_front_end_through_a_csi_index(tmp_path):
     """A BAM that only has a .csi next to it ([3P] IndexedReader::from_path takes either index, src/call.rs:242): spans planned from
     the .csi's bins and per-bin offsets; the text equals the host sweep's and the Python restatement's."""
@@ -663,6 +687,128 @@ def test_inflate_fuzz_agrees_with_zlib_on_mutated_streams(ctx):
             assert status[i] != 0, (i, len(p), n)
     assert 400 < n_ok < 3600  # the corpus exercises both outcomes
     assert (rc == 0) == (n_ok == len(payloads))
+
+
+def _bam_like_payloads(rng: random.Random):
+    """What the blocks of a long-read BAM hold: fixed fields + CIGARs, packed bases, base qualities, ML / MM tags."""
+    out = []
+    nib = [1, 2, 4, 8]
+    for kind in range(4):
+        parts = []
+        while sum(len(x) for x in parts) < 65000:
+            if kind in (0, 3):  # records without SEQ: fixed fields, read name, CIGAR words
+                parts.append(struct.pack("<iiBBHHHIiii", 0, rng.randint(1, 1 << 27), 9, 60, 4681, rng.randint(50, 300), 16 * rng.randint(0, 1), 0, -1, -1, 0))
+                parts.append(b"read%06d\0" % rng.randint(0, 999999))
+                parts.append(b"".join(struct.pack("<I", rng.randint(1, 400) << 4 | rng.choice([0, 0, 0, 1, 2, 7, 8])) for _ in range(rng.randint(50, 300))))
+                if kind == 3:
+                    parts.append(b"HPC" + bytes([rng.randint(1, 2)]) + b"SAZchr7,%d,+,50M,60,0;\0" % rng.randint(1, 1 << 27))
+            elif kind == 1:  # packed bases
+                parts.append(bytes(rng.choice(nib) << 4 | rng.choice(nib) for _ in range(6000)))
+            else:  # qualities (skewed Phred) and a methylation tag
+                parts.append(bytes(min(50, max(1, int(rng.gammavariate(4.0, 5.0)))) for _ in range(6000)))
+                parts.append(b"MLBC" + struct.pack("<I", 300) + bytes(rng.choice([0, 3, 250, 255]) for _ in range(300)))
+        out.append(b"".join(parts)[:65280])
+    return out
+
+
+@pytest.mark.skipif(not __import__("tools.libdeflate_shim", fromlist=["x"]).available(), reason="libdeflate runtime not in the image")
+def test_inflate_of_libdeflate_streams(ctx):
+    """htslib is commonly built with libdeflate: BAMs written by it hold DEFLATE streams zlib's compressor never produces (other block
+    splitting, lazy / near-optimal match choices from level 8 on, other code shapes).  Every payload class of the zlib test and
+    BAM-like bytes, compressed by the image's libdeflate at levels 0 - 12, through every form of the device inflate (the fixture's):
+    the bytes of the input, and what libdeflate's own decoder and zlib's make of the same stream."""
+    from tools import libdeflate_shim as ld
+
+    rng = random.Random(77)
+    blobs, want = [], []
+    for data in _payloads(rng) + _bam_like_payloads(rng):
+        for level in (0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 12):
+            if level == 0 and len(data) > 65000:
+                data = data[:65000]
+            try:
+                blob = ld.bgzf_block(data, level)
+            except AssertionError:
+                continue  # incompressible bytes that do not fit one block at this level
+            payload = blob[18:-8]
+            assert zlib.decompressobj(-15).decompress(payload) == data
+            rc, back = ld.decompress(payload, len(data))
+            assert rc == 0 and back == data
+            blobs.append(blob)
+            want.append(data)
+    comp = b"".join(blobs)
+    blocks = hipcall.scan_bgzf(comp)
+    assert len(blocks) == len(want) and len(want) > 100
+    rc, out, status = ctx.bgzf_inflate(comp, blocks)
+    assert rc == 0 and not status.any()
+    for b, w in zip(blocks, want):
+        got = out[int(b["out_off"]) : int(b["out_off"]) + int(b["isize"])].tobytes()
+        assert got == w, (len(w), w[:16])
+
+
+@pytest.mark.skipif(not __import__("tools.libdeflate_shim", fromlist=["x"]).available(), reason="libdeflate runtime not in the image")
+def test_inflate_fuzz_on_mutated_libdeflate_streams(ctx):
+    """The mutation fuzz with libdeflate-written originals (levels 1 - 12): accept exactly what zlib accepts, with the same bytes."""
+    from tools import libdeflate_shim as ld
+
+    rng = random.Random(4711)
+    base = []
+    for k in range(24):
+        n = rng.choice([40, 300, 2000, 9000, 30000])
+        kind = k % 4
+        if kind == 0:
+            data = bytes(rng.choice(b"ACGTN=") for _ in range(n))
+        elif kind == 1:
+            data = bytes(min(50, max(1, int(rng.gammavariate(4.0, 5.0)))) for _ in range(n))
+        elif kind == 2:
+            data = (bytes(rng.getrandbits(8) for _ in range(17)) * (n // 17 + 1))[:n]
+        else:
+            data = b"".join(struct.pack("<I", rng.randint(1, 400) << 4 | rng.choice([0, 1, 2, 4])) for _ in range(n // 4))
+        base.append((ld.Compressor(rng.choice([1, 3, 6, 6, 9, 12])).compress(data), len(data)))
+    payloads, isizes = [], []
+    for _ in range(3000):
+        p, n = rng.choice(base)
+        p = bytearray(p)
+        for _ in range(rng.choice([0, 1, 1, 1, 2, 5])):
+            how = rng.random()
+            at = rng.randrange(len(p))
+            if how < 0.6:
+                p[at] ^= 1 << rng.randrange(8)
+            elif how < 0.8:
+                p[at] = rng.getrandbits(8)
+            elif how < 0.9 and len(p) > 8:
+                del p[rng.randrange(len(p) // 2, len(p)):]
+            else:
+                p[at:at] = bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 4)))
+        payloads.append(bytes(p))
+        isizes.append(n if rng.random() < 0.9 else max(0, n + rng.choice([-1, 1, 7])))
+    comp = bytearray()
+    blocks = np.zeros(len(payloads), dtype=hipcall.BGZF_BLOCK_DTYPE)
+    uo = 0
+    for i, (p, n) in enumerate(zip(payloads, isizes)):
+        blocks[i] = (len(comp), len(p), n, uo)
+        comp += p + bytes(8)
+        uo += n
+    ctx.set_option("verify_crc", 0)
+    try:
+        rc, out, status = ctx.bgzf_inflate(bytes(comp), blocks, check=False)
+    finally:
+        ctx.set_option("verify_crc", 1)
+    n_ok = 0
+    for i, (p, n) in enumerate(zip(payloads, isizes)):
+        d = zlib.decompressobj(-15)
+        try:
+            got = d.decompress(p, n + 1)
+            accept = d.eof and len(got) == n
+        except zlib.error:
+            accept, got = False, b""
+        o = int(blocks[i]["out_off"])
+        if accept:
+            n_ok += 1
+            assert status[i] == 0, (i, hex(int(status[i])))
+            assert out[o : o + n].tobytes() == got, i
+        else:
+            assert status[i] != 0, (i, len(p), n)
+    assert 300 < n_ok < 2800
 
 
 def test_device_aux_walk_skips_long_strings_of_every_length(tmp_path):

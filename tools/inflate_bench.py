@@ -11,11 +11,30 @@ from inquistr_amd import hipcall, synth  # noqa: E402
 from tools import bamio, make_synth_bam  # noqa: E402
 
 
+def _block_writer():
+    """bamio.bgzf_block (zlib), or CODEC=libdeflate: the same blocks as an htslib built with libdeflate writes them."""
+    import os
+
+    if os.environ.get("CODEC") == "libdeflate":
+        from tools import libdeflate_shim
+
+        comps = {}
+
+        def mk(data, level):
+            if level not in comps:
+                comps[level] = libdeflate_shim.Compressor(level)
+            return libdeflate_shim.bgzf_block(data, level, comps[level])
+
+        return mk
+    return bamio.bgzf_block
+
+
 def make_blocks(n_blocks: int, level: int, kind: str = "cigar"):
+    bgzf_block = _block_writer()
     if kind == "qual":  # what most of a real long-read BAM is: base qualities (Phred 0..50) and packed bases
         rng = np.random.default_rng(3)
         base = (rng.integers(0, 51, 64 * bamio.BLOCK, dtype=np.uint8)).tobytes()
-        comp = [bamio.bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base), bamio.BLOCK)]
+        comp = [bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base), bamio.BLOCK)]
         return b"".join((comp * (n_blocks // len(comp) + 1))[:n_blocks])
     if kind in ("seq", "ont"):
         # seq: packed bases (two per byte, 16 equiprobable byte values); ont: long reads as a nanopore BAM holds them:
@@ -33,7 +52,7 @@ def make_blocks(n_blocks: int, level: int, kind: str = "cigar"):
                 parts += [bytes(36), packed[at : at + 12_000].tobytes(), q[at : at + 24_000].tobytes(), b"MLB" + q[at : at + 400].tobytes()]
                 at += 36_000
             base = b"".join(parts)
-        comp = [bamio.bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base) - bamio.BLOCK, bamio.BLOCK)]
+        comp = [bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base) - bamio.BLOCK, bamio.BLOCK)]
         return b"".join((comp * (n_blocks // len(comp) + 1))[:n_blocks])
     wl = synth.WORKLOADS["unphased100k"]
     need = n_blocks * bamio.BLOCK
@@ -45,7 +64,7 @@ def make_blocks(n_blocks: int, level: int, kind: str = "cigar"):
         blob += data
         g += 200
     base = bytes(blob)
-    comp = [bamio.bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base) - bamio.BLOCK, bamio.BLOCK)]
+    comp = [bgzf_block(base[i : i + bamio.BLOCK], level) for i in range(0, len(base) - bamio.BLOCK, bamio.BLOCK)]
     comp = (comp * (n_blocks // len(comp) + 1))[:n_blocks]
     return b"".join(comp)
 
