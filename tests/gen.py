@@ -163,3 +163,42 @@ def same_f64(a: np.ndarray, b: np.ndarray) -> bool:
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return a.shape == b.shape and bool(np.all((np.isnan(a) & np.isnan(b)) | (a == b)))
+
+
+def mixed_depth_case(seed: int, case_index: int = 0):
+    """One batch that mixes the depth classes of DESIGN.md 3.2 - <= 64 offered reads, 65 - 256, 257 - 2 048 (reduced by the workgroup
+    that walked them), 2 049 - 16 384, several loci of 16 385 - 65 536 (walked by a group of workgroups each) and, every fourth
+    case_index, one locus beyond 65 536 (the whole grid) -, reads drawn from a pool of shapes (ties everywhere) plus reads with ONE
+    indel of a wide range of lengths inside the window (Calls of many distinct values), HP / mapq / strand / 2D bits random per read,
+    `support` from 1 to beyond a group's size.  Returns (Batch, depths)."""
+    rng = random.Random(seed)
+    unphased = bool(case_index & 1)
+    support = rng.choice([1, 2, 3, 3, 5, 40, 700, 9000])
+    minlen = rng.choice([5, 0, 12])
+    start, end = 700_000, 700_000 + rng.choice([0, 40, 140])
+    shapes = random_locus_reads(rng, start, end, rng.choice([12, 60, 200]), long_every=rng.choice([0, 7]))
+    wide = rng.choice([3, 40, 3000])
+    for _ in range(rng.choice([0, 100, 400])):
+        pos = start - 10 - rng.randint(1, 300)
+        op = rng.choice("IIID")
+        ln = rng.randint(1, wide) if op == "I" else rng.randint(1, 30)
+        lead = ("S", rng.choice([4, 30])) if rng.random() < 0.1 else None
+        cig = ([lead] if lead else []) + [("M", start - pos + rng.randint(0, end - start + 5)), (op, ln), ("M", 400)]
+        shapes.append(py.Record(pos=pos if not lead else start + rng.randint(-5, 5), cigar=cig, mapq=60, flag=rng.choice([0, 16])))
+    n_pool = 72_000 if case_index % 4 == 0 else rng.choice([21_000, 30_000, 40_000])
+    pool = [(shapes[rng.randrange(len(shapes))], rng.choice([9, 60, 60, 60]), rng.choice([None, 0, 1, 1, 2, 2]), rng.random() < 0.15) for _ in range(n_pool)]
+    bb = BatchBuilder(minlen=minlen, support=support, unphased=unphased)
+    ids = [bb.add_read(r.pos, encode_cigar(r.cigar), mapq=mq, phase=ph, reverse=bool(r.flag & 0x10), is_2d=twod) for r, mq, ph, twod in pool]
+    order = sorted(range(len(ids)), key=lambda k: (bb._reads[ids[k]][2], k))
+    depths = []
+    for lo_d, hi_d, cnt in ((1, 64, 6), (65, 256, 5), (257, 2048, 5), (2049, 16384, 3), (16385, min(65536, n_pool), rng.choice([2, 5, 9]))):
+        depths += [rng.randint(lo_d, hi_d) for _ in range(cnt)]
+    if n_pool > 65_536:
+        depths.append(rng.randint(65_537, n_pool))
+    depths += [64, 65, 256, 257, 2048, 2049, 16384, 16385][: rng.randint(0, 8)]
+    rng.shuffle(depths)
+    for d in depths:
+        off = rng.randint(0, n_pool - d)
+        sh = rng.choice([-10, 0, 0, 10])  # (windows shifted against each other: not every locus sees the same Calls)
+        bb.add_locus(start + sh, end + sh, [ids[k] for k in order[off : off + d]])
+    return bb.build(), depths

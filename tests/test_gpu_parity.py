@@ -426,6 +426,24 @@ def test_very_deep_locus_with_calls_of_every_spread(ctx, orc, unphased, spread):
             assert not np.isnan(got.phase2[0]) and not np.isnan(got.phase2[1])
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_batches_that_mix_every_depth_class(ctx, orc, case):
+    """One batch with loci of every depth class side by side (gen.mixed_depth_case: <= 64, 65 - 256, 257 - 2 048, 2 049 - 16 384, several
+    of 16 385 - 65 536, cases 0 and 4 one beyond 65 536; class boundaries themselves; Calls of few or many distinct values; support 1 ...
+    9 000; both modes; with and without the caller's depth hint): the three launches behind one call share work lists, scratch and the
+    persistent tail - rows, per-pair Calls and bits, tie counts equal the oracle's.  tools/soak_deep.py runs hundreds of these."""
+    batch, depths = gen.mixed_depth_case(880_000 + case, case)
+    ctx.set_option("max_reads_hint", 0 if case % 3 else int(max(depths)))
+    try:
+        rc, got = ctx.call_batch(batch, debug=True)
+    finally:
+        ctx.set_option("max_reads_hint", 0)
+    oc, want = orc.call_batch(batch, debug=True, threads=8)
+    assert rc == oc == 0
+    _assert_same(got, want, f"mixed depths case {case}: {sorted(depths)[-4:]}")
+    assert max(depths) > (65_536 if case % 4 == 0 else 16_384) and batch.n_loci == len(depths)
+
+
 def test_allocation_that_meets_out_of_memory_frees_the_parked_buffers_and_tries_again(orc):
     """ensure() parks a buffer it has outgrown instead of freeing it (no wait for the device); an allocation that then fails for lack
     of memory must give those back and try again rather than fail the call.  The failure is injected ("test_fail_allocs":

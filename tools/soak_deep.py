@@ -8,14 +8,12 @@ size, both modes, with and without the caller's depth hint.  Rows, per-pair Call
 usage: python tools/soak_deep.py [--cases 60] [--seed0 500000]"""
 import argparse
 import os
-import random
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-from inquistr_amd import batch as B
 from inquistr_amd import hipcall
 from oracle import orc
 from tests import gen
@@ -30,39 +28,8 @@ t0 = time.time()
 with hipcall.Context(0) as ctx:
     for i in range(a.cases):
         seed = a.seed0 + i
-        rng = random.Random(seed)
-        unphased = bool(i & 1)
-        support = rng.choice([1, 2, 3, 3, 5, 40, 700, 9000])
-        minlen = rng.choice([5, 0, 12])
-        start, end = 700_000, 700_000 + rng.choice([0, 40, 140])
-        shapes = gen.random_locus_reads(rng, start, end, rng.choice([12, 60, 200]), long_every=rng.choice([0, 7]))
-        # ... and reads that span the window with ONE indel inside it, lengths from a wide range: Calls of many distinct values
-        # (the generator's shapes mostly call 0), or of few (ties), by the case
-        wide = rng.choice([3, 40, 3000])
-        for _ in range(rng.choice([0, 100, 400])):
-            pos = start - 10 - rng.randint(1, 300)
-            op = rng.choice("IIID")
-            ln = rng.randint(1, wide) if op == "I" else rng.randint(1, 30)
-            lead = ("S", rng.choice([4, 30])) if rng.random() < 0.1 else None
-            cig = ([lead] if lead else []) + [("M", start - pos + rng.randint(0, end - start + 5)), (op, ln), ("M", 400)]
-            shapes.append(gen.py.Record(pos=pos if not lead else start + rng.randint(-5, 5), cigar=cig, mapq=60, flag=rng.choice([0, 16])))
-        n_pool = rng.choice([21_000, 30_000, 72_000 if i % 4 == 0 else 40_000])
-        pool = [(shapes[rng.randrange(len(shapes))], rng.choice([9, 60, 60, 60]), rng.choice([None, 0, 1, 1, 2, 2]), rng.random() < 0.15) for _ in range(n_pool)]
-        bb = B.BatchBuilder(minlen=minlen, support=support, unphased=unphased)
-        ids = [bb.add_read(r.pos, B.encode_cigar(r.cigar), mapq=mq, phase=ph, reverse=bool(r.flag & 0x10), is_2d=twod) for r, mq, ph, twod in pool]
-        order = sorted(range(len(ids)), key=lambda k: (bb._reads[ids[k]][2], k))
-        depths = []
-        for lo_d, hi_d, cnt in ((1, 64, 6), (65, 256, 5), (257, 2048, 5), (2049, 16384, 3), (16385, min(65536, n_pool), rng.choice([2, 5, 9]))):
-            depths += [rng.randint(lo_d, hi_d) for _ in range(cnt)]
-        if n_pool > 65_536:
-            depths.append(rng.randint(65_537, n_pool))
-        depths += [64, 65, 256, 257, 2048, 2049, 16384, 16385][: rng.randint(0, 8)]
-        rng.shuffle(depths)
-        for j, d in enumerate(depths):
-            off = rng.randint(0, n_pool - d)
-            sh = rng.choice([-10, 0, 0, 10])  # (windows shifted against each other: not every locus sees the same Calls)
-            bb.add_locus(start + sh, end + sh, [ids[k] for k in order[off : off + d]])
-        batch = bb.build()
+        batch, depths = gen.mixed_depth_case(seed, i)
+        unphased, support, minlen = bool(batch.unphased), int(batch.support), int(batch.minlen)
         hint = 0 if i % 3 else int(max(depths))
         ctx.set_option("max_reads_hint", hint)
         rc, got = ctx.call_batch(batch, debug=True, check=False)
