@@ -187,3 +187,58 @@ def test_config4_row_count_through_eight_ranks(tmp_path):
     # 0.05 s on a quiet machine; the bound leaves room for eight ranks leaving at once on eight shared cores -
     # this container has shown 0.24 - 1.1 s at times - and still excludes the per-row Python of round 2 (tens of seconds)
     assert stats["rows"] == n_contigs * per and stats["output_s"] < 5.0, stats
+
+
+def _plan_worker(rank, world, port, bam, bed, mode, status_dir):
+    """mode 'digest': rank 1 cuts the targets differently (a different host library, a file that changed under one rank);
+    mode 'open': rank 2 cannot open its BED.  Every rank writes the status and message it left with."""
+    import torch.distributed as dist
+
+    from inquistr_amd import call as hostcall
+    from inquistr_amd import call_dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    my_bed = bed
+    if mode == "digest" and rank == 1:
+        real = hostcall.Run.partition
+
+        def other_cut(self, w):
+            order, cuts = real(self, w)
+            cuts = cuts.copy()
+            cuts[1] += 1  # one target moves from part 1 to part 0
+            return order, cuts
+
+        hostcall.Run.partition = other_cut
+    if mode == "open" and rank == 2:
+        my_bed = bed + ".missing"
+    status, message = 0, ""
+    try:
+        with open(os.devnull, "w") as f:
+            call_dist.genotype_repeats_distributed(bam, None, my_bed, 5, 3, 2, False, "S", out=f, rank=rank, world=world,
+                                                   compute=lambda batch: (batch.locus_start * 0.0, batch.locus_start * 0.0))
+    except hostcall.CallError as e:
+        status, message = e.status, e.message
+    with open(os.path.join(status_dir, f"rank{rank}"), "w") as f:
+        f.write(f"{status}\t{message}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["digest", "open"])
+def test_ranks_that_do_not_share_one_plan_leave_together(tmp_path, mode):
+    """Every rank opens the run and cuts the targets itself (no plan is broadcast); status, message and a digest of the plan are
+    exchanged in front of the rows.  A rank that cut differently, or could not open its input, ends the call on EVERY rank with one
+    status before anybody computes a row or waits in the gather."""
+    bam, bed, loci, recs = _make_case(tmp_path, 43, n_loci=40)
+    status_dir = str(tmp_path / "status")
+    os.makedirs(status_dir)
+    mp.spawn(_plan_worker, args=(3, _free_port(), bam, bed, mode, status_dir), nprocs=3, join=True)
+    got = [open(os.path.join(status_dir, f"rank{r}")).read().split("\t", 1) for r in range(3)]
+    assert len({g[0] for g in got}) == 1 and got[0][0] != "0", got
+    if mode == "digest":
+        assert all(g[0] == "1" and "cut the targets differently" in g[1] for g in got), got
+    else:
+        assert all(g[1] == got[0][1] and g[1] for g in got), got  # the failing rank's message, on every rank
