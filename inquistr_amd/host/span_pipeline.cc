@@ -197,8 +197,8 @@ void SpanPipeline::run() {
                              pool.last_cpus().c_str());
             }
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            std::fprintf(stderr, "[inq loader] @%.1f slot %d: plan %.2f ms, buffer %.2f ms (%s), read+tables %.2f ms for %.1f MB, %zu segments, %zu anchors\n",
-                         stamp_ms(), it->slot, ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), nbytes / 1e6,
+            std::fprintf(stderr, "[inq loader] @%.1f slot %d: plan %.2f ms, buffer %.2f ms (%s), read+tables %.2f ms (copy %.2f, block table + anchors %.2f) for %.1f MB, %zu segments, %zu anchors\n",
+                         stamp_ms(), it->slot, ms(t0, t1), ms(t1, t2), it->pinned ? "pinned" : "pageable", ms(t2, t3), it->data.ms_read, it->data.ms_tables, nbytes / 1e6,
                          it->plan.segs.size(), it->data.anchors.size());
         }
         have = more.get();

@@ -85,6 +85,7 @@ struct SpanData {
     std::vector<uint64_t> anchors, anchor_stop;
     uint64_t comp_bytes = 0;
     uint64_t file_begin = 0;  // file offset of the first segment
+    double ms_read = 0, ms_tables = 0;  // where load() spent its time: the parallel copy, the block table + anchors (INQ_TIMING=2 prints them)
 };
 
 // The threads that copy file bytes into a span buffer (pread from the page cache): made once per file, not once per span, and

@@ -114,3 +114,41 @@ def test_reader_pool_runs_every_job_exactly_once(threads, pin):
         for n_jobs, rounds in ((0, 3), (1, 50), (3, 200), (64, 100), (1000, 20)):
             want = rounds * n_jobs * (n_jobs + 1) // 2
             assert L.inq_host_iopool_selftest(threads, node, pin, n_jobs, rounds) == want, (threads, pin, node, n_jobs, rounds)
+
+
+@pytest.mark.parametrize("seed,block,gap", [(11, 1500, None), (12, 700, 0), (13, bamio.BLOCK, None)])
+def test_block_tables_do_not_depend_on_how_the_copy_is_dealt(tmp_path, monkeypatch, seed, block, gap):
+    """The span loader cuts a span's bytes into jobs at index anchors (every virtual offset of the index names a BGZF block start); the
+    thread that copies a job's bytes also hops through its block headers.  Whatever the job size - one job per piece, a job per anchor,
+    something between - the compressed bytes, the block table (payload offsets, lengths, ISIZE, dense output offsets) and the anchors
+    are the same, and every block inflates (zlib) to its ISIZE."""
+    import zlib
+
+    if gap is not None:
+        monkeypatch.setenv("INQ_SPAN_GAP_BYTES", str(gap))
+    bam, bed, loci, recs = _make_case(tmp_path, seed, n_loci=90, ultra_long=True, block=block)
+
+    def collect(job_bytes):
+        if job_bytes is None:
+            monkeypatch.delenv("INQ_SPAN_JOB_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("INQ_SPAN_JOB_BYTES", str(job_bytes))
+        sp = call.Spans(bam, region_file=bed, threads=4, max_comp_bytes=0)
+        out = []
+        for span in sp.spans():
+            out.append((bytes(span["comp"]), span["blocks"].copy(), span["anchors"].copy(), span["anchor_stop"].copy(), span["locus_index"].copy()))
+        sp.close()
+        return out
+
+    plain = collect(None)
+    assert plain and sum(len(s[1]) for s in plain) > (20 if block < 5000 else 2)
+    for job_bytes in (1, 4000, 50_000):
+        got = collect(job_bytes)
+        assert len(got) == len(plain)
+        for a, b in zip(plain, got):
+            assert a[0] == b[0]
+            assert a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    for comp, blocks, *_ in plain:
+        for blk in blocks[:: max(1, len(blocks) // 40)]:
+            o, n = int(blk["comp_off"]), int(blk["comp_len"])
+            assert len(zlib.decompressobj(-15).decompress(comp[o : o + n])) == int(blk["isize"])
