@@ -40,7 +40,7 @@ namespace inqhost {
 
 // Experiments' switches (INQ_SPAN_REGISTER, INQ_SPAN_BUFFERS, INQ_IO_PIN, INQ_EXIT_PROBE, INQ_GATE_READS, INQ_SPAN_PINNED) are read from
 // the environment only by a build with -DINQ_DEBUG_ENV (make DEBUG_ENV=1).  What the shipped host library reads is listed in
-// INQ_TIMING, INQ_FRONTEND, INQ_SPAN_MB, INQ_SPAN_GAP_BYTES, INQ_FLUSH_LOCI, INQ_NUMA_NODE, INQ_NUMA_CPUS,
+// INQ_TIMING, INQ_FRONTEND, INQ_SPAN_MB, INQ_SPAN_GAP_BYTES, INQ_SPAN_JOB_BYTES, INQ_FLUSH_LOCI, INQ_NUMA_NODE, INQ_NUMA_CPUS,
 // INQ_CTX_TIMEOUT_S, INQ_FAST_EXIT, INQ_SERVER, INQ_SERVER_IDLE, INQ_HOST_LIB, and torch.distributed.run's LOCAL_WORLD_SIZE / LOCAL_RANK.
 #ifdef INQ_DEBUG_ENV
 inline const char *debug_env(const char *name) { return std::getenv(name); }
