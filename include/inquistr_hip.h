@@ -192,6 +192,11 @@ int inq_ctx_timing_reset(inq_ctx_t *ctx);
  * block) so that its commit step does not decode them again (+3 - 4 % on match-heavy blocks, -2 ... -5 % on sequence / quality
  * bytes, and four times the HBM traffic of the inflate: the stores cost what the second decode did), 0 (default since round 4) =
  * it decodes again, -1 = on for spans whose sampled block headers say match-heavy (round 3's default);
+ * "blocking_sync" = 1: every wait of this context gives its core back (hipDeviceScheduleBlockingSync; as a process default - set
+ *   before the context is made - also a blocking upload event) instead of spinning.  Default 0: spinning costs two cores (the caller's
+ *   thread during a span's inflate, the uploader's during its copy) and answers a few microseconds sooner; libinquistr_host.so sets 1
+ *   by itself when a caller's share of the granted cores is below 8 (eight ranks on a 16-core grant), where those two cores are the
+ *   readers'.
  * "inflate_ahead" = 1 (default since round 4): inq_span_stage inflates a span right behind its upload, on a stream of its own, so
  * that the inflate of span k + 1 runs next to span k's record scan, gather and join (costs one inflated buffer per staging slot:
  * device allocations cost microseconds, tools/alloc_probe.hip); 0 = the span is inflated when it is called;
@@ -209,6 +214,9 @@ uint64_t inq_ctx_alloc_retries(const inq_ctx_t *ctx);
  * inside inq_ctx_create / _early / _multi before the context is handed out.  For a host that does not make the contexts itself
  * (libinquistr_host.so does: `inquistr call --ctx-option key=value`).  The library reads NO option from the environment. */
 int inq_default_option(const char *key, int64_t value);
+/* INQ_OK and *value if the process default of `key` has been set (by inq_default_option), INQ_ERR_ARG otherwise: lets a host library
+ * choose a default of its own ("blocking_sync" when its share of the cores is small) without overriding what its user asked for. */
+int inq_default_option_get(const char *key, int64_t *value);
 
 /* Page-locks caller-owned host memory in place (hipHostRegister: 0.5 ms for 268 MB of huge-page-backed memory, against 50 - 60 ms
  * for inq_alloc_pinned of the same size), so that copies from it are plain DMA.  The runtime must be up (a ctx exists). */

@@ -141,6 +141,7 @@ const char *inq_strerror(int code) {
 }
 
 static void apply_default_options(inq_ctx *c);
+static bool default_option(const char *key, int64_t *value);
 
 // The context in two steps for a caller that is in a hurry: *out is set and *stage_ready raised as soon as the staging entry points
 // (inq_span_stage_begin / _wait / inq_span_stage) may be used - the runtime is up, the copy and inflate streams and the staging
@@ -180,6 +181,14 @@ int inq_ctx_create_early(int device_id, inq_ctx_t **out, volatile int *stage_rea
         return code;
     };
     lap("device properties");
+    {   // "blocking_sync" has to be known before the first stream and event are made
+        int64_t v = 0;
+        if (default_option("blocking_sync", &v) && v) {
+            c->blocking_sync = 1;
+            (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);  // (an error here - flags fixed by an earlier user of the device - is not ours to report)
+            (void)hipGetLastError();
+        }
+    }
     if (hipSetDevice(device_id) != hipSuccess) return fail(INQ_ERR_HIP);
     // the streams of the staging path first (the process's first stream costs 18 - 170 ms, every further one 8): uploads and the
     // inflates behind them start while the rest of the context is still being made
@@ -591,6 +600,24 @@ int inq_default_option(const char *key, int64_t value) {
     }
 }
 
+static bool default_option(const char *key, int64_t *value) {
+    std::lock_guard<std::mutex> g(g_defaults_mu);
+    for (auto &kv : g_defaults)
+        if (kv.first == key) {
+            if (value) *value = kv.second;
+            return true;
+        }
+    return false;
+}
+int inq_default_option_get(const char *key, int64_t *value) {
+    if (!key) return INQ_ERR_ARG;
+    try {
+        return default_option(key, value) ? INQ_OK : INQ_ERR_ARG;
+    } catch (...) {
+        return INQ_ERR_NOMEM;
+    }
+}
+
 static void apply_default_options(inq_ctx *c) {
     std::vector<std::pair<std::string, int64_t>> d;
     {
@@ -628,6 +655,17 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     }
     if (std::strcmp(key, "inflate_lit_pairs") == 0) {
         c->inflate_lit_pairs = value < 0 ? -1 : (value != 0);
+        return INQ_OK;
+    }
+    if (std::strcmp(key, "blocking_sync") == 0) {
+        // as a default option (set BEFORE the context is made) it also makes the context's events blocking ones; on a live context it
+        // switches the device's wait mode only
+        c->blocking_sync = value != 0;
+        if (c->device >= 0 && c->stream) {
+            (void)hipSetDevice(c->device);
+            (void)hipSetDeviceFlags(value ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin);
+            (void)hipGetLastError();
+        }
         return INQ_OK;
     }
     if (std::strcmp(key, "inflate_ahead") == 0) {

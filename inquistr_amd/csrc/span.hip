@@ -119,7 +119,8 @@ int inq::span_state_init(inq_ctx *c) {
     // ("inflate_ahead", "gather_nt": options, inq_ctx_set_option / inq_default_option - the environment is not read)
     for (auto &g : S->stage) {
         HIP_TRY(c, hipMalloc((void **)&g.d_err, sizeof(unsigned int)));
-        HIP_TRY(c, hipEventCreate(&g.ev_up));
+        // (ev_up is waited for by the uploader thread: a blocking event gives its core back to the readers while a span crosses the link)
+        HIP_TRY(c, hipEventCreateWithFlags(&g.ev_up, c->blocking_sync ? hipEventBlockingSync : hipEventDefault));
         HIP_TRY(c, hipEventCreate(&g.ev_inf0));
         HIP_TRY(c, hipEventCreate(&g.ev_inf1));
     }

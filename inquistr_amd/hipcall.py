@@ -54,6 +54,7 @@ ABI_SYMBOLS = (
     "inq_ctx_create_early",
     "inq_ctx_create_multi",
     "inq_default_option",
+    "inq_default_option_get",
     "inq_ctx_alloc_retries",
     "inq_span_stage_begin",
     "inq_span_stage_wait",
@@ -192,6 +193,8 @@ def load(path: Optional[str] = None):
     L.inq_ctx_alloc_retries.argtypes = [vp]
     L.inq_default_option.restype = C.c_int
     L.inq_default_option.argtypes = [C.c_char_p, C.c_int64]
+    L.inq_default_option_get.restype = C.c_int
+    L.inq_default_option_get.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
     L.inq_ctx_create_multi.restype = C.c_int
     L.inq_ctx_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.inq_ctx_destroy.restype = None

@@ -98,6 +98,12 @@ int prepare(const inq_call_args_t *a, Prepared &P, std::string &msg, BedCache *b
 // after the time-out, the context counts as failed (INQ_ERR_HIP, "did not come up"), the thread is left behind (detached: it may
 // be stuck inside a signal handler or the driver) and the call ends with INQ_EXIT_ERROR.
 double ctx_timeout_s();
+// A caller short of cores (its share of the granted cores below 8: eight ranks on a 16-core grant have 2 each) cannot afford the two
+// cores that SPIN while a span inflates (the caller's thread in hipStreamSynchronize) and crosses the link (the uploader's in
+// hipEventSynchronize): they are the readers' (measured with the process confined to 4 CPUs: tools/few_cores.sh).  The context is then
+// made with blocking waits ("blocking_sync"), unless the user has set the option either way (--ctx-option, inq_default_option).
+// sharers: 0 = local_share().
+void choose_wait_mode(int sharers);
 typedef int (*CtxCreateFn)(int device, inq_ctx_t **ctx, volatile int *stage_ready);
 CtxCreateFn ctx_create_fn();  // inq_ctx_create_early, or what inq_host_test_ctx_creator put in its place (tests)
 struct AsyncCtx {
@@ -124,9 +130,10 @@ struct AsyncCtx {
     std::chrono::steady_clock::time_point t_start;
     AsyncCtx() = default;
     AsyncCtx(const AsyncCtx &) = delete;
-    void start(int device) {
+    void start(int device, int sharers = 0) {
         t_start = std::chrono::steady_clock::now();
         started = true;
+        choose_wait_mode(sharers);
         std::shared_ptr<State> s = st;  // the thread keeps the block alive, whatever becomes of this object
         CtxCreateFn create = ctx_create_fn();
         th = std::thread([s, device, create] {

@@ -92,7 +92,7 @@ static int genotype_devices_impl(const inq_call_args_t *args, const int32_t *dev
     std::vector<std::unique_ptr<AsyncCtx>> actx(n_devices);
     for (size_t r = 0; r < n_devices; ++r) {
         actx[r].reset(new AsyncCtx());
-        actx[r]->start(device_ids[r]);
+        actx[r]->start(device_ids[r], (int)n_devices);
     }
     Prepared P;
     std::string msg;

@@ -395,6 +395,14 @@ void local_share(int *sharers, int *index) {
     *index = k;
 }
 
+void choose_wait_mode(int sharers) {
+    int64_t v = 0;
+    if (inq_default_option_get("blocking_sync", &v) == INQ_OK) return;  // the user's word
+    int idx = 0;
+    if (sharers <= 0) local_share(&sharers, &idx);
+    if (granted_cpus() / std::max(1, sharers) < 8) (void)inq_default_option("blocking_sync", 1);
+}
+
 int span_io_threads(const inq_call_args_t *args, int sharers) {
     // -t counts the reference's calling workers; here the host only copies file bytes, which a few pread streams do best whatever -t
     // says - bounded by this caller's SHARE of the cores the process was granted: eight ranks on one host must not start 8 x 32

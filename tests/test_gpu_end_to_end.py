@@ -609,6 +609,25 @@ def test_rows_left_in_device_memory_equal_the_host_rows(tmp_path, frontend, unph
 
 
 @pytest.mark.parametrize("frontend", ["device", "host"])
+def test_blocking_waits_print_the_same_rows(tmp_path, frontend):
+    """"blocking_sync" (every wait of the context gives its core back: what the host library picks by itself for a caller whose share
+    of the granted cores is below 8, here forced either way through the CLI's --ctx-option, and picked by the library for a process
+    confined to two CPUs): the same text as with spinning waits, on both front ends."""
+    bam, bed, loci, recs = _make_case(tmp_path, 61, n_loci=70, ultra_long=True)
+    want = _expected_text(loci, recs, False, 5, 3, "S", 4)
+    env = dict(os.environ, INQ_FRONTEND=frontend)
+    for extra in (["--ctx-option", "blocking_sync=1"], ["--ctx-option", "blocking_sync=0"]):
+        r = subprocess.run([call.CLI_PATH, "call", bam, "-R", bed, "--sample-name", "S", "-t", "4"] + extra, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == want, extra
+    cpus = sorted(os.sched_getaffinity(0))[:2]
+    r = subprocess.run(["taskset", "-c", ",".join(map(str, cpus)), call.CLI_PATH, "call", bam, "-R", bed, "--sample-name", "S", "-t", "4"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want
+
+
+@pytest.mark.parametrize("frontend", ["device", "host"])
 def test_runs_on_one_session_equal_runs_of_their_own(tmp_path, frontend):
     """inq_session_run_open: runs opened on ONE session (its device context, span buffers and BED cache - what a resident rank of
     call_dist keeps for the life of the process) give the rows of runs that make their own context, file after file, host rows and

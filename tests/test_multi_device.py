@@ -91,6 +91,44 @@ def test_reader_pool_takes_this_callers_share_of_the_granted_cores():
         del os.environ["LOCAL_WORLD_SIZE"], os.environ["LOCAL_RANK"]
 
 
+def test_a_caller_short_of_cores_gets_blocking_waits_unless_its_user_said_otherwise():
+    """The two cores that spin while a span inflates and crosses the link are the readers' when a caller's share of the granted cores
+    is small (tools/few_cores.sh: + 7 ... 15 % span loop with the process confined to 2 - 4 CPUs): the host library then makes its
+    contexts with "blocking_sync" - a process default set when the context thread is started - and leaves the option alone when the
+    user has set it either way, or when the share is 8 cores or more.  Fresh processes: the default is the process's."""
+    import subprocess
+    import sys
+
+    prog = """
+import ctypes as C, sys
+from inquistr_amd import call, hipcall
+L, H = call.load(), hipcall.load()
+sharers, user = int(sys.argv[1]), sys.argv[2]
+if user != "-":
+    assert H.inq_default_option(b"blocking_sync", int(user)) == 0
+L.inq_host_set_local_share(sharers, 0)
+v = C.c_int64(-1)
+assert (H.inq_default_option_get(b"blocking_sync", C.byref(v)) == 0) == (user != "-")
+S = call.Session(0)  # starts the context thread (there is no GPU here: the context fails later, the choice is made before)
+rc = H.inq_default_option_get(b"blocking_sync", C.byref(v))
+print(rc, v.value, L.inq_host_granted_cpus())
+S.close()
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(sharers, user="-"):
+        r = subprocess.run([sys.executable, "-c", prog, str(sharers), user], capture_output=True, text=True, cwd=root, timeout=120)
+        assert r.returncode == 0, r.stderr[-1500:]
+        rc, v, granted = r.stdout.split()[-3:]
+        return int(rc), int(v), int(granted)
+
+    rc, v, granted = run(64)  # a 64th of the grant: far below 8 cores
+    assert granted // 64 < 8 and (rc, v) == (0, 1)
+    assert run(64, "0")[:2] == (0, 0) and run(64, "1")[:2] == (0, 1)  # the user's word stays
+    if granted >= 8:
+        assert run(1)[0] != 0  # a caller with the whole grant: nothing is set, waits spin (the lower latency)
+
+
 # ---- a device context that never comes up: every waiter is bounded, the call ends with exit status 1 ----
 MODES = {1: "returns 'no device' at once", 2: "hangs in its first call, nothing published",
          3: "publishes a staging context, then hangs", 4: "publishes a staging context, then fails"}
