@@ -143,7 +143,25 @@ bool SpanPipeline::fit(Item &it, size_t bytes) {
     return p != nullptr;
 }
 
+CpuByKind &cpu_by_kind() {
+    static CpuByKind &k = *new CpuByKind();
+    return k;
+}
+uint64_t thread_cpu_us() {
+    struct timespec t;
+    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t) != 0) return 0;
+    return (uint64_t)t.tv_sec * 1000000ull + (uint64_t)t.tv_nsec / 1000ull;
+}
+namespace {
+struct CpuLap {  // adds the calling thread's CPU time between construction and destruction to a counter
+    std::atomic<uint64_t> &to;
+    uint64_t t0 = thread_cpu_us();
+    ~CpuLap() { to.fetch_add(thread_cpu_us() - t0, std::memory_order_relaxed); }
+};
+}  // namespace
+
 void SpanPipeline::run() {
+    CpuLap cpu_lap{cpu_by_kind().loader_us};
     prefer_gpu_node_for_this_thread(device_);
     SpanLoader loader;
     std::string e;
@@ -224,6 +242,7 @@ void SpanPipeline::run() {
 // uploads in file order behind the reader; up to two spans enqueued at a time (when the staging has a wait step), so that the copy
 // engine goes from one span's bytes straight to the next one's
 void SpanPipeline::run_uploads() {
+    CpuLap cpu_lap{cpu_by_kind().uploader_us};
     prefer_gpu_node_for_this_thread(device_);  // the runtime's staging chunks are allocated by the thread that first copies
     struct Flight {
         Item *it;
@@ -602,6 +621,15 @@ int run_device_front(const inq_call_args_t *args, const CallView &V, AsyncCtx &a
             leak_all = true;
         }
         if (timing) std::fprintf(stderr, "[inq timing] spans done at %.3fs after the start of the device path\n", secs(t_begin, clk::now()));
+        if (timing) {
+            struct timespec pt;
+            const double proc = clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &pt) == 0 ? (double)pt.tv_sec + (double)pt.tv_nsec * 1e-9 : 0.0;
+            const CpuByKind &k = cpu_by_kind();
+            std::fprintf(stderr,
+                         "[inq timing] cpu seconds so far: process %.3f | this thread (device calls) %.3f | reader pool %.3f (the loader's own share of the copies is "
+                         "under 'loader' until it ends) | loader %.3f, uploader %.3f (counted when they end) | the rest: the runtime's threads, the context thread\n",
+                         proc, thread_cpu_us() * 1e-6, k.readers_us.load() * 1e-6, k.loader_us.load() * 1e-6, k.uploader_us.load() * 1e-6);
+        }
     }
     if (timing) std::fprintf(stderr, "[inq timing] loader joined at %.3fs\n", secs(t_begin, clk::now()));
     if (hrc != INQ_OK) {  // no GPU is an error even for an empty target list

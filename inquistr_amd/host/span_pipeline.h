@@ -1,5 +1,6 @@
 // span_pipeline.h - host half of the device front end: span buffers, the loader and uploader threads (span_pipeline.cc)
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -187,5 +188,6 @@ private:
 };
 
 uint64_t span_bytes_from_env();
+
 
 }  // namespace inqhost

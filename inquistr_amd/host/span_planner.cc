@@ -112,6 +112,10 @@ std::string IoPool::last_cpus() const {
 }
 
 void IoPool::work(int id) {
+    struct Lap {
+        uint64_t t0 = thread_cpu_us();
+        ~Lap() { cpu_by_kind().readers_us.fetch_add(thread_cpu_us() - t0, std::memory_order_relaxed); }
+    } lap;
     uint64_t seen = 0;
     for (;;) {
         const std::function<void(size_t)> *fn;

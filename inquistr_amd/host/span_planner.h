@@ -88,6 +88,14 @@ struct SpanData {
     double ms_read = 0, ms_tables = 0;  // where load() spent its time: the parallel copy, the block table + anchors (INQ_TIMING=2 prints them)
 };
 
+// CPU seconds of a pipeline's threads by kind (INQ_TIMING prints them with the process's total: what is left is the runtime's own
+// threads) - who uses the cores of a caller that has few
+struct CpuByKind {
+    std::atomic<uint64_t> readers_us{0}, loader_us{0}, uploader_us{0};
+};
+CpuByKind &cpu_by_kind();
+uint64_t thread_cpu_us();  // CPU time of the calling thread so far
+
 // The threads that copy file bytes into a span buffer (pread from the page cache): made once per file, not once per span, and
 // spread over the L3 domains (CCDs) of the NUMA node the GPU hangs on.  Why spread: a copy is bound by memory bandwidth, and on
 // the two-socket EPYC hosts measured a CCD's link to memory carries a fraction of the socket's; left to the scheduler, sixteen
