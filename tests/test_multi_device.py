@@ -91,6 +91,7 @@ def test_reader_pool_takes_this_callers_share_of_the_granted_cores():
         del os.environ["LOCAL_WORLD_SIZE"], os.environ["LOCAL_RANK"]
 
 
+@pytest.mark.skipif("tsan" in os.environ.get("LD_PRELOAD", ""), reason="starts child processes: a fork of the instrumented, threaded test process hangs in ThreadSanitizer")
 def test_a_caller_short_of_cores_gets_blocking_waits_unless_its_user_said_otherwise():
     """The two cores that spin while a span inflates and crosses the link are the readers' when a caller's share of the granted cores
     is small (tools/few_cores.sh: + 7 ... 15 % span loop with the process confined to 2 - 4 CPUs): the host library then makes its
