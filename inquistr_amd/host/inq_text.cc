@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 namespace inqhost {
 
@@ -18,7 +19,7 @@ static void append_u64(std::string &out, uint64_t v) {
 }
 
 // Rust's `{}` for f64 restricted to what the path produces: NaN, integers and halves ((a + b) as f64 / 2.0,
-// src/call.rs:518) of at most 2^53 in magnitude print without exponent; anything else falls back to printf
+// src/call.rs:518) of at most 2^53 in magnitude take the fast path; anything else goes the general way below
 void append_f64(std::string &out, double v) {
     if (std::isnan(v)) {
         out += "NaN";
@@ -34,12 +35,43 @@ void append_f64(std::string &out, double v) {
             return;
         }
     }
-    char buf[64];
-    double ip;
-    const double frac = std::modf(v, &ip);
-    if (frac == 0.0) std::snprintf(buf, sizeof buf, "%.0f", v);
-    else std::snprintf(buf, sizeof buf, "%s%.0f.5", v < 0 ? "-" : "", std::fabs(ip));
-    out += buf;
+    // anything else - never produced by the path - as Rust's Display prints it [3P core::fmt::float]: the SHORTEST decimal digits that
+    // read back as v, written out positionally (no exponent; 2^60 is "1152921504606847000", not its exact digits), "inf", "-0"
+    if (std::isinf(v)) {
+        out += v < 0 ? "-inf" : "inf";
+        return;
+    }
+    char e[40];
+    int prec = 0;
+    for (; prec <= 16; ++prec) {
+        std::snprintf(e, sizeof e, "%.*e", prec, a);
+        if (std::strtod(e, nullptr) == a) break;
+    }
+    if (prec > 16) std::snprintf(e, sizeof e, "%.16e", a);
+    std::string digits;
+    int exp10 = 0;
+    for (const char *q = e; *q; ++q) {
+        if (*q >= '0' && *q <= '9') digits.push_back(*q);
+        else if (*q == 'e') {
+            exp10 = std::atoi(q + 1);
+            break;
+        }
+    }
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    if (std::signbit(v)) out.push_back('-');
+    const int nd = (int)digits.size();
+    if (exp10 >= nd - 1) {
+        out += digits;
+        out.append((size_t)(exp10 - (nd - 1)), '0');
+    } else if (exp10 >= 0) {
+        out.append(digits, 0, (size_t)exp10 + 1);
+        out.push_back('.');
+        out.append(digits, (size_t)exp10 + 1, std::string::npos);
+    } else {
+        out += "0.";
+        out.append((size_t)(-exp10 - 1), '0');
+        out += digits;
+    }
 }
 
 std::string format_f64(double v) {

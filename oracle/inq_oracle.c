@@ -541,25 +541,52 @@ int orc_call_batch(const inq_batch_t *b, inq_result_t *res, int n_threads) {
 /* [3P] Rust f64 Display: shortest round-trip digits, never exponent form, "NaN" for NaN.
  * The path only produces integers and halves (src/call.rs:515-520). */
 size_t orc_format_f64(double v, char *buf, size_t cap) {
+    /* [3P] Rust's Display for f64 (core::fmt::float, flt2dec shortest): the shortest decimal digits that read back as v, written
+     * positionally - never an exponent: 2^60 prints as 1152921504606847000 -, "NaN", "inf", "-0".  What the path produces
+     * (integers and halves below 2^53, src/call.rs:518) are their own shortest digits. */
     if (isnan(v)) return (size_t)snprintf(buf, cap, "NaN");
     if (isinf(v)) return (size_t)snprintf(buf, cap, v < 0 ? "-inf" : "inf");
-    double ip;
-    double frac = modf(v, &ip);
-    if (frac == 0.0) {
-        if (v == 0.0 && signbit(v)) return (size_t)snprintf(buf, cap, "-0");
-        return (size_t)snprintf(buf, cap, "%.0f", v);
+    double a = fabs(v);
+    char e[40];
+    int prec = 0;
+    for (; prec <= 16; prec++) {
+        snprintf(e, sizeof e, "%.*e", prec, a);
+        if (strtod(e, NULL) == a) break;
     }
-    if (fabs(frac) == 0.5) {
-        const char *sign = v < 0 ? "-" : "";
-        return (size_t)snprintf(buf, cap, "%s%.0f.5", sign, fabs(ip));
+    if (prec > 16) snprintf(e, sizeof e, "%.16e", a);
+    char digits[24];
+    int nd = 0, exp10 = 0;
+    for (const char *q = e; *q; q++) {
+        if (*q >= '0' && *q <= '9') digits[nd++] = *q;
+        else if (*q == 'e') {
+            exp10 = atoi(q + 1);
+            break;
+        }
     }
-    /* not reachable from this path; shortest round-trip search as Rust would print */
-    for (int prec = 1; prec <= 17; prec++) {
-        char tmp[64];
-        snprintf(tmp, sizeof tmp, "%.*f", prec, v);
-        if (strtod(tmp, NULL) == v) return (size_t)snprintf(buf, cap, "%s", tmp);
+    while (nd > 1 && digits[nd - 1] == '0') nd--;
+    size_t n = 0;
+#define PUT(c)                      \
+    do {                            \
+        if (n + 1 < cap) buf[n] = (c); \
+        n++;                        \
+    } while (0)
+    if (signbit(v)) PUT('-');
+    if (exp10 >= nd - 1) {
+        for (int i = 0; i < nd; i++) PUT(digits[i]);
+        for (int i = 0; i < exp10 - (nd - 1); i++) PUT('0');
+    } else if (exp10 >= 0) {
+        for (int i = 0; i <= exp10; i++) PUT(digits[i]);
+        PUT('.');
+        for (int i = exp10 + 1; i < nd; i++) PUT(digits[i]);
+    } else {
+        PUT('0');
+        PUT('.');
+        for (int i = 0; i < -exp10 - 1; i++) PUT('0');
+        for (int i = 0; i < nd; i++) PUT(digits[i]);
     }
-    return (size_t)snprintf(buf, cap, "%.17f", v);
+#undef PUT
+    if (cap) buf[n < cap ? n : cap - 1] = 0;
+    return n;
 }
 
 /* src/call.rs:57-65 */

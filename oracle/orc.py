@@ -204,8 +204,8 @@ def call_batch_raw(bc: InqBatchC, rc: InqResultC, threads: int = 1) -> int:
 
 
 def format_f64(v: float) -> str:
-    buf = C.create_string_buffer(128)
-    lib().orc_format_f64(v, buf, 128)
+    buf = C.create_string_buffer(512)  # (f64::MAX takes 309 digits, the smallest subnormal 326 characters)
+    lib().orc_format_f64(v, buf, 512)
     return buf.value.decode()
 
 

@@ -210,14 +210,20 @@ def genotype_repeat_unphased(recs, tid, start, end, minlen, support):
 
 
 def format_f64(v: float) -> str:
-    """[3P] Rust `{}` for f64, restricted to what the path produces."""
+    """[3P] Rust `{}` for f64: the shortest digits that read back as v (Python's repr finds the same), written positionally - never
+    an exponent: 2.0 ** 60 is "1152921504606847000" -, "NaN", "inf", "-0"."""
+    from decimal import Decimal
+
     v = float(v)
     if math.isnan(v):
         return "NaN"
-    if v == int(v):
-        return str(int(v))
+    if math.isinf(v):
+        return "-inf" if v < 0 else "inf"
     r = repr(v)
-    assert "e" not in r
+    if "e" in r or "E" in r:
+        r = format(Decimal(r), "f")
+    if r.endswith(".0"):
+        r = r[:-2]
     return r
 
 
