@@ -51,6 +51,15 @@ def _process_session(device: int):
     return sess
 
 
+def _drop_process_session(device: int) -> None:
+    sess = _sessions.pop(device, None)
+    if sess is not None:
+        try:
+            sess.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def _exchange_status(status: int, message: str, rank: int, world: int, group=None):
     """Every rank learns whether any rank failed (and rank 0 the failing rank's message) BEFORE the row gather, so that a
     data-dependent failure on one rank (a record the reference panics on, a HIP error, out of memory) ends the run on all
@@ -182,9 +191,14 @@ def genotype_repeats_distributed(bamp: str, region: Optional[str], region_file: 
             stats["span_loop_GBps"] = last["bam_bytes_read"] / 1e9 / last["span_loop_s"] if last["span_loop_s"] > 0 else None
         except Exception:  # noqa: BLE001
             stats["bam_bytes_read"] = None
+    own_failure = st
     st, msg, bad_rank = _exchange_status(st, msg, rank, world, group)
     if st != 0:
         run.close()
+        if own_failure == 1 and compute is None and session is None:
+            # an error exit of THIS rank's device work (HIP, memory, no device - not one of the reference's panics, which a session
+            # survives): the process's session is given up, the next call makes a new context
+            _drop_process_session(device)
         raise hostcall.CallError(st, f"rank {bad_rank}: {msg}" if world > 1 else msg)
     # ---- the one exchange of the path: 2 x f64 per locus to rank 0 (at world size 1 inside an initialised nccl group the same
     # collective runs over the device buffer: the path a one-GPU box can exercise)

@@ -185,3 +185,13 @@ def test_session_and_run_fail_loudly_without_gpu(tmp_path):
         assert e.value.status == 1
         # (left open: the session closes the runs still open on it before it goes)
     assert not (srun._h and srun._h.value)
+    # call_dist (one process per GPU) takes the process's session by itself; a rank whose device work ends with an error exit gives the
+    # session up, so that the next call makes a new context instead of meeting the dead one
+    from inquistr_amd import call_dist
+
+    for _ in range(2):
+        with pytest.raises(call.CallError) as e, open(tmp_path / "dist.inq", "w") as f:
+            call_dist.genotype_repeats_distributed(bam, None, bed, 5, 3, 2, False, "S", out=f)
+        assert e.value.status == 1 and "no CPU fallback" in e.value.message
+        assert call_dist._sessions == {}
+    assert (tmp_path / "dist.inq").read_text() == ""
