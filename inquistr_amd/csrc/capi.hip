@@ -489,7 +489,8 @@ static int outlier_rows_impl(inq_ctx_t *c, const float *values, const uint32_t *
     if ((rc = ensure(c, c->olen, n_rows * 4)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->oflags, cells)) != INQ_OK) return rc;
     if ((rc = ensure(c, c->okeep, n_rows)) != INQ_OK) return rc;
-    if (method == INQ_OUTLIER_ZSCORE && (rc = ensure(c, c->otrans, outlier_rows_padded(n_rows) * stride * 4)) != INQ_OK) return rc;
+    const bool tile = c->outlier_tile && stride <= kOutlierTileMaxStride;
+    if (method == INQ_OUTLIER_ZSCORE && !tile && (rc = ensure(c, c->otrans, outlier_rows_padded(n_rows) * stride * 4)) != INQ_OK) return rc;
     if (cells) HIP_TRY(c, hipMemcpyAsync(c->ovalues.p, values, cells * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->olen.p, row_len, n_rows * 4, hipMemcpyHostToDevice, s));
     if (cells) HIP_TRY(c, hipMemsetAsync(c->oflags.p, 0, cells, s));
@@ -515,7 +516,7 @@ static int outlier_rows_impl(inq_ctx_t *c, const float *values, const uint32_t *
         ev = &c->ev_pool[c->ev_used++];
         HIP_TRY(c, hipEventRecord(ev->e0, s));
     }
-    launch_outlier(a, method, (float *)c->otrans.p, s);
+    launch_outlier(a, method, (float *)c->otrans.p, s, tile);
     HIP_TRY(c, hipGetLastError());
     if (ev) {
         HIP_TRY(c, hipEventRecord(ev->e1, s));
@@ -655,6 +656,10 @@ int inq_ctx_set_option(inq_ctx_t *c, const char *key, int64_t value) {
     }
     if (std::strcmp(key, "inflate_lit_pairs") == 0) {
         c->inflate_lit_pairs = value < 0 ? -1 : (value != 0);
+        return INQ_OK;
+    }
+    if (std::strcmp(key, "outlier_tile") == 0) {
+        c->outlier_tile = value != 0;
         return INQ_OK;
     }
     if (std::strcmp(key, "blocking_sync") == 0) {

@@ -56,6 +56,7 @@ struct inq_ctx {
     // for "+0.3 s for a one-file process"; round 4 found that figure to be the driver's teardown of the PREVIOUS process in the
     // timing loop, not the allocations (hipMalloc: 10 - 200 us whatever the size): on
     int inflate_ahead = 1;
+    int outlier_tile = 1;   // z-score of rows of <= 256 values through an LDS tile (0: the transposed-copy kernel for every width)
     int blocking_sync = 0;  // waits give the core back (hipDeviceScheduleBlockingSync, blocking events): for a caller short of cores
     // the gather's stores bypass the caches (bam_scan.hip): the batch it builds is read by a later launch, not by this one; the locus
     // kernels behind it run at 5.4 - 6.2 instead of 4.9 - 5.3 TB/s of algorithmic bytes (profiles/r04_results/locus_kernels_in_the_cli.txt)

@@ -119,8 +119,10 @@ struct OutlierArgs {
     uint8_t *flags;  // [n_rows][stride]: 1 = outlier
     uint8_t *keep;   // [n_rows]: INQ_OUTLIER_ROW_*
 };
-// z-score works on a transposed copy ([stride][rows_padded] floats, caller's scratch); flags must be zero-filled
+// z-score: rows of at most kOutlierTileMaxStride values go through an LDS tile (one read of the matrix; use_tile), wider ones work on
+// a transposed copy ([stride][rows_padded] floats, caller's scratch); flags must be zero-filled
+constexpr uint32_t kOutlierTileMaxStride = 256;
 inline uint64_t outlier_rows_padded(uint64_t n_rows) { return (n_rows + 63) / 64 * 64; }
-void launch_outlier(const OutlierArgs &a, int method, float *transposed, hipStream_t s);
+void launch_outlier(const OutlierArgs &a, int method, float *transposed, hipStream_t s, bool use_tile = true);
 
 }  // namespace inq

@@ -69,6 +69,122 @@ __global__ __launch_bounds__(256) void outlier_zscore_kernel(OutlierArgs a, cons
         if (__fdiv_rn(__fsub_rn(clean(p[(uint64_t)k * rows_padded]), mean), sd) >= a.zscore_cutoff) f[k] = 1;  // :106
 }
 
+// The same arithmetic for rows of at most kOutlierTileMaxStride (256) values, ONE read of the matrix instead of five (transpose: read + write,
+// three passes over the transposed copy): a wave copies R whole rows - R * stride contiguous floats of the row-major matrix,
+// coalesced - into an LDS tile whose row pitch is odd (lane r walks row r: no bank conflicts), then lane r runs the three passes
+// over ITS row out of LDS, every f32 operation in the reference's order as above.  R = 64 rows up to 128 values, 32 up to 256
+// (33 KB of LDS per wave either way: four waves per CU, each with up to 32 KB of loads in flight).
+template <int R, bool VEC4>
+__global__ __launch_bounds__(64) void outlier_zscore_tile_kernel(OutlierArgs a) {
+    extern __shared__ float tile[];
+    const uint32_t stride = a.stride, pitch = stride | 1u, lane = threadIdx.x;
+    const uint64_t row0 = (uint64_t)blockIdx.x * (uint32_t)R;
+    const uint32_t rows_here = (uint32_t)(a.n_rows - row0 < (uint64_t)R ? a.n_rows - row0 : (uint64_t)R);
+    const float *src = a.values + row0 * (uint64_t)stride;
+    const uint32_t total = rows_here * stride;  // <= 8 192 floats: 64 rows of <= 128 values, or 32 of <= 256
+    if (VEC4) {
+        // stride % 4 == 0: rows begin on 16-byte boundaries and no float4 straddles two rows.  ALL of a lane's loads (<= 32 x 16 B, the
+        // whole tile = 32 KB per wave) are issued before the first one is waited for: four waves per CU keep 128 KB in flight
+        constexpr int kPerLane = 32;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 v[kPerLane];
+        const f4 *src4 = reinterpret_cast<const f4 *>(src);
+        const uint32_t total4 = total >> 2;
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const uint32_t e4 = (uint32_t)i * 64u + lane;
+            if (e4 < total4) v[i] = __builtin_nontemporal_load(src4 + e4);
+        }
+        const uint32_t stride4 = stride >> 2;
+        uint32_t row = lane / stride4, col4 = lane % stride4;
+        const uint32_t step_rows = 64u / stride4, step_cols = 64u % stride4;
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const uint32_t e4 = (uint32_t)i * 64u + lane;
+            if (e4 < total4) {
+                float *dst = tile + row * pitch + col4 * 4u;
+                dst[0] = v[i].x, dst[1] = v[i].y, dst[2] = v[i].z, dst[3] = v[i].w;
+            }
+            col4 += step_cols;
+            row += step_rows;
+            if (col4 >= stride4) col4 -= stride4, ++row;
+        }
+    } else {
+        uint32_t row = lane / stride, col = lane % stride;
+        const uint32_t step_rows = 64u / stride, step_cols = 64u % stride;
+#pragma unroll 16
+        for (uint32_t e = lane; e < total; e += 64u) {
+            tile[row * pitch + col] = src[e];
+            col += step_cols;
+            row += step_rows;
+            if (col >= stride) col -= stride, ++row;
+        }
+    }
+    __syncthreads();
+    if (lane >= rows_here) return;
+    const uint64_t grow = row0 + lane;
+    const uint32_t n = a.row_len[grow];
+    const float *p = tile + lane * pitch;
+    uint8_t *f = a.flags + grow * (uint64_t)stride;  // zero-filled by the caller: only the (rare) hits are written
+    if (n == 0) {
+        a.keep[grow] = INQ_OUTLIER_ROW_EMPTY;
+        return;
+    }
+    // Every pass is a chain of dependent f32 operations (the reference's order), but the LDS reads that feed it are not: eight values
+    // are fetched at a time, then consumed in order - an LDS round trip per eight elements instead of one per element.
+    constexpr uint32_t kU = 8;
+    float sum = 0.0f, mx = clean(p[0]);
+    uint32_t k = 0;
+    for (; k + kU <= n; k += kU) {
+        float v[kU];
+#pragma unroll
+        for (uint32_t j = 0; j < kU; ++j) v[j] = clean(p[k + j]);
+#pragma unroll
+        for (uint32_t j = 0; j < kU; ++j) {
+            sum = __fadd_rn(sum, v[j]);
+            mx = v[j] > mx ? v[j] : mx;
+        }
+    }
+    for (; k < n; ++k) {
+        const float v = clean(p[k]);
+        sum = __fadd_rn(sum, v);
+        mx = v > mx ? v : mx;
+    }
+    if (mx < (float)a.minsize) {
+        a.keep[grow] = INQ_OUTLIER_ROW_SKIP;
+        return;
+    }
+    a.keep[grow] = INQ_OUTLIER_ROW_KEEP;
+    const float count = (float)n;
+    const float mean = __fdiv_rn(sum, count);
+    float var = 0.0f;
+    for (k = 0; k + kU <= n; k += kU) {
+        float d[kU];
+#pragma unroll
+        for (uint32_t j = 0; j < kU; ++j) {
+            d[j] = __fsub_rn(mean, clean(p[k + j]));
+            d[j] = __fmul_rn(d[j], d[j]);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kU; ++j) var = __fadd_rn(var, d[j]);
+    }
+    for (; k < n; ++k) {
+        const float d = __fsub_rn(mean, clean(p[k]));
+        var = __fadd_rn(var, __fmul_rn(d, d));
+    }
+    const float sd = __fsqrt_rn(__fdiv_rn(var, count));
+    for (k = 0; k + kU <= n; k += kU) {  // (independent per element: the divisions overlap)
+        bool hit[kU];
+#pragma unroll
+        for (uint32_t j = 0; j < kU; ++j) hit[j] = __fdiv_rn(__fsub_rn(clean(p[k + j]), mean), sd) >= a.zscore_cutoff;
+#pragma unroll
+        for (uint32_t j = 0; j < kU; ++j)
+            if (hit[j]) f[k + j] = 1;
+    }
+    for (; k < n; ++k)
+        if (__fdiv_rn(__fsub_rn(clean(p[k]), mean), sd) >= a.zscore_cutoff) f[k] = 1;
+}
+
 constexpr uint32_t kDbscanMaxCols = 8192;
 
 // 1-D DBSCAN of one row per workgroup, O(n log n): the row is sorted in LDS (bitonic, value + original index),
@@ -232,9 +348,19 @@ __global__ __launch_bounds__(THREADS) void outlier_dbscan_kernel(OutlierArgs a) 
 
 }  // namespace
 
-void launch_outlier(const OutlierArgs &a, int method, float *transposed, hipStream_t s) {
+void launch_outlier(const OutlierArgs &a, int method, float *transposed, hipStream_t s, bool use_tile) {
     if (!a.n_rows) return;
-    if (method == INQ_OUTLIER_ZSCORE) {
+    if (method == INQ_OUTLIER_ZSCORE && a.stride && a.stride <= kOutlierTileMaxStride && use_tile) {
+        const uint32_t pitch = a.stride | 1u;
+        const bool vec4 = a.stride % 4u == 0u && (reinterpret_cast<uintptr_t>(a.values) & 15u) == 0u;
+        if (a.stride <= 128u) {
+            if (vec4) hipLaunchKernelGGL((outlier_zscore_tile_kernel<64, true>), dim3((uint32_t)((a.n_rows + 63) / 64)), dim3(64), 64u * pitch * 4u, s, a);
+            else hipLaunchKernelGGL((outlier_zscore_tile_kernel<64, false>), dim3((uint32_t)((a.n_rows + 63) / 64)), dim3(64), 64u * pitch * 4u, s, a);
+        } else {
+            if (vec4) hipLaunchKernelGGL((outlier_zscore_tile_kernel<32, true>), dim3((uint32_t)((a.n_rows + 31) / 32)), dim3(64), 32u * pitch * 4u, s, a);
+            else hipLaunchKernelGGL((outlier_zscore_tile_kernel<32, false>), dim3((uint32_t)((a.n_rows + 31) / 32)), dim3(64), 32u * pitch * 4u, s, a);
+        }
+    } else if (method == INQ_OUTLIER_ZSCORE) {
         const uint64_t rows_padded = outlier_rows_padded(a.n_rows);
         if (a.stride)
             hipLaunchKernelGGL(outlier_transpose_kernel, dim3((uint32_t)((a.n_rows + 63) / 64), (a.stride + 63) / 64), dim3(256), 0, s,

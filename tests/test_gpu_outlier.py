@@ -86,6 +86,29 @@ def test_outlier_rows_match_the_restatement(ctx, method, seed, n_cols):
         assert not flags[i, lens[i]:].any()
 
 
+@pytest.mark.parametrize("n_cols", [1, 3, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257])
+def test_zscore_through_the_lds_tile_equals_the_transposed_copy(ctx, n_cols):
+    """Rows of at most 256 values take the LDS-tile kernel (one read of the row-major matrix, 64 or 32 rows per wave), wider ones and
+    "outlier_tile" = 0 the transposed-copy kernel: the same flags and row states from both, on ragged rows (lengths 0 ... n_cols), a row
+    count that is no multiple of a tile, NaNs, and equal to the plain-Python restatement."""
+    rng = random.Random(1000 + n_cols)
+    vals, lens = _random_matrix(rng, 777, n_cols)
+    vals[rng.randrange(777), rng.randrange(n_cols)] = np.nan
+    cutoff = rng.choice([1.0, 2.0, 3.0])
+    rc, flags, keep = ctx.outlier_rows(vals, lens, "zscore", minsize=10, zscore_cutoff=cutoff, mincluster=3)
+    ctx.set_option("outlier_tile", 0)
+    try:
+        rc2, flags2, keep2 = ctx.outlier_rows(vals, lens, "zscore", minsize=10, zscore_cutoff=cutoff, mincluster=3)
+    finally:
+        ctx.set_option("outlier_tile", 1)
+    assert rc == rc2 == 0 and np.array_equal(flags, flags2) and np.array_equal(keep, keep2)
+    for i in range(0, len(lens), 7):
+        row = [np.float32(0) if np.isnan(x) else x for x in vals[i, : lens[i]]]
+        if row and max(row) >= np.float32(10):
+            assert keep[i] == 1 and list(flags[i, : lens[i]].astype(bool)) == oo.z_score_flags(row, cutoff), i
+    assert keep.tolist().count(1) > 50
+
+
 @pytest.mark.parametrize("method", ["zscore", "dbscan"])
 def test_outlier_command_text(tmp_path, method):
     rng = random.Random(77)
