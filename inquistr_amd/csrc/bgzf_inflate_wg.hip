@@ -72,29 +72,72 @@ constexpr int kMaxLit = 288, kMaxDist = 32;
 
 constexpr uint32_t E_LIT = 0u, E_LEN = 1u, E_EOB = 2u, E_LONG = 3u;
 // table entry: bits 0-3 code length (0 = not a code), 4-5 type, 6 = everything the decode loop leaves its fast path for
-// (end of block, not a code, a code longer than the table's index), 8-11 extra bits, 16-31 literal / base value
+// (end of block, not a code, a code longer than the table's index), and
+//   32-bit form (INQ_WG_LUT16 = 0): 8-11 extra bits, 16-31 literal / base value
+//   16-bit form (INQ_WG_LUT16 = 1): 7-15 a literal's byte, or a length / distance symbol's INDEX - extra bits and base are
+//     arithmetic in the index (RFC 1951 3.2.5), a handful of operations on the match path in exchange for 2.5 KB of LDS
+//     (17.9 instead of 20.4 KB per workgroup: nine BGZF blocks in flight per CU instead of eight)
+#ifndef INQ_WG_LUT16
+#define INQ_WG_LUT16 0
+#endif
 constexpr uint32_t kSpecial = 0x40u;
 constexpr uint32_t kLongEntry = (E_LONG << 4) | kSpecial;  // code longer than the table's index: canonical path
 constexpr uint32_t kNoCode = kSpecial;
+#if INQ_WG_LUT16
+typedef uint16_t lut_t;
+constexpr uint32_t kValShift = 7u;
+__device__ __forceinline__ uint32_t mk_entry(uint32_t n, uint32_t type, uint32_t, uint32_t val) { return n | (type << 4) | (val << kValShift); }
+__device__ __forceinline__ uint32_t len_xbits(uint32_t e) {
+    const uint32_t s = e >> kValShift;
+    return (s < 8u || s == 28u) ? 0u : (s - 4u) >> 2;
+}
+__device__ __forceinline__ uint32_t len_base(uint32_t e, uint32_t xb) {
+    const uint32_t s = e >> kValShift;
+    return s < 8u ? 3u + s : s == 28u ? 258u : 3u + ((4u + (s & 3u)) << xb);
+}
+__device__ __forceinline__ uint32_t dist_xbits(uint32_t d) {
+    const uint32_t s = d >> kValShift;
+    return s < 4u ? 0u : (s - 2u) >> 1;
+}
+__device__ __forceinline__ uint32_t dist_base(uint32_t d, uint32_t xb) {
+    const uint32_t s = d >> kValShift;
+    return s < 4u ? 1u + s : 1u + ((2u + (s & 1u)) << xb);
+}
+#else
+typedef uint32_t lut_t;
+constexpr uint32_t kValShift = 16u;
 __device__ __forceinline__ uint32_t mk_entry(uint32_t n, uint32_t type, uint32_t xb, uint32_t val) {
     return n | (type << 4) | (xb << 8) | (val << 16);
 }
+__device__ __forceinline__ uint32_t len_xbits(uint32_t e) { return (e >> 8) & 15u; }
+__device__ __forceinline__ uint32_t len_base(uint32_t e, uint32_t) { return e >> 16; }
+__device__ __forceinline__ uint32_t dist_xbits(uint32_t d) { return (d >> 8) & 15u; }
+__device__ __forceinline__ uint32_t dist_base(uint32_t d, uint32_t) { return d >> 16; }
+#endif
 // RFC 1951 3.2.5: literal/length symbol -> entry
 __device__ __forceinline__ uint32_t ll_entry(uint32_t sym, uint32_t n) {
     if (sym < 256u) return mk_entry(n, E_LIT, 0u, sym);
     if (sym == 256u) return mk_entry(n, E_EOB, 0u, 0u) | kSpecial;
     const uint32_t s = sym - 257u;
     if (s >= 29u) return kNoCode;  // 286, 287 take part in the fixed code but never appear in valid data
+#if INQ_WG_LUT16
+    return mk_entry(n, E_LEN, 0u, s);
+#else
     if (s < 8u) return mk_entry(n, E_LEN, 0u, 3u + s);
     if (s == 28u) return mk_entry(n, E_LEN, 0u, 258u);
     const uint32_t xb = (s - 4u) >> 2;
     return mk_entry(n, E_LEN, xb, 3u + ((4u + (s & 3u)) << xb));
+#endif
 }
 __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t n) {
     if (sym >= 30u) return kNoCode;
+#if INQ_WG_LUT16
+    return mk_entry(n, E_LEN, 0u, sym);
+#else
     if (sym < 4u) return mk_entry(n, E_LEN, 0u, 1u + sym);
     const uint32_t xb = (sym - 2u) >> 1;
     return mk_entry(n, E_LEN, xb, 1u + ((2u + (sym & 1u)) << xb));
+#endif
 }
 
 template <int T>
@@ -109,8 +152,8 @@ struct WgLds {
     static_assert((kRoundCap & (kRoundCap - 1)) == 0 && kRoundCap >= 1024 && kRoundCap <= 16384, "root indices are masked with kRoundCap - 1; 32768 + kRoundCap stays below the literal range");
     static_assert(kSegBits % 64 == 0 && kSegBits >= 128, "segments are whole dwords, and half a segment is longer than the longest symbol (48 bits)");
     static_assert(T * kSegBits + 64 <= 65536, "bit positions of a round fit 16 bits (start_sh, mid_sh)");
-    uint32_t lut_ll[1 << kLitBits];
-    uint32_t lut_d[1 << kDistBits];
+    lut_t lut_ll[1 << kLitBits];
+    lut_t lut_d[1 << kDistBits];
     uint32_t stage[kStage];
     // root of every output byte of the stretch being committed: a literal's value, or where a match byte is copied from
     // as position - (stretch start - 32768)
@@ -348,7 +391,7 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
 #if !INQ_WG_LITFIRST
         lit = !(e & (E_LEN << 4));
 #endif
-        const uint32_t n = e & 15u, xb = (e >> 8) & 15u;  // a literal has no extra bits
+        const uint32_t n = e & 15u, xb = INQ_WG_LUT16 && lit ? 0u : len_xbits(e);  // a literal has no extra bits
         constexpr bool PAIR = FORM == 1;
         if constexpr (PAIR) {
             if (lit) {
@@ -364,18 +407,18 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
                 const bool two = !(e2 & (kSpecial | (E_LEN << 4))) && b.pos + n < lim;
                 b.consume(n + (two ? (e2 & 15u) : 0u));
                 if (MODE == 2) {
-                    out[o + nb] = (uint8_t)(e >> 16);
-                    if (two) out[o + nb + 1u] = (uint8_t)(e2 >> 16);
+                    out[o + nb] = (uint8_t)(e >> kValShift);
+                    if (two) out[o + nb + 1u] = (uint8_t)(e2 >> kValShift);
                 }
                 if (MODE == 1) {  // the bytes themselves: stored by the gather, coalesced
-                    L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));
-                    if (two) L.root[o + nb + 1u - r0] = (uint16_t)(kRootLit | (e2 >> 16));
+                    L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> kValShift));
+                    if (two) L.root[o + nb + 1u - r0] = (uint16_t)(kRootLit | (e2 >> kValShift));
                 }
                 if (MODE == 0 && tok) {
-                    if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
+                    if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> kValShift);
                     ++nt;
                     if (two) {
-                        if (nt < kTokCap) tok[nt * T] = kTokLit | (e2 >> 16);
+                        if (nt < kTokCap) tok[nt * T] = kTokLit | (e2 >> kValShift);
                         ++nt;
                     }
                 }
@@ -386,17 +429,17 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
         } else {
             b.consume(n + xb);
             if (lit) {
-                if (MODE == 2) out[o + nb] = (uint8_t)(e >> 16);
-                if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> 16));  // the byte itself: stored by the gather, coalesced
+                if (MODE == 2) out[o + nb] = (uint8_t)(e >> kValShift);
+                if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> kValShift));  // the byte itself: stored by the gather, coalesced
                 if (MODE == 0 && tok) {
-                    if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> 16);
+                    if (nt < kTokCap) tok[nt * T] = kTokLit | (e >> kValShift);
                     ++nt;
                 }
                 ++nb;
                 continue;
             }
         }
-        const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(bits, n, xb);
+        const uint32_t len = len_base(e, xb) + __builtin_amdgcn_ubfe(bits, n, xb);
         const uint32_t dbits = b.peek();
         uint32_t d = L.lut_d[dbits & ((1u << kDistBits) - 1u)];
         if (d & kSpecial) {
@@ -407,8 +450,8 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
             }
         }
         const uint32_t dn = d & 15u;
-        const uint32_t dxb = (d >> 8) & 15u;
-        const uint32_t dist = (d >> 16) + __builtin_amdgcn_ubfe(dbits, dn, dxb);
+        const uint32_t dxb = dist_xbits(d);
+        const uint32_t dist = dist_base(d, dxb) + __builtin_amdgcn_ubfe(dbits, dn, dxb);
         b.consume(dn + dxb);
         if (MODE == 0 && tok) {
             if (nt < kTokCap) tok[nt * T] = (len << 16) | (dist - 1u);
@@ -737,7 +780,7 @@ __device__ void build_tables(WgLds<T> &L, int tid) {
     __syncthreads();
     // an entry's code length is the number of limits its pattern is not below (they grow with the length): the limits are read once,
     // the count has no dependent LDS read in it
-    auto fill = [&](auto tbl_c, uint32_t *lut, int bits) {
+    auto fill = [&](auto tbl_c, lut_t *lut, int bits) {
         constexpr int tbl = decltype(tbl_c)::value;
         uint32_t lim[16];
 #pragma unroll
@@ -753,7 +796,7 @@ __device__ void build_tables(WgLds<T> &L, int tid) {
                 if (tbl == 0) ent = idx < (uint32_t)kMaxLit ? ll_entry(L.sorted[idx], len) : kNoCode;
                 else ent = idx < (uint32_t)kMaxDist ? dist_entry(L.sorted[kMaxLit + idx], len) : kNoCode;
             }
-            lut[e] = ent;
+            lut[e] = (lut_t)ent;
         }
     };
     fill(std::integral_constant<int, 0>{}, L.lut_ll, kLitBits);
