@@ -391,7 +391,11 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
 #if !INQ_WG_LITFIRST
         lit = !(e & (E_LEN << 4));
 #endif
-        const uint32_t n = e & 15u, xb = INQ_WG_LUT16 && lit ? 0u : len_xbits(e);  // a literal has no extra bits
+#if INQ_WG_LUT16
+        const uint32_t n = e & 15u;  // (extra bits: computed on the match path only, below)
+#else
+        const uint32_t n = e & 15u, xb = len_xbits(e);  // a literal has no extra bits
+#endif
         constexpr bool PAIR = FORM == 1;
         if constexpr (PAIR) {
             if (lit) {
@@ -425,9 +429,12 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
                 nb += two ? 2u : 1u;
                 continue;
             }
-            b.consume(n + xb);
         } else {
+#if INQ_WG_LUT16
+            if (lit) b.consume(n);
+#else
             b.consume(n + xb);
+#endif
             if (lit) {
                 if (MODE == 2) out[o + nb] = (uint8_t)(e >> kValShift);
                 if (MODE == 1) L.root[o + nb - r0] = (uint16_t)(kRootLit | (e >> kValShift));  // the byte itself: stored by the gather, coalesced
@@ -439,6 +446,12 @@ __device__ __forceinline__ uint32_t decode_segment(WgLds<T> &L, uint32_t start, 
                 continue;
             }
         }
+#if INQ_WG_LUT16
+        const uint32_t xb = len_xbits(e);
+        b.consume(n + xb);
+#else
+        if constexpr (PAIR) b.consume(n + xb);
+#endif
         const uint32_t len = len_base(e, xb) + __builtin_amdgcn_ubfe(bits, n, xb);
         const uint32_t dbits = b.peek();
         uint32_t d = L.lut_d[dbits & ((1u << kDistBits) - 1u)];
