@@ -107,12 +107,12 @@ __device__ __forceinline__ uint32_t dist_base(uint32_t d, uint32_t xb) {
 typedef uint32_t lut_t;
 constexpr uint32_t kValShift = 16u;
 __device__ __forceinline__ uint32_t mk_entry(uint32_t n, uint32_t type, uint32_t xb, uint32_t val) {
-    return n | (type << 4) | (xb << 8) | (val << 16);
+    return n | (type << 4) | (xb << 8) | (val << kValShift);
 }
 __device__ __forceinline__ uint32_t len_xbits(uint32_t e) { return (e >> 8) & 15u; }
-__device__ __forceinline__ uint32_t len_base(uint32_t e, uint32_t) { return e >> 16; }
+__device__ __forceinline__ uint32_t len_base(uint32_t e, uint32_t) { return e >> kValShift; }
 __device__ __forceinline__ uint32_t dist_xbits(uint32_t d) { return (d >> 8) & 15u; }
-__device__ __forceinline__ uint32_t dist_base(uint32_t d, uint32_t) { return d >> 16; }
+__device__ __forceinline__ uint32_t dist_base(uint32_t d, uint32_t) { return d >> kValShift; }
 #endif
 // RFC 1951 3.2.5: literal/length symbol -> entry
 __device__ __forceinline__ uint32_t ll_entry(uint32_t sym, uint32_t n) {
