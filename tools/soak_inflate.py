@@ -26,6 +26,15 @@ for r in range(rounds):
     finally:
         random.Random = orig
     print(f"round {r}: 4000 damaged streams agree with zlib", flush=True)
+    from tools import libdeflate_shim
+
+    if libdeflate_shim.available():  # the same with originals written by libdeflate (levels 1 - 12)
+        random.Random = Seeded
+        try:
+            t.test_inflate_fuzz_on_mutated_libdeflate_streams(ctx)
+        finally:
+            random.Random = orig
+        print(f"round {r}: 3000 damaged libdeflate-written streams agree with zlib", flush=True)
 print(f"inflate soak done: {rounds} rounds, 0 disagreements")
 
 # ---- valid streams of many shapes, thousands of blocks per launch, both kernels, bytes against the input
