@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <type_traits>
 
 #include "../../include/inquistr_hip.h"
 #include "front_kernels.h"
@@ -72,20 +73,20 @@ __global__ __launch_bounds__(256) void outlier_zscore_kernel(OutlierArgs a, cons
 // The same arithmetic for rows of at most kOutlierTileMaxStride (256) values, ONE read of the matrix instead of five (transpose: read + write,
 // three passes over the transposed copy): a wave copies R whole rows - R * stride contiguous floats of the row-major matrix,
 // coalesced - into an LDS tile whose row pitch is odd (lane r walks row r: no bank conflicts), then lane r runs the three passes
-// over ITS row out of LDS, every f32 operation in the reference's order as above.  R = 64 rows up to 128 values, 32 up to 256
-// (33 KB of LDS per wave either way: four waves per CU, each with up to 32 KB of loads in flight).
-template <int R, bool VEC4>
+// over ITS row out of LDS, every f32 operation in the reference's order as above.  R = 64 rows up to 64 values, 32 beyond (16.6 KB of
+// LDS per wave = nine waves per CU up to 128 values, 33 KB up to 256), each wave with its whole tile of loads in flight.
+template <int R, int MAXS, bool VEC4>
 __global__ __launch_bounds__(64) void outlier_zscore_tile_kernel(OutlierArgs a) {
     extern __shared__ float tile[];
     const uint32_t stride = a.stride, pitch = stride | 1u, lane = threadIdx.x;
     const uint64_t row0 = (uint64_t)blockIdx.x * (uint32_t)R;
     const uint32_t rows_here = (uint32_t)(a.n_rows - row0 < (uint64_t)R ? a.n_rows - row0 : (uint64_t)R);
     const float *src = a.values + row0 * (uint64_t)stride;
-    const uint32_t total = rows_here * stride;  // <= 8 192 floats: 64 rows of <= 128 values, or 32 of <= 256
+    const uint32_t total = rows_here * stride;  // <= R * MAXS floats
     if (VEC4) {
         // stride % 4 == 0: rows begin on 16-byte boundaries and no float4 straddles two rows.  ALL of a lane's loads (<= 32 x 16 B, the
         // whole tile = 32 KB per wave) are issued before the first one is waited for: four waves per CU keep 128 KB in flight
-        constexpr int kPerLane = 32;
+        constexpr int kPerLane = R * MAXS / 256;  // the tile's float4s dealt over 64 lanes
         typedef float f4 __attribute__((ext_vector_type(4)));
         f4 v[kPerLane];
         const f4 *src4 = reinterpret_cast<const f4 *>(src);
@@ -353,13 +354,18 @@ void launch_outlier(const OutlierArgs &a, int method, float *transposed, hipStre
     if (method == INQ_OUTLIER_ZSCORE && a.stride && a.stride <= kOutlierTileMaxStride && use_tile) {
         const uint32_t pitch = a.stride | 1u;
         const bool vec4 = a.stride % 4u == 0u && (reinterpret_cast<uintptr_t>(a.values) & 15u) == 0u;
-        if (a.stride <= 128u) {
-            if (vec4) hipLaunchKernelGGL((outlier_zscore_tile_kernel<64, true>), dim3((uint32_t)((a.n_rows + 63) / 64)), dim3(64), 64u * pitch * 4u, s, a);
-            else hipLaunchKernelGGL((outlier_zscore_tile_kernel<64, false>), dim3((uint32_t)((a.n_rows + 63) / 64)), dim3(64), 64u * pitch * 4u, s, a);
-        } else {
-            if (vec4) hipLaunchKernelGGL((outlier_zscore_tile_kernel<32, true>), dim3((uint32_t)((a.n_rows + 31) / 32)), dim3(64), 32u * pitch * 4u, s, a);
-            else hipLaunchKernelGGL((outlier_zscore_tile_kernel<32, false>), dim3((uint32_t)((a.n_rows + 31) / 32)), dim3(64), 32u * pitch * 4u, s, a);
-        }
+        auto go = [&](auto rows_c, auto maxs_c) {
+            constexpr int R = decltype(rows_c)::value, MAXS = decltype(maxs_c)::value;
+            const dim3 grid((uint32_t)((a.n_rows + R - 1) / R));
+            if (vec4) hipLaunchKernelGGL((outlier_zscore_tile_kernel<R, MAXS, true>), grid, dim3(64), (uint32_t)R * pitch * 4u, s, a);
+            else hipLaunchKernelGGL((outlier_zscore_tile_kernel<R, MAXS, false>), grid, dim3(64), (uint32_t)R * pitch * 4u, s, a);
+        };
+        // rows per wave, measured (profiles/r05_results/outlier_zscore_lds_tile.txt): 16.6 KB of LDS = nine waves per CU up to 128
+        // values (the passes are chains of dependent operations: other waves are what hides them); wider rows keep 32 rows per wave
+        // (33 KB, four waves per CU: with 16 rows three quarters of the lanes idle through passes twice as long)
+        if (a.stride <= 64u) go(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
+        else if (a.stride <= 128u) go(std::integral_constant<int, 32>{}, std::integral_constant<int, 128>{});
+        else go(std::integral_constant<int, 32>{}, std::integral_constant<int, 256>{});
     } else if (method == INQ_OUTLIER_ZSCORE) {
         const uint64_t rows_padded = outlier_rows_padded(a.n_rows);
         if (a.stride)
