@@ -440,9 +440,22 @@ SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamFile &ba
     // A/B switches of rounds 2 - 3, read only by a build with -DINQ_DEBUG_ENV
     if (const char *pin_env = debug_env("INQ_SPAN_PINNED")) pinned = pin_env[0] == '1';
     if (debug_env("INQ_GATE_READS")) gate = [&actx] { (void)actx.wait(); };
+    // A file (or this caller's share of it) of less than 2 GB is cut into ~8 spans, not into 256 MB ones: with three spans the device
+    // idles through the first upload and the last inflate (0.8 GB CIGAR-only file on a resident context: 53.4 ms at 256 MB, 48.4 at
+    // 128, 49.8 at 64, 55.6 at 32; files of 1.9 GB and more: 256 MB is as quick or quicker - profiles/r05_results/span_size_for_small_files.txt).
+    // INQ_SPAN_MB fixes the size.
+    uint64_t span_bytes = span_bytes_from_env();
+    if (!std::getenv("INQ_SPAN_MB")) {
+        struct stat st;
+        if (::stat(args->bam, &st) == 0 && st.st_size > 0) {
+            const uint64_t share = (uint64_t)st.st_size / (uint64_t)std::max(1, sharers);
+            const uint64_t want = ((share / 8u) + (16ull << 20) - 1) / (16ull << 20) * (16ull << 20);
+            span_bytes = std::min<uint64_t>(span_bytes, std::max<uint64_t>(want, 64ull << 20));
+        }
+    }
     // the loader uploads every span it has read (waiting for the context the first time), so that the upload of span k+1
     // overlaps the inflate of span k
-    return new SpanPipeline(args->bam, bam, targets, span_bytes_from_env(), span_io_threads(args, sharers), pinned,
+    return new SpanPipeline(args->bam, bam, targets, span_bytes, span_io_threads(args, sharers), pinned,
                             [&actx](const inq_span_t &sp, int slot) { return actx.wait_stage() && inq_span_stage_begin(actx.ctx, &sp, slot) == INQ_OK; },
                             slot_base, pool, gate,
                             [&actx, dev = args->device]() -> int {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of one host-library environment switch on a RESIDENT context: a session calls the same file N times with the switch at each
-of its values in turn (GPU box; by hand).  usage: python tools/session_ab.py NAME=v0,v1 workload loci seq(0/1) [runs]"""
+of its values in turn (GPU box; by hand).  usage: python tools/session_ab.py NAME=v0,v1 workload loci seq(0/1) [runs]   (a value "-" = the variable unset)"""
 import os, statistics, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 name, vals = sys.argv[1].split("=")
@@ -20,13 +20,22 @@ for _ in range(2):
 print(f"{wl} {loci} loci seq={seq}: {os.path.getsize(prefix + '.bam') / 1e6:.0f} MB")
 un = synth.WORKLOADS[wl].unphased
 res = {v: [] for v in vals}
+
+
+def setv(v):  # "-" = the variable unset
+    if v == "-":
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = v
+
+
 with call.Session(0) as S, open(os.devnull, "w") as out:
     for v in vals:  # warm
-        os.environ[name] = v
+        setv(v)
         S.call(prefix + ".bam", region_file=prefix + ".bed", threads=16, unphased=un, sample_name="S", out=out, frontend="device")
     for r in range(runs):
         for v in vals:
-            os.environ[name] = v
+            setv(v)
             t = time.perf_counter()
             S.call(prefix + ".bam", region_file=prefix + ".bed", threads=16, unphased=un, sample_name="S", out=out, frontend="device")
             res[v].append(time.perf_counter() - t)
