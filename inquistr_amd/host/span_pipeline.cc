@@ -444,8 +444,11 @@ SpanPipeline *start_span_pipeline(const inq_call_args_t *args, const BamFile &ba
     // idles through the first upload and the last inflate (0.8 GB CIGAR-only file on a resident context: 53.4 ms at 256 MB, 48.4 at
     // 128, 49.8 at 64, 55.6 at 32; files of 1.9 GB and more: 256 MB is as quick or quicker - profiles/r05_results/span_size_for_small_files.txt).
     // INQ_SPAN_MB fixes the size.
+    // Only for a device that is READY (a session's later files, a resident rank, a server): a process that has just started reads four
+    // spans ahead while its context is being made, and the more bytes those hold the better (the CLI's loop on that file: 21.5 ms
+    // with 256 MB spans, 26.8 with 112 MB ones).
     uint64_t span_bytes = span_bytes_from_env();
-    if (!std::getenv("INQ_SPAN_MB")) {
+    if (!std::getenv("INQ_SPAN_MB") && actx.ready.load()) {
         struct stat st;
         if (::stat(args->bam, &st) == 0 && st.st_size > 0) {
             const uint64_t share = (uint64_t)st.st_size / (uint64_t)std::max(1, sharers);
