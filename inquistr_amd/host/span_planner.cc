@@ -501,15 +501,22 @@ bool SpanLoader::load(const SpanPlan &p, BaiAnchors &anch, uint8_t *buf, int n_t
             std::vector<uint64_t>().swap(j.starts);
         }
         const uint64_t seg_u_end = uo;
+        // (the anchors come in ascending order, and so do the blocks: the search for an anchor's block starts where the last one
+        // ended and usually ends there or a step further - a CIGAR-only file has 35 000 anchors per 100 MB, and a binary search for
+        // each was 1.5 ms of the loader's 2.7 ms per span)
+        size_t cursor = 0;
         auto map_vo = [&](uint64_t v, uint64_t *u) -> bool {
             const uint64_t co = v >> 16, within = v & 0xffff;
             if (co == pc.end && within == 0) {
                 *u = seg_u_end;
                 return true;
             }
-            auto it = std::lower_bound(starts.begin(), starts.end(), co);
-            if (it == starts.end() || *it != co) return false;
-            const inq_bgzf_block_t &b = out.blocks[first_block + (size_t)(it - starts.begin())];
+            if (cursor >= starts.size() || starts[cursor] > co) cursor = 0;  // (an offset that goes backwards: start over)
+            size_t steps = 0;
+            while (cursor < starts.size() && starts[cursor] < co && steps < 8) ++cursor, ++steps;
+            if (cursor < starts.size() && starts[cursor] < co) cursor = (size_t)(std::lower_bound(starts.begin() + (long)cursor, starts.end(), co) - starts.begin());
+            if (cursor >= starts.size() || starts[cursor] != co) return false;
+            const inq_bgzf_block_t &b = out.blocks[first_block + cursor];
             if (within > b.isize) return false;
             *u = b.out_off + within;
             return true;
