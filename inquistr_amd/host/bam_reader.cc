@@ -8,11 +8,44 @@
 
 namespace inqhost {
 
-static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
-static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-static inline uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+// (little-endian host: x86-64, the only host of a gfx950 box; one load each instead of byte-wise assembly - an index holds 10^5 - 10^6 of them)
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "little-endian host");
+static inline uint16_t le16(const uint8_t *p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+static inline uint32_t le32(const uint8_t *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+static inline uint64_t le64(const uint8_t *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
 
 // ---------------- BAI ----------------
+
+void BinMap::seal() {
+    // bin ids of a .bai are below 37 451: a counting sort; anything wider (.csi with a deep binning) goes through std::stable_sort
+    uint32_t mx = 0;
+    bool sorted = true;
+    for (size_t i = 0; i < entries_.size(); ++i) {
+        mx = std::max(mx, entries_[i].first);
+        if (i && entries_[i].first < entries_[i - 1].first) sorted = false;
+    }
+    if (!sorted) {
+        if (mx < (1u << 17)) {
+            std::vector<uint32_t> start((size_t)mx + 2, 0u);
+            for (const Entry &e : entries_) ++start[(size_t)e.first + 1];
+            for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+            std::vector<Entry> out(entries_.size());
+            for (const Entry &e : entries_) out[start[e.first]++] = e;
+            entries_.swap(out);
+        } else {
+            std::stable_sort(entries_.begin(), entries_.end(), [](const Entry &a, const Entry &b) { return a.first < b.first; });
+        }
+    }
+    fix();
+}
+
+void BinMap::fix() {
+    for (Entry &e : entries_) e.second.b = chunks_.data() + e.at;
+}
+
+BinMap::const_iterator BinMap::lower_bound(uint32_t bin) const {
+    return std::lower_bound(begin(), end(), bin, [](const Entry &e, uint32_t b) { return e.first < b; });
+}
 
 bool BaiIndex::load(const std::string &path, std::string *err) {
     FILE *f = std::fopen(path.c_str(), "rb");
@@ -56,10 +89,10 @@ bool BaiIndex::load(const std::string &path, std::string *err) {
                     R.n_mapped = le64(&d[p + 16]);
                     R.n_unmapped = le64(&d[p + 24]);
                 } else {
-                    auto &v = R.bins[bin];
+                    BinMap::Chunk *v = R.bins.add(bin, n_chunk);
                     for (uint32_t c = 0; c < n_chunk; ++c) {
                         uint64_t beg = le64(&d[p + 16 * c]), end = le64(&d[p + 16 * c + 8]);
-                        v.emplace_back(beg, end);
+                        v[c] = BinMap::Chunk(beg, end);
                         if (first || beg < R.min_offset) R.min_offset = beg;
                         if (first || end > R.max_offset) R.max_offset = end;
                         first = false;
@@ -67,6 +100,7 @@ bool BaiIndex::load(const std::string &path, std::string *err) {
                 }
                 p += (size_t)n_chunk * 16;
             }
+            R.bins.seal();
             if (!need(4)) goto trunc;
             uint32_t n_intv = le32(&d[p]);
             p += 4;
@@ -137,7 +171,7 @@ bool BaiIndex::load_csi(const std::string &path, std::string *err) {
                     R.n_mapped = le64(&d[p + 16]);
                     R.n_unmapped = le64(&d[p + 24]);
                 } else {
-                    auto &v = R.bins[bin];
+                    BinMap::Chunk *v = R.bins.add(bin, n_chunk);
                     R.loff[bin] = loffset;
                     if (n_chunk && bin < level_first(depth + 1)) {
                         int l = 0;
@@ -146,7 +180,7 @@ bool BaiIndex::load_csi(const std::string &path, std::string *err) {
                     }
                     for (uint32_t c = 0; c < n_chunk; ++c) {
                         const uint64_t beg = le64(&d[p + 16 * c]), end = le64(&d[p + 16 * c + 8]);
-                        v.emplace_back(beg, end);
+                        v[c] = BinMap::Chunk(beg, end);
                         if (first || beg < R.min_offset) R.min_offset = beg;
                         if (first || end > R.max_offset) R.max_offset = end;
                         first = false;
@@ -154,6 +188,7 @@ bool BaiIndex::load_csi(const std::string &path, std::string *err) {
                 }
                 p += (size_t)n_chunk * 16;
             }
+            R.bins.seal();
         }
         if (need(8)) n_no_coor = le64(&d[p]);
     }

@@ -21,8 +21,60 @@ struct BamRef {
     int64_t len = 0;
 };
 
+// The bins of one contig: bin id -> its chunks.  What the code needs of a std::map<uint32_t, std::vector<chunk>> - iteration in bin
+// order with ->first / ->second, lower_bound, the chunks as a range - without a tree node and a vector allocation per bin: a
+// whole-genome index holds 10^5 bins, and building the map was 8 of the 10 ms an open took (every rank of a multi-GPU run opens).
+// Entries are appended while the index is parsed (add), then sorted once (seal); the chunks of all bins lie in one array.
+class BinMap {
+public:
+    typedef std::pair<uint64_t, uint64_t> Chunk;
+    struct Chunks {  // the chunks of one bin, as a range
+        const Chunk *b = nullptr;
+        uint32_t n = 0;
+        const Chunk *begin() const { return b; }
+        const Chunk *end() const { return b + n; }
+        bool empty() const { return n == 0; }
+        size_t size() const { return n; }
+        const Chunk &operator[](size_t i) const { return b[i]; }
+    };
+    struct Entry {
+        uint32_t first = 0;  // bin id
+        Chunks second;
+        uint32_t at = 0;     // (index of the first chunk in the array, until seal() turns it into the pointer)
+    };
+    typedef const Entry *const_iterator;
+    // parsing: room for `n` more chunks of bin `bin`; returns where to write them
+    Chunk *add(uint32_t bin, uint32_t n) {
+        Entry e;
+        e.first = bin, e.second.n = n, e.at = (uint32_t)chunks_.size();
+        entries_.push_back(e);
+        chunks_.resize(chunks_.size() + n);
+        return chunks_.data() + e.at;
+    }
+    void reserve(size_t bins, size_t chunks) { entries_.reserve(bins), chunks_.reserve(chunks); }
+    void seal();  // sorts by bin id (stable: equal ids keep file order), fixes the pointers
+    BinMap() = default;
+    BinMap(BinMap &&) = default;  // (a moved vector keeps its storage: the pointers stay good)
+    BinMap &operator=(BinMap &&) = default;
+    BinMap(const BinMap &o) : entries_(o.entries_), chunks_(o.chunks_) { fix(); }
+    BinMap &operator=(const BinMap &o) {
+        if (this != &o) entries_ = o.entries_, chunks_ = o.chunks_, fix();
+        return *this;
+    }
+    bool empty() const { return entries_.empty(); }
+    size_t size() const { return entries_.size(); }
+    const_iterator begin() const { return entries_.data(); }
+    const_iterator end() const { return entries_.data() + entries_.size(); }
+    const_iterator lower_bound(uint32_t bin) const;
+
+private:
+    void fix();  // entries' chunk pointers from their indices
+    std::vector<Entry> entries_;
+    std::vector<Chunk> chunks_;
+};
+
 struct BaiRef {
-    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    BinMap bins;
     std::map<uint32_t, uint64_t> loff;  // .csi only: per bin, the smallest offset of a record overlapping the bin's first window
     std::vector<uint64_t> ioffset;  // .bai only: 16 kb linear index
     uint64_t n_mapped = 0, n_unmapped = 0;
